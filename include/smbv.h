@@ -1,0 +1,158 @@
+/* smbv.h — C ABI of libsmbv.so: the MI355X (gfx950) hot path of the smb-vision 3-D masked-image-modeling train step.
+ *
+ * Drop-in boundary: the reference has no native code and no FFI; its hot path is reached through the
+ * Python model-class interface called by HF Trainer (reference src/run_mim.py:345-357, 429-436).  This library is what
+ * the Python mirror of that interface (smb_vision_amd/modeling_videomae.py) binds with ctypes; INTEGRATION.md shows the
+ * stub a maintainer of the reference would add.  Each entry point names the reference code it replaces (paths relative
+ * to the reference repo root; "spec" = src/models/videomae/modeling_videomae.py).
+ *
+ * Conventions for EVERY function:
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise;
+ *   - the caller owns every buffer, including workspaces; the library never allocates or frees device memory,
+ *     never synchronises, never changes the current device; work is enqueued on `stream` (a hipStream_t);
+ *   - bf16 tensors are uint16 storage; matrices are row-major with an explicit leading dimension where one is taken;
+ *   - pointers must be 16-byte aligned unless noted;
+ *   - return value: 0 = ok, negative = SMBV_ERR_* (bad shape / alignment / argument / workspace), positive = hipError_t;
+ *     smbv_last_error() returns the message of the calling thread's last failure; no C++ exception crosses the ABI;
+ *   - re-entrant and stream-ordered; safe from autograd's backward thread.
+ */
+#ifndef SMBV_H
+#define SMBV_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMBV_OK 0
+#define SMBV_ERR_SHAPE (-1)
+#define SMBV_ERR_ALIGN (-2)
+#define SMBV_ERR_ARG (-3)
+#define SMBV_ERR_WORKSPACE (-4)
+#define SMBV_MAX_LAYERS 48
+
+typedef void* smbv_stream;   /* hipStream_t */
+typedef uint16_t smbv_bf16;
+
+int smbv_version(void);                                   /* ABI version (major*1000 + minor) */
+int smbv_last_error(char* buf, size_t len);               /* copies the thread's last error text; returns its length */
+
+/* ---- per-op entry points (also what the parity tests call) ------------------------------------------------------ */
+
+/* Epilogue of smbv_gemm_nt (all optional; see csrc/smbv_kernels.h GemmEpi). */
+typedef struct smbv_gemm_epi {
+  float alpha;
+  const float* bias;
+  const float* rowadd; const int32_t* rowidx; int ldr;
+  const smbv_bf16* dgelu_pre; int ld_pre;
+  int act_gelu; smbv_bf16* aux_pre; int ld_aux;
+  smbv_bf16* out_bf16; int ld_ob;
+  float* out_f32; int ld_of;
+  int grp_in, grp_out;
+} smbv_gemm_epi;
+
+/* C[M,N] = epi(A[M,K] · B[N,K]^T): every nn.Linear forward of the path (spec :261-264, :311-313, :368-370, :384-386,
+ * :801-803, :720-722) with B = the HF weight [out,in]; and their input gradients with B = a transposed bf16 copy. */
+int smbv_gemm_nt(const smbv_bf16* A, int lda, const smbv_bf16* B, int ldb, int M, int N, int K, const smbv_gemm_epi* epi,
+                 smbv_stream stream);
+/* out[N1,N2] (fp32) = sum_m X[m,N1] · Y[m,N2]: the weight gradients of the same Linears (autograd of the above). */
+int smbv_gemm_tn(const smbv_bf16* X, int ldx, const smbv_bf16* Y, int ldy, int M, int N1, int N2, float* out, void* ws,
+                 size_t ws_bytes, smbv_stream stream);
+size_t smbv_gemm_tn_workspace_bytes(int M, int N1, int N2);
+
+/* nn.LayerNorm over the last dim (spec :402-403, :412, :423, :676/:721); y is the bf16 GEMM operand.
+ * Input rows are read at (row / grp_in) * grp_out + row % grp_in + row_off when grp_in > 0. */
+int smbv_layernorm_fwd(const float* x, const float* gamma, const float* beta, smbv_bf16* y, float* mean, float* rstd, int rows,
+                       int D, float eps, long grp_in, long grp_out, long row_off, smbv_stream stream);
+int smbv_layernorm_bwd(const smbv_bf16* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       const float* dres, float* dx, smbv_bf16* dx_bf16, float* dgamma, float* dbeta, int rows, int D, long grp_in,
+                       long grp_out, long row_off, void* ws, size_t ws_bytes, smbv_stream stream);
+size_t smbv_layernorm_bwd_workspace_bytes(int rows, int D);
+
+/* softmax_fp32(Q K^T * scale) V, head_dim 64 (spec :196-223, dispatched at :270-289).  Q,K,V: column slices of one
+ * token-major [B*S, ld] matrix (head h at columns h*64..); O: [B*S, ldo]; LSE/delta: fp32 [B,H,S]. */
+int smbv_attention_fwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, smbv_bf16* O, int ldo, float* LSE,
+                       int B, int S, int H, int Dh, float scale, smbv_stream stream);
+int smbv_attention_bwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* dO,
+                       int ldo, const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S,
+                       int H, int Dh, float scale, smbv_stream stream);
+
+/* Brick readers over pixel_values fp32 [B,T,1,H,W] (spec :172-177,190-191 Conv3d patchify; :835-867 labels; :896-897 MSE).
+ * idx: int32 token ids (0..N-1) of the selected bricks, `per_batch` per volume, rows = B*per_batch. */
+int smbv_gather_bricks(const float* pix, const int32_t* idx, int rows, int per_batch, smbv_bf16* out, int T, int H, int W, int ts,
+                       int ps, smbv_stream stream);
+int smbv_brick_stats(const float* pix, const int32_t* idx, int rows, int per_batch, float* mean, float* rinv, int T, int H, int W,
+                     int ts, int ps, smbv_stream stream);
+int smbv_mse_fwd(const float* pix, const int32_t* idx, int rows, int per_batch, const float* mean, const float* rinv,
+                 const smbv_bf16* logits, float* row_partial, float* loss, int T, int H, int W, int ts, int ps, smbv_stream stream);
+int smbv_mse_bwd(const float* pix, const int32_t* idx, int rows, int per_batch, const float* mean, const float* rinv,
+                 const smbv_bf16* logits, smbv_bf16* dlogits, const float* gscale, int T, int H, int W, int ts, int ps,
+                 smbv_stream stream);
+
+int smbv_cast_f32_bf16(const float* src, smbv_bf16* dst, size_t n, smbv_stream stream);
+int smbv_transpose_cast_f32_bf16(const float* src, smbv_bf16* dst, int R, int C, int ldd, smbv_stream stream);
+int smbv_colsum_bf16(const smbv_bf16* X, int ld, int M, int N, float* out, void* ws, size_t ws_bytes, smbv_stream stream);
+size_t smbv_colsum_workspace_bytes(int M, int N);
+
+/* ---- the whole MIM train step: VideoMAEForPreTraining.forward (spec :753-908) and its autograd -------------------- */
+
+typedef struct smbv_mim_cfg {
+  int B, T, H, W;                 /* volume batch: pixel_values fp32 [B,T,1,H,W] */
+  int ps, ts;                     /* patch_size, tubelet_size */
+  int N, Nvis, Nmask;             /* tokens per volume: all / visible / masked */
+  int d, heads, ff, layers;       /* encoder: hidden_size, num_attention_heads, intermediate_size, num_hidden_layers */
+  int dd, dheads, dff, dlayers;   /* decoder_* */
+  float ln_eps;                   /* config.layer_norm_eps (blocks) */
+  float dec_norm_eps;             /* decoder.norm eps: torch default 1e-5 (spec :676) */
+} smbv_mim_cfg;
+
+/* fp32 tensors of one VideoMAELayer in the pinned-era (vendored) state-dict layout. */
+typedef struct smbv_layer_ptrs {
+  float *ln1_w, *ln1_b;           /* layernorm_before */
+  float *q_w, *k_w, *v_w;         /* attention.attention.{query,key,value}.weight [w,w] */
+  float *q_b, *v_b;               /* attention.attention.{q_bias,v_bias} [w] (key has no bias) */
+  float *proj_w, *proj_b;         /* attention.output.dense */
+  float *ln2_w, *ln2_b;           /* layernorm_after */
+  float *fc1_w, *fc1_b;           /* intermediate.dense [ff,w] */
+  float *fc2_w, *fc2_b;           /* output.dense [w,ff] */
+} smbv_layer_ptrs;
+
+/* One instance holds the parameters, a second one (same shape) the gradients. */
+typedef struct smbv_mim_tensors {
+  float *pe_w, *pe_b;             /* videomae.embeddings.patch_embeddings.projection [d,1,ts,ps,ps], [d] */
+  smbv_layer_ptrs enc[SMBV_MAX_LAYERS];
+  float *e2d_w;                   /* encoder_to_decoder.weight [dd,d] */
+  float *mask_token;              /* [1,1,dd] */
+  smbv_layer_ptrs dec[SMBV_MAX_LAYERS];
+  float *dnorm_w, *dnorm_b;       /* decoder.norm */
+  float *head_w, *head_b;         /* decoder.head [K,dd], [K] */
+} smbv_mim_tensors;
+
+typedef struct smbv_mim_io {
+  const float* pixel_values;      /* fp32 [B,T,1,H,W] */
+  const int32_t* vis_idx;         /* int32 [B,Nvis]  ascending token ids with bool_masked_pos == 0 */
+  const int32_t* mask_idx;        /* int32 [B,Nmask] ascending token ids with bool_masked_pos == 1 */
+  const float* pos_enc;           /* fp32 [N,d]  sin-cos table (spec :95-106), resident on device */
+  const float* pos_dec;           /* fp32 [N,dd] */
+  float* loss;                    /* fp32 [1] */
+  smbv_bf16* logits;              /* bf16 [B*Nmask, K] */
+  const float* grad_scale;        /* backward only: fp32 [1] upstream d(loss) (NULL = 1.0) */
+} smbv_mim_io;
+
+/* bytes of the activation/weight-copy/scratch workspace one step needs (fwd writes it, bwd reads it). */
+size_t smbv_mim_workspace_bytes(const smbv_mim_cfg* cfg);
+/* host pointers to cfg / params / io structs; device pointers inside them. */
+int smbv_mim_forward(const smbv_mim_cfg* cfg, const smbv_mim_tensors* params, const smbv_mim_io* io, void* ws, size_t ws_bytes,
+                     smbv_stream stream);
+/* Gradients of loss*grad_scale w.r.t. every tensor in `grads` (overwritten, not accumulated).  `events`/`n_events`:
+ * optional hipEvent_t array recorded on `stream` as gradient groups complete, in this order:
+ *   [0] head+decoder.norm, [1..dlayers] decoder layers (last first), [dlayers+1] mask_token+encoder_to_decoder,
+ *   [..+layers] encoder layers (last first), [last] patch embedding  — used to launch RCCL all-reduces on a side stream. */
+int smbv_mim_backward(const smbv_mim_cfg* cfg, const smbv_mim_tensors* params, const smbv_mim_tensors* grads, const smbv_mim_io* io,
+                      void* ws, size_t ws_bytes, void** events, int n_events, smbv_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMBV_H */

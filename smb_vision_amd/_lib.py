@@ -1,0 +1,112 @@
+"""ctypes binding of libsmbv.so (include/smbv.h).  There is NO fallback: if the library is missing or a call fails
+this raises — the product path never routes around the HIP kernels."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsmbv.so")
+MAX_LAYERS = 48
+
+c_f = C.c_void_p  # all device pointers travel as void*
+
+
+class GemmEpi(C.Structure):
+    _fields_ = [
+        ("alpha", C.c_float), ("bias", c_f),
+        ("rowadd", c_f), ("rowidx", c_f), ("ldr", C.c_int),
+        ("dgelu_pre", c_f), ("ld_pre", C.c_int),
+        ("act_gelu", C.c_int), ("aux_pre", c_f), ("ld_aux", C.c_int),
+        ("out_bf16", c_f), ("ld_ob", C.c_int),
+        ("out_f32", c_f), ("ld_of", C.c_int),
+        ("grp_in", C.c_int), ("grp_out", C.c_int),
+    ]
+
+
+class MimCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("B", "T", "H", "W", "ps", "ts", "N", "Nvis", "Nmask", "d", "heads", "ff", "layers", "dd", "dheads", "dff", "dlayers")] + \
+               [("ln_eps", C.c_float), ("dec_norm_eps", C.c_float)]
+
+
+LAYER_FIELDS = ("ln1_w", "ln1_b", "q_w", "k_w", "v_w", "q_b", "v_b", "proj_w", "proj_b", "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
+
+
+class LayerPtrs(C.Structure):
+    _fields_ = [(n, c_f) for n in LAYER_FIELDS]
+
+
+class MimTensors(C.Structure):
+    _fields_ = [("pe_w", c_f), ("pe_b", c_f), ("enc", LayerPtrs * MAX_LAYERS), ("e2d_w", c_f), ("mask_token", c_f),
+                ("dec", LayerPtrs * MAX_LAYERS), ("dnorm_w", c_f), ("dnorm_b", c_f), ("head_w", c_f), ("head_b", c_f)]
+
+
+class MimIO(C.Structure):
+    _fields_ = [("pixel_values", c_f), ("vis_idx", c_f), ("mask_idx", c_f), ("pos_enc", c_f), ("pos_dec", c_f),
+                ("loss", c_f), ("logits", c_f), ("grad_scale", c_f)]
+
+
+_SIGS = {
+    "smbv_version": (C.c_int, []),
+    "smbv_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "smbv_gemm_nt": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GemmEpi), c_f]),
+    "smbv_gemm_tn": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f, C.c_size_t, c_f]),
+    "smbv_gemm_tn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "smbv_layernorm_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_float, C.c_long, C.c_long, C.c_long, c_f]),
+    "smbv_layernorm_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, c_f, C.c_size_t, c_f]),
+    "smbv_layernorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "smbv_attention_fwd": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f]),
+    "smbv_attention_bwd": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_f]),
+    "smbv_gather_bricks": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "smbv_brick_stats": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "smbv_mse_fwd": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "smbv_mse_bwd": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "smbv_cast_f32_bf16": (C.c_int, [c_f, c_f, C.c_size_t, c_f]),
+    "smbv_transpose_cast_f32_bf16": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
+    "smbv_colsum_bf16": (C.c_int, [c_f, C.c_int, C.c_int, C.c_int, c_f, c_f, C.c_size_t, c_f]),
+    "smbv_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "smbv_mim_workspace_bytes": (C.c_size_t, [C.POINTER(MimCfg)]),
+    "smbv_mim_forward": (C.c_int, [C.POINTER(MimCfg), C.POINTER(MimTensors), C.POINTER(MimIO), c_f, C.c_size_t, c_f]),
+    "smbv_mim_backward": (C.c_int, [C.POINTER(MimCfg), C.POINTER(MimTensors), C.POINTER(MimTensors), C.POINTER(MimIO), c_f, C.c_size_t,
+                                    C.POINTER(C.c_void_p), C.c_int, c_f]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+class SmbvError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libsmbv.so or raise.  (Build it with ``python -m smb_vision_amd.build``.)"""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SmbvError(f"{LIB_PATH} not found: the smb_vision_amd HIP library is required (python -m smb_vision_amd.build); "
+                        "there is no CPU / PyTorch fallback for the hot path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if an export declared in include/smbv.h is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    load().smbv_last_error(buf, 512)
+    return buf.value.decode()
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc in (-1,):
+        raise ValueError(f"{what}: {msg}")
+    raise SmbvError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,319 @@
+// Fused multi-head self-attention backward (flash-style recompute from LSE), head_dim 64.
+// Autograd of src/models/videomae/modeling_videomae.py:196-223 (softmax(QK^T*scale) V).
+//
+// Three launches, no float atomics (bitwise reproducible):
+//   attn_delta   delta[q] = sum_d dO[q,d] * O[q,d]
+//   attn_dkv     key-owner: a block owns 128 keys (4 waves x 32 keys, key on the MFMA lane), sweeps the query tiles;
+//                S = Q K^T and dP = dO V^T come out with the key on the lane and the query in the registers, so P and dS
+//                are directly the B operands of dV^T += dO^T P and dK^T += Q^T dS (A operands by ds_read_b64_tr_b16
+//                from the same row-major Q / dO LDS image the row reads use).
+//   attn_dq      query-owner: a block owns 128 queries (query on the lane), sweeps the key tiles;
+//                S^T = K Q^T, dP^T = V dO^T, dS^T is the B operand of dQ^T += K^T dS^T (A operand by tr-read of K).
+// The split costs 7 MFMA products instead of 5 but needs no cross-workgroup reduction at all (a dQ accumulated with
+// float atomics would be bound by the ~1.3 TB/s atomic rate at S = 20,480: see DESIGN.md).
+#include "smbv_common.h"
+#include "smbv_kernels.h"
+
+namespace smbv {
+
+// 128-byte-row LDS image usable for ds_read_b128 row reads (16 rows x same chunk) AND ds_read_b64_tr_b16 blocks
+// (4 consecutive rows x 32 B): chunk16 ^= f((row>>1)&7), f(x) = ((x&1)<<2) | (x>>1).
+__device__ __forceinline__ int swz128(int row, int c16) {
+  const int x = (row >> 1) & 7;
+  return row * 128 + ((c16 ^ (((x & 1) << 2) | (x >> 1))) << 4);
+}
+
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO, int ldo,
+                                                         float* __restrict__ delta, int B, int S, int H) {
+  // 8 lanes per (row, head): 16 B each
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long pair = gid >> 3;
+  const int sub = gid & 7;
+  const long total = (long)B * S * H;
+  float acc = 0.f;
+  if (pair < total) {
+    const long row = pair / H;
+    const int head = pair % H;
+    const u32x4 o = *(const u32x4*)(O + row * ldo + head * 64 + sub * 8);
+    const u32x4 g = *(const u32x4*)(dO + row * ldo + head * 64 + sub * 8);
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc += bf_lo(o[i]) * bf_lo(g[i]) + bf_hi(o[i]) * bf_hi(g[i]);
+  }
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  acc += __shfl_xor(acc, 4, 64);
+  if (pair < total && sub == 0) {
+    const long row = pair / H;
+    const int head = pair % H;
+    const long b = row / S, s = row % S;
+    delta[(b * H + head) * S + s] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                       const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO,
+                                                       int ldo, const float* __restrict__ LSE, const float* __restrict__ delta,
+                                                       bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int ldd, int S, int H,
+                                                       float scale) {
+  // LDS per buffer: Q [32][128 B] 4 KiB | dO 4 KiB | lse2 [32] f32 | delta [32] f32
+  constexpr int BUF = 4096 + 4096 + 128 + 128;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int r = l & 31, h2 = l >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const size_t row0 = (size_t)b * S;
+  const int key = blockIdx.x * 128 + w * 32 + r;
+  const int hoff = head * 64;
+  const float c = scale * 1.4426950408889634f;
+  const float* lse_p = LSE + ((size_t)b * H + head) * S;
+  const float* del_p = delta + ((size_t)b * H + head) * S;
+
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) {
+    u32x4 a = {0, 0, 0, 0}, bb = {0, 0, 0, 0};
+    if (key < S) {
+      a = *(const u32x4*)(K + (row0 + key) * ld + hoff + 16 * ks + 8 * h2);
+      bb = *(const u32x4*)(V + (row0 + key) * ld + hoff + 16 * ks + 8 * h2);
+    }
+    kf[ks] = __builtin_bit_cast(bf16x8, a);
+    vf[ks] = __builtin_bit_cast(bf16x8, bb);
+  }
+  f32x16 dkt[2], dvt[2];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { dkt[0][i] = 0.f; dkt[1][i] = 0.f; dvt[0][i] = 0.f; dvt[1][i] = 0.f; }
+
+  u32x4 rq, rdo;
+  float rstat = 0.f;
+  auto gload = [&](int qt) {
+    const int q0 = qt * 32;
+    const int row = t >> 3, ch = t & 7;
+    const bool ok = (q0 + row) < S;
+    rq = ok ? *(const u32x4*)(Q + (row0 + q0 + row) * ld + hoff + ch * 8) : (u32x4){0, 0, 0, 0};
+    rdo = ok ? *(const u32x4*)(dO + (row0 + q0 + row) * ldo + hoff + ch * 8) : (u32x4){0, 0, 0, 0};
+    if (t < 32) rstat = (q0 + t < S) ? lse_p[q0 + t] * 1.4426950408889634f : INFINITY;
+    else if (t < 64) rstat = (q0 + t - 32 < S) ? del_p[q0 + t - 32] : 0.f;
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* s = smem + buf * BUF;
+    const int row = t >> 3, ch = t & 7;
+    *(u32x4*)(s + swz128(row, ch)) = rq;
+    *(u32x4*)(s + 4096 + swz128(row, ch)) = rdo;
+    if (t < 64) ((float*)(s + 8192))[t] = rstat;  // [0..31] lse2, [32..63] delta
+  };
+
+  const int nq = (S + 31) / 32;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int g1 = (l >> 4) & 1, qq = (l >> 2) & 3, pp = l & 3;
+  for (int qt = 0; qt < nq; qt++) {
+    const int buf = qt & 1;
+    if (qt + 1 < nq) gload(qt + 1);
+    const unsigned char* sq = smem + buf * BUF;
+    const unsigned char* sdo = sq + 4096;
+    const float* sst = (const float*)(sq + 8192);
+
+    f32x16 s, dp;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const bf16x8 qa = *(const bf16x8*)(sq + swz128(r, 2 * ks + h2));
+      const bf16x8 da = *(const bf16x8*)(sdo + swz128(r, 2 * ks + h2));
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);     // [q][key]
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);   // [q][key]
+    }
+    // row constants for this lane's 16 rows: rows 8*rg + 4*h2 + (0..3)
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const f32x4 ls = *(const f32x4*)(sst + 8 * rg + 4 * h2);
+      const f32x4 de = *(const f32x4*)(sst + 32 + 8 * rg + 4 * h2);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float p = exp2f(s[4 * rg + e] * c - ls[e]);
+        s[4 * rg + e] = p;
+        dp[4 * rg + e] = p * (dp[4 * rg + e] - de[e]);
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+      bf16x8 pf, dsf;
+#pragma unroll
+      for (int j = 0; j < 8; j++) { pf[j] = (__bf16)s[8 * s2 + j]; dsf[j] = (__bf16)dp[8 * s2 + j]; }
+      const int qb = 16 * s2 + 4 * h2 + qq;
+#pragma unroll
+      for (int dt = 0; dt < 2; dt++) {
+        const int c16 = 4 * dt + 2 * g1 + (pp >> 1);
+        const int sub = 8 * (pp & 1);
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x4 a0 = lds_read_tr16(sdo + swz128(qb, c16) + sub);
+        const s16x4 a1 = lds_read_tr16(sdo + swz128(qb + 8, c16) + sub);
+        const s16x8 aa = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aa), pf, dvt[dt], 0, 0, 0);
+        const s16x4 b0 = lds_read_tr16(sq + swz128(qb, c16) + sub);
+        const s16x4 b1 = lds_read_tr16(sq + swz128(qb + 8, c16) + sub);
+        const s16x8 bb = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bb), dsf, dkt[dt], 0, 0, 0);
+      }
+    }
+    if (qt + 1 < nq) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (key < S) {
+    bf16_t* kp = dK + (row0 + key) * ldd + hoff;
+    bf16_t* vp = dV + (row0 + key) * ldd + hoff;
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int d0 = 32 * dt + 8 * rg + 4 * h2;
+        u32x2 pk = {pack_bf16(dkt[dt][4 * rg] * scale, dkt[dt][4 * rg + 1] * scale), pack_bf16(dkt[dt][4 * rg + 2] * scale, dkt[dt][4 * rg + 3] * scale)};
+        *(u32x2*)(kp + d0) = pk;
+        u32x2 pv = {pack_bf16(dvt[dt][4 * rg], dvt[dt][4 * rg + 1]), pack_bf16(dvt[dt][4 * rg + 2], dvt[dt][4 * rg + 3])};
+        *(u32x2*)(vp + d0) = pv;
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                      const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO, int ldo,
+                                                      const float* __restrict__ LSE, const float* __restrict__ delta,
+                                                      bf16_t* __restrict__ dQ, int ldd, int S, int H, float scale) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 64 * 128];  // [buf][K|V][64 keys][128 B]
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int r = l & 31, h2 = l >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const size_t row0 = (size_t)b * S;
+  const int q = blockIdx.x * 128 + w * 32 + r;
+  const int hoff = head * 64;
+  const float c = scale * 1.4426950408889634f;
+
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) {
+    u32x4 a = {0, 0, 0, 0}, bb = {0, 0, 0, 0};
+    if (q < S) {
+      a = *(const u32x4*)(Q + (row0 + q) * ld + hoff + 16 * ks + 8 * h2);
+      bb = *(const u32x4*)(dO + (row0 + q) * ldo + hoff + 16 * ks + 8 * h2);
+    }
+    qf[ks] = __builtin_bit_cast(bf16x8, a);
+    dof[ks] = __builtin_bit_cast(bf16x8, bb);
+  }
+  float lse2 = INFINITY, dl = 0.f;
+  if (q < S) {
+    lse2 = LSE[((size_t)b * H + head) * S + q] * 1.4426950408889634f;
+    dl = delta[((size_t)b * H + head) * S + q];
+  }
+  f32x16 dqt[2];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { dqt[0][i] = 0.f; dqt[1][i] = 0.f; }
+
+  u32x4 rk[2], rv[2];
+  auto gload = [&](int kt) {
+    const int k0 = kt * 64;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int id = t + 256 * i, row = id >> 3, ch = id & 7;
+      const bool ok = (k0 + row) < S;
+      const size_t off = (row0 + k0 + row) * ld + hoff + ch * 8;
+      rk[i] = ok ? *(const u32x4*)(K + off) : (u32x4){0, 0, 0, 0};
+      rv[i] = ok ? *(const u32x4*)(V + off) : (u32x4){0, 0, 0, 0};
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* sk = smem + buf * (2 * 64 * 128);
+    unsigned char* sv = sk + 64 * 128;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int id = t + 256 * i, row = id >> 3, ch = id & 7;
+      *(u32x4*)(sk + swz128(row, ch)) = rk[i];
+      *(u32x4*)(sv + swz128(row, ch)) = rv[i];
+    }
+  };
+
+  const int nt = (S + 63) / 64;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int g1 = (l >> 4) & 1, qq = (l >> 2) & 3, pp = l & 3;
+  for (int kt = 0; kt < nt; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nt) gload(kt + 1);
+    const unsigned char* sk = smem + buf * (2 * 64 * 128);
+    const unsigned char* sv = sk + 64 * 128;
+    const bool ragged = kt * 64 + 64 > S;
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; kt2++) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; i++) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        const bf16x8 ka = *(const bf16x8*)(sk + swz128(32 * kt2 + r, 2 * ks + h2));
+        const bf16x8 va = *(const bf16x8*)(sv + swz128(32 * kt2 + r, 2 * ks + h2));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], s, 0, 0, 0);      // [key][q]
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dp, 0, 0, 0);   // [key][q]
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        float p = exp2f(s[i] * c - lse2);
+        if (ragged) {
+          const int key = kt * 64 + 32 * kt2 + (i & 3) + 8 * (i >> 2) + 4 * h2;
+          if (key >= S) p = 0.f;
+        }
+        dp[i] = p * (dp[i] - dl);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++) {
+        bf16x8 dsf;
+#pragma unroll
+        for (int j = 0; j < 8; j++) dsf[j] = (__bf16)dp[8 * s2 + j];
+        const int kb = 32 * kt2 + 16 * s2 + 4 * h2 + qq;
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++) {
+          const int c16 = 4 * dt + 2 * g1 + (pp >> 1);
+          const int sub = 8 * (pp & 1);
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x4 a0 = lds_read_tr16(sk + swz128(kb, c16) + sub);
+          const s16x4 a1 = lds_read_tr16(sk + swz128(kb + 8, c16) + sub);
+          const s16x8 aa = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aa), dsf, dqt[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (kt + 1 < nt) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (q < S) {
+    bf16_t* qp = dQ + (row0 + q) * ldd + hoff;
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int d0 = 32 * dt + 8 * rg + 4 * h2;
+        u32x2 pk = {pack_bf16(dqt[dt][4 * rg] * scale, dqt[dt][4 * rg + 1] * scale), pack_bf16(dqt[dt][4 * rg + 2] * scale, dqt[dt][4 * rg + 3] * scale)};
+        *(u32x2*)(qp + d0) = pk;
+      }
+  }
+}
+
+int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
+                  float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, hipStream_t st) {
+  if (Dh != 64) { set_error("attention_bwd: head_dim %d not supported (only 64)", Dh); return SMBV_ERR_SHAPE; }
+  if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 7) || (ldd & 3)) { set_error("attention_bwd: bad shape"); return SMBV_ERR_SHAPE; }
+  if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)dO) & 15) || (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 7)) { set_error("attention_bwd: alignment"); return SMBV_ERR_ALIGN; }
+  const long pairs = (long)B * S * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(pairs * 8, 256)), dim3(256), 0, st, O, dO, ldo, delta, B, S, H);
+  int rc = check_launch("attn_delta");
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_dkv_kernel, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, H, scale);
+  rc = check_launch("attn_dkv");
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_dq_kernel, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, H, scale);
+  return check_launch("attn_dq");
+}
+
+}  // namespace smbv

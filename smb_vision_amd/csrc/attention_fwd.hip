@@ -1,0 +1,175 @@
+// Fused multi-head self-attention forward (flash-style, no mask, non-causal, dropout 0) for head_dim 64.
+// Replaces eager_attention_forward / SDPA / flash-attn at src/models/videomae/modeling_videomae.py:196-223, 270-289:
+//   O = softmax_fp32(Q K^T * Dh^-0.5) V, plus LSE per query row for the backward.
+//
+// Layout: Q, K, V are column slices of one token-major matrix [B*S, ld] (the fused QKV GEMM output), head h at
+// columns h*64 .. h*64+63; O is token-major [B*S, ldo].  No head-major copies are made.
+//
+// Work decomposition: grid (ceil(S/128), H, B); 4 waves per block, each wave owns 32 query rows; K/V tiles of 64
+// keys staged global -> registers -> LDS (double-buffered, one barrier per tile).
+//   S^T[key][q]  = K * Q^T     v_mfma_f32_32x32x16_bf16, A = K fragment (ds_read_b128 from the swizzled K image),
+//                              B = Q fragment (registers, loaded once) -> the query sits on the MFMA lane, so the row
+//                              max / sum of the online softmax are lane-local (one cross-half shuffle per tile).
+//   O^T[d][q]   += V^T * P^T   the S^T accumulator, exponentiated and packed to bf16, IS the B operand (its rows are the
+//                              contraction index); A = V^T fragment fetched with ds_read_b64_tr_b16 from the row-major
+//                              V image -> no P round trip through LDS and no transposed copy of V.
+// Softmax statistics in fp32; p = exp2(s*c - m*c) with c = scale*log2(e).
+#include "smbv_common.h"
+#include "smbv_kernels.h"
+
+namespace smbv {
+
+__device__ __forceinline__ int swz_k64(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// V image: 128-B rows, 32-B columns XOR-ed with bit1 of (key>>1) so that the 4 keys of a tr-read block hit distinct banks
+__device__ __forceinline__ int swz_v64(int key, int c32) { return key * 128 + ((c32 ^ (((key >> 1) & 1) << 1)) << 5); }
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                       const bf16_t* __restrict__ V, int ld, bf16_t* __restrict__ O, int ldo,
+                                                       float* __restrict__ LSE, int S, int H, float scale) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 64 * 128];  // [buf][K|V][64 keys][128 B]
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int r = l & 31, h2 = l >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const size_t row0 = (size_t)b * S;
+  const int q = blockIdx.x * 128 + w * 32 + r;
+  const int hoff = head * 64;
+  const float c = scale * 1.4426950408889634f;
+
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) {
+    u32x4 v = {0, 0, 0, 0};
+    if (q < S) v = *(const u32x4*)(Q + (row0 + q) * ld + hoff + 16 * ks + 8 * h2);
+    qf[ks] = __builtin_bit_cast(bf16x8, v);
+  }
+
+  f32x16 ot[2];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { ot[0][i] = 0.f; ot[1][i] = 0.f; }
+  float m_i = -INFINITY, l_i = 0.f;
+
+  u32x4 rk[2], rv[2];
+  auto gload = [&](int kt) {
+    const int k0 = kt * 64;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int id = t + 256 * i, row = id >> 3, ch = id & 7;
+      const bool ok = (k0 + row) < S;
+      const size_t off = (row0 + k0 + row) * ld + hoff + ch * 8;
+      rk[i] = ok ? *(const u32x4*)(K + off) : (u32x4){0, 0, 0, 0};
+      rv[i] = ok ? *(const u32x4*)(V + off) : (u32x4){0, 0, 0, 0};
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* sk = smem + buf * (2 * 64 * 128);
+    unsigned char* sv = sk + 64 * 128;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int id = t + 256 * i, row = id >> 3, ch = id & 7;
+      *(u32x4*)(sk + swz_k64(row, ch)) = rk[i];
+      *(u32x4*)(sv + swz_v64(row, ch >> 1) + 16 * (ch & 1)) = rv[i];
+    }
+  };
+
+  const int nt = (S + 63) / 64;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int g1 = (l >> 4) & 1, qq = (l >> 2) & 3, pp = l & 3;
+  for (int kt = 0; kt < nt; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nt) gload(kt + 1);
+    const unsigned char* sk = smem + buf * (2 * 64 * 128);
+    const unsigned char* sv = sk + 64 * 128;
+
+    f32x16 s[2];
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; kt2++) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) s[kt2][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        const bf16x8 kf = *(const bf16x8*)(sk + swz_k64(32 * kt2 + r, 2 * ks + h2));
+        s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt2], 0, 0, 0);
+      }
+    }
+    if (kt * 64 + 64 > S) {  // ragged last tile: keys >= S get -inf
+#pragma unroll
+      for (int kt2 = 0; kt2 < 2; kt2++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const int key = kt * 64 + 32 * kt2 + (i & 3) + 8 * (i >> 2) + 4 * h2;
+          if (key >= S) s[kt2][i] = -INFINITY;
+        }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) mx = fmaxf(mx, s[0][i]);
+#pragma unroll
+    for (int i = 0; i < 16; i++) mx = fmaxf(mx, s[1][i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_i, mx);  // finite: every tile holds at least one valid key
+    const float alpha = exp2f((m_i - m_new) * c);
+    const float mc = m_new * c;
+    m_i = m_new;
+    float rowsum = 0.f;
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; kt2++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const float p = exp2f(s[kt2][i] * c - mc);
+        s[kt2][i] = p;
+        rowsum += p;
+      }
+    l_i = l_i * alpha + rowsum;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
+
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; kt2++)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; j++) pf[j] = (__bf16)s[kt2][8 * s2 + j];
+        const int kb = 32 * kt2 + 16 * s2 + 4 * h2 + qq;  // this lane's address row for the tr-read
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++) {
+          const int c32 = 2 * dt + g1;
+          const s16x4 v0 = lds_read_tr16(sv + swz_v64(kb, c32) + 8 * pp);
+          const s16x4 v1 = lds_read_tr16(sv + swz_v64(kb + 8, c32) + 8 * pp);
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, ot[dt], 0, 0, 0);
+        }
+      }
+    if (kt + 1 < nt) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  const float l_tot = l_i + __shfl_xor(l_i, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (q < S) {
+    bf16_t* op = O + (row0 + q) * ldo + hoff;
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int d0 = 32 * dt + 8 * rg + 4 * h2;
+        u32x2 pk = {pack_bf16(ot[dt][4 * rg] * inv, ot[dt][4 * rg + 1] * inv), pack_bf16(ot[dt][4 * rg + 2] * inv, ot[dt][4 * rg + 3] * inv)};
+        *(u32x2*)(op + d0) = pk;
+      }
+    if (h2 == 0) LSE[((size_t)b * H + head) * S + q] = m_i * scale + __logf(l_tot);
+  }
+}
+
+int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf16_t* O, int ldo, float* LSE, int B, int S, int H, int Dh,
+                  float scale, hipStream_t st) {
+  if (Dh != 64) { set_error("attention_fwd: head_dim %d not supported (only 64)", Dh); return SMBV_ERR_SHAPE; }
+  if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 3)) { set_error("attention_fwd: bad shape B=%d S=%d H=%d ld=%d ldo=%d", B, S, H, ld, ldo); return SMBV_ERR_SHAPE; }
+  if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || ((uintptr_t)O & 7)) { set_error("attention_fwd: alignment"); return SMBV_ERR_ALIGN; }
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, H, scale);
+  return check_launch("attention_fwd");
+}
+
+}  // namespace smbv

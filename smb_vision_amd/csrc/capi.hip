@@ -1,0 +1,129 @@
+// extern "C" surface of libsmbv.so (declared in include/smbv.h) + error plumbing.
+#include "smbv_common.h"
+#include "smbv_kernels.h"
+#include "../../include/smbv.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace smbv {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return SMBV_OK;
+}
+
+static GemmEpi to_epi(const smbv_gemm_epi* s) {
+  GemmEpi e;
+  if (!s) return e;
+  e.alpha = s->alpha;
+  e.bias = s->bias;
+  e.rowadd = s->rowadd; e.rowidx = s->rowidx; e.ldr = s->ldr;
+  e.dgelu_pre = s->dgelu_pre; e.ld_pre = s->ld_pre;
+  e.act_gelu = s->act_gelu; e.aux_pre = s->aux_pre; e.ld_aux = s->ld_aux;
+  e.out_bf16 = s->out_bf16; e.ld_ob = s->ld_ob;
+  e.out_f32 = s->out_f32; e.ld_of = s->ld_of;
+  e.grp_in = s->grp_in; e.grp_out = s->grp_out;
+  return e;
+}
+
+}  // namespace smbv
+
+using namespace smbv;
+
+extern "C" {
+
+int smbv_version(void) { return 1000; }
+
+int smbv_last_error(char* buf, size_t len) {
+  const size_t n = strlen(g_err);
+  if (buf && len) {
+    const size_t c = n < len - 1 ? n : len - 1;
+    memcpy(buf, g_err, c);
+    buf[c] = 0;
+  }
+  return (int)n;
+}
+
+int smbv_gemm_nt(const smbv_bf16* A, int lda, const smbv_bf16* B, int ldb, int M, int N, int K, const smbv_gemm_epi* epi, smbv_stream stream) {
+  if (!A || !B || !epi || (!epi->out_bf16 && !epi->out_f32)) { set_error("smbv_gemm_nt: null operand / no output"); return SMBV_ERR_ARG; }
+  return gemm_nt(A, lda, B, ldb, M, N, K, to_epi(epi), (hipStream_t)stream);
+}
+int smbv_gemm_tn(const smbv_bf16* X, int ldx, const smbv_bf16* Y, int ldy, int M, int N1, int N2, float* out, void* ws, size_t ws_bytes, smbv_stream stream) {
+  if (!X || !Y || !out) { set_error("smbv_gemm_tn: null operand"); return SMBV_ERR_ARG; }
+  return gemm_tn(X, ldx, Y, ldy, M, N1, N2, out, ws, ws_bytes, (hipStream_t)stream);
+}
+size_t smbv_gemm_tn_workspace_bytes(int M, int N1, int N2) { return gemm_tn_workspace_bytes(M, N1, N2); }
+
+int smbv_layernorm_fwd(const float* x, const float* gamma, const float* beta, smbv_bf16* y, float* mean, float* rstd, int rows, int D, float eps,
+                       long grp_in, long grp_out, long row_off, smbv_stream stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd) { set_error("smbv_layernorm_fwd: null operand"); return SMBV_ERR_ARG; }
+  return layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, eps, grp_in, grp_out, row_off, (hipStream_t)stream);
+}
+int smbv_layernorm_bwd(const smbv_bf16* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
+                       smbv_bf16* dx_bf16, float* dgamma, float* dbeta, int rows, int D, long grp_in, long grp_out, long row_off, void* ws,
+                       size_t ws_bytes, smbv_stream stream) {
+  if (!dy || !x || !mean || !rstd || !gamma || !dgamma || !dbeta) { set_error("smbv_layernorm_bwd: null operand"); return SMBV_ERR_ARG; }
+  return layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, dx_bf16, dgamma, dbeta, rows, D, grp_in, grp_out, row_off, ws, ws_bytes, (hipStream_t)stream);
+}
+size_t smbv_layernorm_bwd_workspace_bytes(int rows, int D) { return layernorm_bwd_workspace_bytes(rows, D); }
+
+int smbv_attention_fwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, smbv_bf16* O, int ldo, float* LSE, int B, int S, int H,
+                       int Dh, float scale, smbv_stream stream) {
+  if (!Q || !K || !V || !O || !LSE) { set_error("smbv_attention_fwd: null operand"); return SMBV_ERR_ARG; }
+  return attention_fwd(Q, K, V, ld, O, ldo, LSE, B, S, H, Dh, scale, (hipStream_t)stream);
+}
+int smbv_attention_bwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* dO, int ldo,
+                       const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S, int H, int Dh, float scale,
+                       smbv_stream stream) {
+  if (!Q || !K || !V || !O || !dO || !LSE || !delta || !dQ || !dK || !dV) { set_error("smbv_attention_bwd: null operand"); return SMBV_ERR_ARG; }
+  return attention_bwd(Q, K, V, ld, O, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, H, Dh, scale, (hipStream_t)stream);
+}
+
+int smbv_gather_bricks(const float* pix, const int32_t* idx, int rows, int per_batch, smbv_bf16* out, int T, int H, int W, int ts, int ps, smbv_stream stream) {
+  if (!pix || !idx || !out) { set_error("smbv_gather_bricks: null operand"); return SMBV_ERR_ARG; }
+  return gather_bricks(pix, idx, rows, per_batch, out, T, H, W, ts, ps, (hipStream_t)stream);
+}
+int smbv_brick_stats(const float* pix, const int32_t* idx, int rows, int per_batch, float* mean, float* rinv, int T, int H, int W, int ts, int ps, smbv_stream stream) {
+  if (!pix || !idx || !mean || !rinv) { set_error("smbv_brick_stats: null operand"); return SMBV_ERR_ARG; }
+  return brick_stats(pix, idx, rows, per_batch, mean, rinv, T, H, W, ts, ps, (hipStream_t)stream);
+}
+int smbv_mse_fwd(const float* pix, const int32_t* idx, int rows, int per_batch, const float* mean, const float* rinv, const smbv_bf16* logits,
+                 float* row_partial, float* loss, int T, int H, int W, int ts, int ps, smbv_stream stream) {
+  if (!pix || !idx || !mean || !rinv || !logits || !row_partial || !loss) { set_error("smbv_mse_fwd: null operand"); return SMBV_ERR_ARG; }
+  return mse_fwd(pix, idx, rows, per_batch, mean, rinv, logits, row_partial, loss, T, H, W, ts, ps, (hipStream_t)stream);
+}
+int smbv_mse_bwd(const float* pix, const int32_t* idx, int rows, int per_batch, const float* mean, const float* rinv, const smbv_bf16* logits,
+                 smbv_bf16* dlogits, const float* gscale, int T, int H, int W, int ts, int ps, smbv_stream stream) {
+  if (!pix || !idx || !mean || !rinv || !logits || !dlogits) { set_error("smbv_mse_bwd: null operand"); return SMBV_ERR_ARG; }
+  return mse_bwd(pix, idx, rows, per_batch, mean, rinv, logits, dlogits, gscale, T, H, W, ts, ps, (hipStream_t)stream);
+}
+
+int smbv_cast_f32_bf16(const float* src, smbv_bf16* dst, size_t n, smbv_stream stream) {
+  if (!src || !dst) { set_error("smbv_cast_f32_bf16: null operand"); return SMBV_ERR_ARG; }
+  return cast_f32_bf16(src, dst, n, (hipStream_t)stream);
+}
+int smbv_transpose_cast_f32_bf16(const float* src, smbv_bf16* dst, int R, int C, int ldd, smbv_stream stream) {
+  if (!src || !dst) { set_error("smbv_transpose_cast_f32_bf16: null operand"); return SMBV_ERR_ARG; }
+  return transpose_cast_f32_bf16(src, dst, R, C, ldd, (hipStream_t)stream);
+}
+int smbv_colsum_bf16(const smbv_bf16* X, int ld, int M, int N, float* out, void* ws, size_t ws_bytes, smbv_stream stream) {
+  if (!X || !out) { set_error("smbv_colsum_bf16: null operand"); return SMBV_ERR_ARG; }
+  return colsum_bf16(X, ld, M, N, out, 0, 0, 0, ws, ws_bytes, (hipStream_t)stream);
+}
+size_t smbv_colsum_workspace_bytes(int M, int N) { return colsum_workspace_bytes(M, N); }
+
+}  // extern "C"

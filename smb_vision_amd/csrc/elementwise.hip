@@ -1,0 +1,131 @@
+// Small HBM-bound helpers of the MIM step: weight casts / transposes, decoder-input assembly, row gathers, column sums.
+#include "smbv_common.h"
+#include "smbv_kernels.h"
+
+namespace smbv {
+
+// fp32 -> bf16 (n multiple of 4)
+__global__ void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n4) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 v = ((const f32x4*)src)[i];
+    u32x2 pk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+    ((u32x2*)dst)[i] = pk;
+  }
+}
+
+int cast_f32_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st) {
+  if (n == 0) return SMBV_OK;
+  if ((n & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) { set_error("cast_f32_bf16: n %% 4 / alignment"); return SMBV_ERR_ALIGN; }
+  const size_t n4 = n >> 2;
+  hipLaunchKernelGGL(cast_kernel, dim3((unsigned)std::min<size_t>(4096, (n4 + 255) / 256)), dim3(256), 0, st, src, dst, n4);
+  return check_launch("cast_f32_bf16");
+}
+
+// dst bf16 [C][ldd >= R] = transpose(src fp32 [R][C]); 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int R, int C, int ldd) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < C && r < R) dst[(size_t)c * ldd + r] = f2bf(tile[tx][ty + 8 * i]);
+  }
+}
+
+int transpose_cast_f32_bf16(const float* src, bf16_t* dst, int R, int C, int ldd, hipStream_t st) {
+  if (R <= 0 || C <= 0 || ldd < R) { set_error("transpose_cast: empty"); return SMBV_ERR_SHAPE; }
+  hipLaunchKernelGGL(transpose_cast_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, st, src, dst, R, C, ldd);
+  return check_launch("transpose_cast");
+}
+
+// decoder input, masked part (src/models/videomae/modeling_videomae.py:811-815): x_full[b, Nvis + i, :] = mask_token + pos[mask_idx[b,i], :]
+__global__ void fill_mask_rows_kernel(float* __restrict__ xfull, const float* __restrict__ mask_token, const float* __restrict__ pos,
+                                      const int* __restrict__ mask_idx, int nmask, int nvis, int D) {
+  const int row = blockIdx.x;  // over B*nmask
+  const int b = row / nmask, i = row % nmask;
+  const float* p = pos + (size_t)mask_idx[row] * D;
+  float* o = xfull + ((size_t)b * (nvis + nmask) + nvis + i) * D;
+  for (int c = threadIdx.x; c < (D >> 2); c += blockDim.x) ((f32x4*)o)[c] = ((const f32x4*)mask_token)[c] + ((const f32x4*)p)[c];
+}
+
+int fill_mask_rows(float* xfull, const float* mask_token, const float* pos, const int* mask_idx, int B, int nmask, int nvis, int D, hipStream_t st) {
+  if (B <= 0 || nmask <= 0 || nvis < 0 || (D & 3)) { set_error("fill_mask_rows: bad shape"); return SMBV_ERR_SHAPE; }
+  hipLaunchKernelGGL(fill_mask_rows_kernel, dim3(B * nmask), dim3(128), 0, st, xfull, mask_token, pos, mask_idx, nmask, nvis, D);
+  return check_launch("fill_mask_rows");
+}
+
+// out bf16 [rows][D] = in bf16 [map(row)][D], map(row) = (row / grp_in) * grp_out + row % grp_in + row_off
+__global__ void gather_rows_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int D8, long grp_in, long grp_out, long row_off) {
+  const long row = blockIdx.x;
+  const long src = (row / grp_in) * grp_out + (row % grp_in) + row_off;
+  for (int c = threadIdx.x; c < D8; c += blockDim.x) ((u32x4*)(out + row * D8 * 8))[c] = ((const u32x4*)(in + src * D8 * 8))[c];
+}
+
+int gather_rows_bf16(const bf16_t* in, bf16_t* out, int rows, int D, long grp_in, long grp_out, long row_off, hipStream_t st) {
+  if (rows <= 0 || (D & 7) || grp_in <= 0) { set_error("gather_rows_bf16: bad shape"); return SMBV_ERR_SHAPE; }
+  if (((uintptr_t)in | (uintptr_t)out) & 15) { set_error("gather_rows_bf16: alignment"); return SMBV_ERR_ALIGN; }
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(64), 0, st, in, out, D >> 3, grp_in, grp_out, row_off);
+  return check_launch("gather_rows_bf16");
+}
+
+// column sums over rows (bias gradients, mask_token gradient): out[n] = sum_m X[map(m)][n]; two deterministic stages.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int ld, int M, int N, float* __restrict__ part, int mchunk,
+                                                     long grp_in, long grp_out, long row_off) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int z = blockIdx.y;
+  if (n >= N) return;
+  const int m0 = z * mchunk, m1 = min(M, m0 + mchunk);
+  float s = 0.f;
+  for (int m = m0; m < m1; m++) {
+    size_t r = m;
+    if (grp_in > 0) r = (size_t)(m / grp_in) * grp_out + (m % grp_in) + row_off;
+    if constexpr (sizeof(T) == 2) s += bf2f(X[r * ld + n]);
+    else s += X[r * ld + n];
+  }
+  part[(size_t)z * N + n] = s;
+}
+
+__global__ void colsum_reduce_kernel(const float* __restrict__ part, int nz, int N, float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int z = 0; z < nz; z++) s += part[(size_t)z * N + n];
+  out[n] = s;
+}
+
+static int colsum_splits(int M, int N) {
+  const int cb = cdiv(N, 256);
+  int z = std::max(1, std::min(cdiv(M, 64), cdiv(1024, cb)));
+  return z;
+}
+size_t colsum_workspace_bytes(int M, int N) { return (size_t)colsum_splits(M, N) * N * sizeof(float); }
+
+template <typename T>
+static int colsum_impl(const T* X, int ld, int M, int N, float* out, long grp_in, long grp_out, long row_off, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (M <= 0 || N <= 0) { set_error("colsum: empty"); return SMBV_ERR_SHAPE; }
+  const int nz = colsum_splits(M, N);
+  if (!ws || ws_bytes < (size_t)nz * N * sizeof(float)) { set_error("colsum: workspace too small"); return SMBV_ERR_WORKSPACE; }
+  const int mchunk = cdiv(M, nz);
+  hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(N, 256), nz), dim3(256), 0, st, X, ld, M, N, (float*)ws, mchunk, grp_in, grp_out, row_off);
+  int rc = check_launch("colsum");
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, (const float*)ws, nz, N, out);
+  return check_launch("colsum_reduce");
+}
+
+int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, long grp_in, long grp_out, long row_off, void* ws, size_t ws_bytes, hipStream_t st) {
+  return colsum_impl<bf16_t>(X, ld, M, N, out, grp_in, grp_out, row_off, ws, ws_bytes, st);
+}
+int colsum_f32(const float* X, int ld, int M, int N, float* out, long grp_in, long grp_out, long row_off, void* ws, size_t ws_bytes, hipStream_t st) {
+  return colsum_impl<float>(X, ld, M, N, out, grp_in, grp_out, row_off, ws, ws_bytes, st);
+}
+
+}  // namespace smbv

@@ -1,0 +1,294 @@
+// MFMA GEMMs for the MIM hot path (gfx950).
+//
+//   gemm_nt : C[M,N] = epi( A[M,K] * B[N,K]^T )      forward linears (HF weight layout [out,in] is exactly B) and
+//                                                    dgrad (with a transposed bf16 weight copy).
+//   gemm_tn : C[N1,N2] = sum_m X[m,N1] * Y[m,N2]     wgrad: dW[out,in] = dY[tokens,out]^T * A[tokens,in]; both operands
+//                                                    are token-major, the contraction index is the slow one, so the
+//                                                    MFMA fragments are fetched with the transposing LDS read
+//                                                    (ds_read_b64_tr_b16).  Split over the token range into slabs that
+//                                                    a second kernel sums (deterministic: no float atomics).
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 accumulators.
+// Global -> registers -> LDS staging, double-buffered LDS, one barrier per K step.  LDS images are XOR-swizzled so
+// that every ds_read_b128 / ds_read_b64_tr_b16 lane group hits 16 distinct 16-B slots.
+// Reference call sites these replace: src/models/videomae/modeling_videomae.py:261-264, 311-313, 368-370, 384-386,
+// 741/801-803, 720-722 (the nn.Linear calls) and their autograd.
+#include "smbv_common.h"
+#include "smbv_kernels.h"
+
+namespace smbv {
+
+static constexpr int BM = 128, BN = 128, BK = 64;
+
+__device__ __forceinline__ int swz_nt(int row, int chunk) { return row * 128 + (((chunk) ^ ((row >> 1) & 7)) << 4); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// NT
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
+                                                      int ldb, int M, int N, int K, int tiles_m, GemmEpi e) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * BM * BK * 2];  // [buf][A|B][128*64 bf16] = 64 KiB
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nk = (K + BK - 1) / BK;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int kt) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int id = t + 256 * i, row = id >> 3, ch = id & 7;
+      const int kk = k0 + ch * 8;
+      const int gm = m0 + row, gn = n0 + row;
+      ra[i] = (gm < M && kk < K) ? *(const u32x4*)(A + (size_t)gm * lda + kk) : (u32x4){0, 0, 0, 0};
+      rb[i] = (gn < N && kk < K) ? *(const u32x4*)(B + (size_t)gn * ldb + kk) : (u32x4){0, 0, 0, 0};
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* sa = smem + buf * (2 * BM * BK * 2);
+    unsigned char* sb = sa + BM * BK * 2;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int id = t + 256 * i, row = id >> 3, ch = id & 7;
+      *(u32x4*)(sa + swz_nt(row, ch)) = ra[i];
+      *(u32x4*)(sb + swz_nt(row, ch)) = rb[i];
+    }
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const unsigned char* sa = smem + buf * (2 * BM * BK * 2);
+    const unsigned char* sb = sa + BM * BK * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      bf16x8 af[4], bfr[4];
+      const int ch = (l >> 4) + 4 * ks;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int ar = wm * 64 + i * 16 + (l & 15);
+        const int br = wn * 64 + i * 16 + (l & 15);
+        af[i] = *(const bf16x8*)(sa + swz_nt(ar, ch));
+        bfr[i] = *(const bf16x8*)(sb + swz_nt(br, ch));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // D[n][m]
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds m = .. + (l&15), n = .. + 4*(l>>4) + r  (4 consecutive n)
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int m = m0 + wm * 64 + i * 16 + (l & 15);
+    if (m >= M) continue;
+    size_t orow = (size_t)m;
+    if (e.grp_in > 0) orow = (size_t)(m / e.grp_in) * e.grp_out + (m % e.grp_in);
+    const float* radd = nullptr;
+    if (e.rowadd) radd = e.rowadd + (size_t)(e.rowidx ? e.rowidx[m] : m) * e.ldr;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * (l >> 4);
+      if (n >= N) continue;
+      f32x4 v = acc[i][j];
+      v *= e.alpha;
+      if (e.bias) v += *(const f32x4*)(e.bias + n);
+      if (radd) v += *(const f32x4*)(radd + n);
+      if (e.dgelu_pre) {
+        const u32x2 p = *(const u32x2*)(e.dgelu_pre + (size_t)m * e.ld_pre + n);
+        v[0] *= gelu_erf_grad(bf_lo(p[0]));
+        v[1] *= gelu_erf_grad(bf_hi(p[0]));
+        v[2] *= gelu_erf_grad(bf_lo(p[1]));
+        v[3] *= gelu_erf_grad(bf_hi(p[1]));
+      }
+      if (e.act_gelu) {
+        if (e.aux_pre) {
+          u32x2 p = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+          *(u32x2*)(e.aux_pre + orow * e.ld_aux + n) = p;
+          // GELU is applied to the bf16-rounded pre-activation (what autocast's bf16 linear output feeds gelu)
+          v[0] = bf_lo(p[0]); v[1] = bf_hi(p[0]); v[2] = bf_lo(p[1]); v[3] = bf_hi(p[1]);
+        }
+        v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+      }
+      if (e.out_f32) *(f32x4*)(e.out_f32 + orow * e.ld_of + n) = v;
+      if (e.out_bf16) {
+        u32x2 p = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+        *(u32x2*)(e.out_bf16 + orow * e.ld_ob + n) = p;
+      }
+    }
+  }
+}
+
+int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt: empty problem M=%d N=%d K=%d", M, N, K); return SMBV_ERR_SHAPE; }
+  if ((K & 7) || (lda & 7) || (ldb & 7) || (N & 3)) { set_error("gemm_nt: K,lda,ldb must be multiples of 8 and N of 4 (K=%d lda=%d ldb=%d N=%d)", K, lda, ldb, N); return SMBV_ERR_SHAPE; }
+  if (((uintptr_t)A | (uintptr_t)B) & 15) { set_error("gemm_nt: operands must be 16-byte aligned"); return SMBV_ERR_ALIGN; }
+  if ((e.out_bf16 && ((e.ld_ob & 3) || ((uintptr_t)e.out_bf16 & 7))) || (e.out_f32 && ((e.ld_of & 3) || ((uintptr_t)e.out_f32 & 15))) ||
+      (e.bias && ((uintptr_t)e.bias & 15)) || (e.rowadd && ((e.ldr & 3) || ((uintptr_t)e.rowadd & 15))) ||
+      (e.dgelu_pre && ((e.ld_pre & 3) || ((uintptr_t)e.dgelu_pre & 7))) || (e.aux_pre && ((e.ld_aux & 3) || ((uintptr_t)e.aux_pre & 7)))) {
+    set_error("gemm_nt: epilogue operand alignment/stride"); return SMBV_ERR_ALIGN;
+  }
+  const int tm = cdiv(M, BM), tn = cdiv(N, BN);
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3(tm * tn), dim3(256), 0, st, A, lda, B, ldb, M, N, K, tm, e);
+  return check_launch("gemm_nt");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// TN (wgrad)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sw_tn(int m) { return (m & 3) | (((m >> 3) & 1) << 2); }
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y,
+                                                      int ldy, int M, int N1, int N2, float* __restrict__ out, int ldo,
+                                                      int tiles_1, int mchunk, size_t slab_stride) {
+  // LDS: [buf][X|Y][64 m][128 n] bf16 (256-B rows) = 2*2*16 KiB
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * BK * 128 * 2];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int w1 = w >> 1, w2 = w & 1;  // wave's 64-wide slice of n1 / n2
+  const int tile_1 = blockIdx.x % tiles_1, tile_2 = blockIdx.x / tiles_1;
+  const int a0 = tile_1 * 128, b0 = tile_2 * 128;  // n1 / n2 origin
+  const int z = blockIdx.y;
+  const int mbeg = z * mchunk, mend = min(M, mbeg + mchunk);
+  const int nk = (mend - mbeg + BK - 1) / BK;
+
+  f32x4 acc[4][4];  // [n1 tile i][n2 tile j], D rows <-> n2, cols <-> n1
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 rx[4], ry[4];
+  auto gload = [&](int kt) {
+    const int mm0 = mbeg + kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int id = t + 256 * i, row = id >> 4, c16 = id & 15;
+      const int gm = mm0 + row;
+      const int ga = a0 + c16 * 8, gb = b0 + c16 * 8;
+      rx[i] = (gm < mend && ga < N1) ? *(const u32x4*)(X + (size_t)gm * ldx + ga) : (u32x4){0, 0, 0, 0};
+      ry[i] = (gm < mend && gb < N2) ? *(const u32x4*)(Y + (size_t)gm * ldy + gb) : (u32x4){0, 0, 0, 0};
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* sx = smem + buf * (2 * BK * 256);
+    unsigned char* sy = sx + BK * 256;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int id = t + 256 * i, row = id >> 4, c16 = id & 15;
+      const int off = row * 256 + 32 * ((c16 >> 1) ^ sw_tn(row)) + 16 * (c16 & 1);
+      *(u32x4*)(sx + off) = rx[i];
+      *(u32x4*)(sy + off) = ry[i];
+    }
+  };
+
+  if (nk > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+  const int g = l >> 4, q = (l >> 2) & 3, p = l & 3;
+  for (int kt = 0; kt < nk; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const unsigned char* sx = smem + buf * (2 * BK * 256);
+    const unsigned char* sy = sx + BK * 256;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      bf16x8 xf[4], yf[4];
+      const int mA = 32 * ks + 8 * g + q, mB = mA + 4;
+      const int swA = sw_tn(mA), swB = sw_tn(mB);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int nt1 = w1 * 4 + i, nt2 = w2 * 4 + i;
+        s16x4 x0 = lds_read_tr16(sx + mA * 256 + 32 * (nt1 ^ swA) + 8 * p);
+        s16x4 x1 = lds_read_tr16(sx + mB * 256 + 32 * (nt1 ^ swB) + 8 * p);
+        s16x4 y0 = lds_read_tr16(sy + mA * 256 + 32 * (nt2 ^ swA) + 8 * p);
+        s16x4 y1 = lds_read_tr16(sy + mB * 256 + 32 * (nt2 ^ swB) + 8 * p);
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 xx = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        s16x8 yy = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+        xf[i] = __builtin_bit_cast(bf16x8, xx);
+        yf[i] = __builtin_bit_cast(bf16x8, yy);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[j], xf[i], acc[i][j], 0, 0, 0);  // D[n2][n1]
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* o = out + (size_t)z * slab_stride;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int n1 = a0 + w1 * 64 + i * 16 + (l & 15);
+    if (n1 >= N1) continue;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int n2 = b0 + w2 * 64 + j * 16 + 4 * (l >> 4);
+      if (n2 >= N2) continue;
+      *(f32x4*)(o + (size_t)n1 * ldo + n2) = acc[i][j];
+    }
+  }
+}
+
+__global__ void reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ slabs, int nslab, size_t n4, size_t slab_stride4) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 s = ((const f32x4*)slabs)[i];
+    for (int z = 1; z < nslab; z++) s += ((const f32x4*)slabs)[i + z * slab_stride4];
+    ((f32x4*)out)[i] = s;
+  }
+}
+
+int gemm_tn_splits(int M, int N1, int N2) {
+  const int tiles = cdiv(N1, 128) * cdiv(N2, 128);
+  int s = 1;
+  while (tiles * s < 384 && s < 32 && M / (s * 2) >= 256) s *= 2;
+  return s;
+}
+
+size_t gemm_tn_workspace_bytes(int M, int N1, int N2) {
+  const int s = gemm_tn_splits(M, N1, N2);
+  return s > 1 ? (size_t)s * N1 * N2 * sizeof(float) : 0;
+}
+
+int gemm_tn(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int M, int N1, int N2, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (M <= 0 || N1 <= 0 || N2 <= 0) { set_error("gemm_tn: empty problem"); return SMBV_ERR_SHAPE; }
+  if ((N1 & 7) || (N2 & 7) || (ldx & 7) || (ldy & 7)) { set_error("gemm_tn: N1,N2,ldx,ldy must be multiples of 8 (N1=%d N2=%d ldx=%d ldy=%d)", N1, N2, ldx, ldy); return SMBV_ERR_SHAPE; }
+  if (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)out) & 15) { set_error("gemm_tn: operands must be 16-byte aligned"); return SMBV_ERR_ALIGN; }
+  const int s = gemm_tn_splits(M, N1, N2);
+  const int t1 = cdiv(N1, 128), t2 = cdiv(N2, 128);
+  if (s == 1) {
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(t1 * t2, 1), dim3(256), 0, st, X, ldx, Y, ldy, M, N1, N2, out, N2, t1, ((M + 63) / 64) * 64, (size_t)0);
+    return check_launch("gemm_tn");
+  }
+  const size_t need = (size_t)s * N1 * N2 * sizeof(float);
+  if (!ws || ws_bytes < need || ((uintptr_t)ws & 15)) { set_error("gemm_tn: workspace too small (%zu < %zu)", ws_bytes, need); return SMBV_ERR_WORKSPACE; }
+  int mchunk = cdiv(cdiv(M, s), 64) * 64;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(t1 * t2, s), dim3(256), 0, st, X, ldx, Y, ldy, M, N1, N2, (float*)ws, N2, t1, mchunk, (size_t)N1 * N2);
+  int rc = check_launch("gemm_tn");
+  if (rc) return rc;
+  const size_t n4 = (size_t)N1 * N2 / 4;
+  const int grid = (int)std::min<size_t>(2048, (n4 + 255) / 256);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, st, out, (const float*)ws, s, n4, n4);
+  return check_launch("reduce_slabs");
+}
+
+}  // namespace smbv

@@ -1,0 +1,65 @@
+// Shared device helpers for the smbv HIP kernels (gfx950 / CDNA4 only: 64-wide waves, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef uint16_t bf16_t;  // storage type for bf16 in global memory
+
+#define SMBV_OK 0
+#define SMBV_ERR_SHAPE (-1)
+#define SMBV_ERR_ALIGN (-2)
+#define SMBV_ERR_ARG (-3)
+#define SMBV_ERR_WORKSPACE (-4)
+
+namespace smbv {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// transposed LDS read (verified by tools/probe/hw_probe.hip): per 16-lane group a 4x16 block of 16-bit
+// elements; lane 4q+p supplies &block[q][4p]; lane i receives {block[0][i], block[1][i], block[2][i], block[3][i]}.
+__device__ __forceinline__ s16x4 lds_read_tr16(const void* lds_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)lds_addr);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace smbv

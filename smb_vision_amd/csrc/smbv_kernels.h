@@ -1,0 +1,61 @@
+// Internal C++ launch functions (one per kernel family).  Every function enqueues on `st`, never allocates device
+// memory, never synchronises, and returns SMBV_OK or a negative SMBV_ERR_* / positive hipError_t.
+#pragma once
+#include "smbv_common.h"
+#include <algorithm>
+#include <cstddef>
+
+namespace smbv {
+
+// Epilogue of gemm_nt, applied to the fp32 accumulator tile before the store.
+struct GemmEpi {
+  float alpha = 1.0f;               // acc *= alpha
+  const float* bias = nullptr;      // + bias[n]
+  const float* rowadd = nullptr;    // + rowadd[(rowidx ? rowidx[m] : m) * ldr + n]   (residual stream / position table)
+  const int* rowidx = nullptr;
+  int ldr = 0;
+  const bf16_t* dgelu_pre = nullptr;  // *= gelu'(dgelu_pre[m * ld_pre + n])          (dgrad through GELU)
+  int ld_pre = 0;
+  int act_gelu = 0;                 // exact-erf GELU; when aux_pre != null the bf16 pre-activation is stored there
+  bf16_t* aux_pre = nullptr;
+  int ld_aux = 0;
+  bf16_t* out_bf16 = nullptr;
+  int ld_ob = 0;
+  float* out_f32 = nullptr;
+  int ld_of = 0;
+  int grp_in = 0, grp_out = 0;      // output row remap: (m / grp_in) * grp_out + m % grp_in   (0 = identity)
+};
+
+int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, hipStream_t st);
+int gemm_tn(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int M, int N1, int N2, float* out, void* ws, size_t ws_bytes, hipStream_t st);
+size_t gemm_tn_workspace_bytes(int M, int N1, int N2);
+
+int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd, int rows, int D, float eps,
+                  long grp_in, long grp_out, long row_off, hipStream_t st);
+int layernorm_bwd(const bf16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
+                  bf16_t* dx_bf16, float* dgamma, float* dbeta, int rows, int D, long grp_in, long grp_out, long row_off, void* ws,
+                  size_t ws_bytes, hipStream_t st);
+size_t layernorm_bwd_workspace_bytes(int rows, int D);
+
+int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf16_t* O, int ldo, float* LSE, int B, int S, int H, int Dh,
+                  float scale, hipStream_t st);
+int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
+                  float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, hipStream_t st);
+
+int gather_bricks(const float* pix, const int* idx, int rows, int per_batch, bf16_t* out, int T, int H, int W, int ts, int ps, hipStream_t st);
+int brick_stats(const float* pix, const int* idx, int rows, int per_batch, float* mean, float* rinv, int T, int H, int W, int ts, int ps,
+                hipStream_t st);
+int mse_fwd(const float* pix, const int* idx, int rows, int per_batch, const float* mean, const float* rinv, const bf16_t* logits,
+            float* row_partial, float* loss, int T, int H, int W, int ts, int ps, hipStream_t st);
+int mse_bwd(const float* pix, const int* idx, int rows, int per_batch, const float* mean, const float* rinv, const bf16_t* logits,
+            bf16_t* dlogits, const float* gscale, int T, int H, int W, int ts, int ps, hipStream_t st);
+
+int cast_f32_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st);
+int transpose_cast_f32_bf16(const float* src, bf16_t* dst, int R, int C, int ldd, hipStream_t st);
+int fill_mask_rows(float* xfull, const float* mask_token, const float* pos, const int* mask_idx, int B, int nmask, int nvis, int D, hipStream_t st);
+int gather_rows_bf16(const bf16_t* in, bf16_t* out, int rows, int D, long grp_in, long grp_out, long row_off, hipStream_t st);
+int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, long grp_in, long grp_out, long row_off, void* ws, size_t ws_bytes, hipStream_t st);
+int colsum_f32(const float* X, int ld, int M, int N, float* out, long grp_in, long grp_out, long row_off, void* ws, size_t ws_bytes, hipStream_t st);
+size_t colsum_workspace_bytes(int M, int N);
+
+}  // namespace smbv

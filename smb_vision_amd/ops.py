@@ -1,0 +1,190 @@
+"""Per-op Python wrappers over the C ABI (torch tensors in, torch tensors out; all work happens in libsmbv.so on the
+current HIP stream).  These are what the GPU parity tests call; the model itself drives the fused whole-step entry
+points (see modeling_videomae.py).  Nothing here computes with PyTorch — tensors are only device memory."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import GemmEpi, check
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.SmbvError("smb_vision_amd ops need tensors on a HIP device (no CPU fallback)")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ws(nbytes, dev):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+
+
+def gemm_nt(A, B, *, bias=None, rowadd=None, rowidx=None, gelu=False, save_pre=False, dgelu_pre=None, out_bf16=True, out_f32=False,
+            alpha=1.0, grp=None, out_rows=None):
+    """C = epi(A[M,K] @ B[N,K]^T).  Returns dict with 'bf16', 'f32', 'pre' entries as requested."""
+    _need_gpu(A, B)
+    lib = _lib.load()
+    M, K = A.shape
+    N = B.shape[0]
+    rows = out_rows or M
+    res = {}
+    e = GemmEpi()
+    e.alpha = alpha
+    e.bias = _p(bias)
+    e.rowadd, e.rowidx, e.ldr = _p(rowadd), _p(rowidx), (rowadd.stride(0) if rowadd is not None else 0)
+    e.dgelu_pre, e.ld_pre = _p(dgelu_pre), (dgelu_pre.stride(0) if dgelu_pre is not None else 0)
+    e.act_gelu = int(gelu)
+    if save_pre:
+        res["pre"] = torch.empty(rows, N, dtype=torch.bfloat16, device=A.device)
+        e.aux_pre, e.ld_aux = res["pre"].data_ptr(), N
+    if out_bf16:
+        res["bf16"] = torch.zeros(rows, N, dtype=torch.bfloat16, device=A.device)
+        e.out_bf16, e.ld_ob = res["bf16"].data_ptr(), N
+    if out_f32:
+        res["f32"] = torch.zeros(rows, N, dtype=torch.float32, device=A.device)
+        e.out_f32, e.ld_of = res["f32"].data_ptr(), N
+    if grp:
+        e.grp_in, e.grp_out = grp
+    check(lib.smbv_gemm_nt(_p(A), A.stride(0), _p(B), B.stride(0), M, N, K, C.byref(e), _stream()), "smbv_gemm_nt")
+    return res
+
+
+def gemm_tn(X, Y):
+    """out[N1,N2] fp32 = X[M,N1]^T @ Y[M,N2]."""
+    _need_gpu(X, Y)
+    lib = _lib.load()
+    M, N1 = X.shape
+    N2 = Y.shape[1]
+    out = torch.empty(N1, N2, dtype=torch.float32, device=X.device)
+    ws = _ws(lib.smbv_gemm_tn_workspace_bytes(M, N1, N2), X.device)
+    check(lib.smbv_gemm_tn(_p(X), X.stride(0), _p(Y), Y.stride(0), M, N1, N2, _p(out), _p(ws), ws.numel(), _stream()), "smbv_gemm_tn")
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps, rows=None, grp=(0, 0, 0)):
+    _need_gpu(x, gamma, beta)
+    lib = _lib.load()
+    D = x.shape[-1]
+    rows = rows if rows is not None else x.numel() // D
+    y = torch.empty(rows, D, dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib.smbv_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, D, eps, *grp, _stream()), "smbv_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, grp=(0, 0, 0)):
+    _need_gpu(dy, x)
+    lib = _lib.load()
+    rows, D = dy.shape
+    dx = torch.zeros_like(x, dtype=torch.float32)
+    dxb = torch.zeros_like(x, dtype=torch.bfloat16)
+    dg = torch.empty(D, dtype=torch.float32, device=x.device)
+    db = torch.empty(D, dtype=torch.float32, device=x.device)
+    ws = _ws(lib.smbv_layernorm_bwd_workspace_bytes(rows, D), x.device)
+    check(lib.smbv_layernorm_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dxb), _p(dg), _p(db), rows, D, *grp,
+                                 _p(ws), ws.numel(), _stream()), "smbv_layernorm_bwd")
+    return dx, dxb, dg, db
+
+
+def attention_fwd(qkv, B, S, H, scale=None):
+    """qkv: bf16 [B*S, 3*H*64] (q | k | v column blocks).  Returns (O bf16 [B*S, H*64], LSE fp32 [B,H,S])."""
+    _need_gpu(qkv)
+    lib = _lib.load()
+    w = H * 64
+    scale = scale if scale is not None else 64 ** -0.5
+    O = torch.empty(B * S, w, dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=qkv.device)
+    base = qkv.data_ptr()
+    check(lib.smbv_attention_fwd(base, base + 2 * w, base + 4 * w, qkv.stride(0), _p(O), w, _p(lse), B, S, H, 64, scale, _stream()),
+          "smbv_attention_fwd")
+    return O, lse
+
+
+def attention_bwd(qkv, O, dO, lse, B, S, H, scale=None):
+    _need_gpu(qkv, O, dO, lse)
+    lib = _lib.load()
+    w = H * 64
+    scale = scale if scale is not None else 64 ** -0.5
+    dqkv = torch.zeros_like(qkv)
+    delta = torch.empty(B, H, S, dtype=torch.float32, device=qkv.device)
+    base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+    check(lib.smbv_attention_bwd(base, base + 2 * w, base + 4 * w, qkv.stride(0), _p(O), _p(dO), w, _p(lse), _p(delta), dbase, dbase + 2 * w,
+                                 dbase + 4 * w, dqkv.stride(0), B, S, H, 64, scale, _stream()), "smbv_attention_bwd")
+    return dqkv, delta
+
+
+def gather_bricks(pix, idx, per_batch, ts, ps):
+    _need_gpu(pix, idx)
+    lib = _lib.load()
+    B, T, Cc, H, W = pix.shape
+    rows = idx.numel()
+    out = torch.empty(rows, ts * ps * ps, dtype=torch.bfloat16, device=pix.device)
+    check(lib.smbv_gather_bricks(_p(pix), _p(idx), rows, per_batch, _p(out), T, H, W, ts, ps, _stream()), "smbv_gather_bricks")
+    return out
+
+
+def brick_stats(pix, idx, per_batch, ts, ps):
+    _need_gpu(pix, idx)
+    lib = _lib.load()
+    B, T, Cc, H, W = pix.shape
+    rows = idx.numel()
+    mean = torch.empty(rows, dtype=torch.float32, device=pix.device)
+    rinv = torch.empty(rows, dtype=torch.float32, device=pix.device)
+    check(lib.smbv_brick_stats(_p(pix), _p(idx), rows, per_batch, _p(mean), _p(rinv), T, H, W, ts, ps, _stream()), "smbv_brick_stats")
+    return mean, rinv
+
+
+def mse_fwd(pix, idx, per_batch, mean, rinv, logits, ts, ps):
+    lib = _lib.load()
+    B, T, Cc, H, W = pix.shape
+    rows = idx.numel()
+    part = torch.empty(rows, dtype=torch.float32, device=pix.device)
+    loss = torch.empty(1, dtype=torch.float32, device=pix.device)
+    check(lib.smbv_mse_fwd(_p(pix), _p(idx), rows, per_batch, _p(mean), _p(rinv), _p(logits), _p(part), _p(loss), T, H, W, ts, ps, _stream()),
+          "smbv_mse_fwd")
+    return loss
+
+
+def mse_bwd(pix, idx, per_batch, mean, rinv, logits, ts, ps, gscale=None):
+    lib = _lib.load()
+    B, T, Cc, H, W = pix.shape
+    rows = idx.numel()
+    dl = torch.empty_like(logits)
+    check(lib.smbv_mse_bwd(_p(pix), _p(idx), rows, per_batch, _p(mean), _p(rinv), _p(logits), _p(dl), _p(gscale), T, H, W, ts, ps, _stream()),
+          "smbv_mse_bwd")
+    return dl
+
+
+def cast_bf16(x):
+    lib = _lib.load()
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib.smbv_cast_f32_bf16(_p(x), _p(out), x.numel(), _stream()), "smbv_cast_f32_bf16")
+    return out
+
+
+def transpose_cast_bf16(x):
+    lib = _lib.load()
+    R, Cc = x.shape
+    out = torch.empty(Cc, R, dtype=torch.bfloat16, device=x.device)
+    check(lib.smbv_transpose_cast_f32_bf16(_p(x), _p(out), R, Cc, R, _stream()), "smbv_transpose_cast_f32_bf16")
+    return out
+
+
+def colsum_bf16(X):
+    lib = _lib.load()
+    M, N = X.shape
+    out = torch.empty(N, dtype=torch.float32, device=X.device)
+    ws = _ws(lib.smbv_colsum_workspace_bytes(M, N), X.device)
+    check(lib.smbv_colsum_bf16(_p(X), X.stride(0), M, N, _p(out), _p(ws), ws.numel(), _stream()), "smbv_colsum_bf16")
+    return out

@@ -1,0 +1,217 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (smb_vision_amd.ops -> libsmbv.so).
+
+Each kernel is compared with a plain PyTorch fp32 computation of the same op on the same (bf16-rounded) operands.
+Tolerances: the kernels take bf16 operands, accumulate in fp32 and (mostly) round the result to bf16, so an output
+element may be off by one bf16 ulp (2^-8 relative) of its magnitude plus fp32 summation-order noise.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from smb_vision_amd import ops as o
+    return o
+
+
+def rel_err(a, b):
+    return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-30))
+
+
+def rms_err(a, b):
+    return float((a.float() - b.float()).pow(2).mean().sqrt() / (b.float().pow(2).mean().sqrt() + 1e-30))
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (1, 8, 8), (1000, 768, 768), (333, 2304, 768), (26, 4096, 64)])
+def test_gemm_nt_plain(ops, M, N, K):
+    A = rnd(M, K, seed=1).bfloat16()
+    B = rnd(N, K, seed=2).bfloat16()
+    bias = rnd(N, seed=3)
+    r = ops.gemm_nt(A, B, bias=bias, out_bf16=True, out_f32=True)
+    ref = A.float() @ B.float().t() + bias
+    assert rel_err(r["f32"], ref) < 1e-5 * math.sqrt(K) + 1e-6
+    assert rel_err(r["bf16"], ref) < 6e-3
+
+
+def test_gemm_nt_asymmetric_identity(ops):
+    # A = I with an asymmetric B catches a transposed store
+    A = torch.eye(128, device="cuda").bfloat16()
+    B = (torch.arange(128 * 128, device="cuda").reshape(128, 128) % 251).float().bfloat16()
+    r = ops.gemm_nt(A, B, out_bf16=False, out_f32=True)
+    assert torch.equal(r["f32"], B.float().t().contiguous())
+
+
+def test_gemm_nt_epilogues(ops):
+    M, N, K = 300, 256, 128
+    A = rnd(M, K, seed=1).bfloat16()
+    B = rnd(N, K, seed=2, scale=0.1).bfloat16()
+    bias = rnd(N, seed=3)
+    resid = rnd(M, N, seed=4)
+    # bias + residual -> fp32
+    r = ops.gemm_nt(A, B, bias=bias, rowadd=resid, out_bf16=True, out_f32=True)
+    ref = A.float() @ B.float().t() + bias + resid
+    assert rel_err(r["f32"], ref) < 1e-4
+    # gathered row add (position table) + output row remap
+    table = rnd(50, N, seed=5)
+    idx = torch.randint(0, 50, (M,), device="cuda", dtype=torch.int32)
+    r = ops.gemm_nt(A, B, rowadd=table, rowidx=idx, out_bf16=False, out_f32=True, grp=(100, 150), out_rows=450)
+    ref = A.float() @ B.float().t() + table[idx.long()]
+    out = r["f32"].view(3, 150, N)[:, :100].reshape(M, N)
+    assert rel_err(out, ref) < 1e-4
+    # GELU with saved pre-activation
+    r = ops.gemm_nt(A, B, bias=bias, gelu=True, save_pre=True)
+    pre = (A.float() @ B.float().t() + bias)
+    assert rel_err(r["pre"], pre) < 6e-3
+    ref = torch.nn.functional.gelu(r["pre"].float())
+    assert rel_err(r["bf16"], ref) < 6e-3
+    # dgrad through GELU
+    pre_b = rnd(M, N, seed=7).bfloat16()
+    r = ops.gemm_nt(A, B, dgelu_pre=pre_b)
+    x = pre_b.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    ref = (A.float() @ B.float().t()) * x.grad
+    assert rel_err(r["bf16"], ref) < 8e-3
+
+
+@pytest.mark.parametrize("M,N1,N2", [(64, 128, 128), (300, 136, 72), (26, 64, 4096), (4096, 128, 128), (1000, 768, 256), (7, 8, 8)])
+def test_gemm_tn(ops, M, N1, N2):
+    X = rnd(M, N1, seed=1).bfloat16()
+    Y = rnd(M, N2, seed=2).bfloat16()
+    out = ops.gemm_tn(X, Y)
+    ref = X.float().t() @ Y.float()
+    assert rel_err(out, ref) < 1e-5 * math.sqrt(M) + 1e-6
+
+
+def test_gemm_tn_asymmetric(ops):
+    M = 128
+    X = torch.eye(M, device="cuda").bfloat16()                       # X^T Y = Y
+    Y = (torch.arange(M * 64, device="cuda").reshape(M, 64) % 127).float().bfloat16()
+    assert torch.equal(ops.gemm_tn(X, Y), Y.float())
+
+
+@pytest.mark.parametrize("rows,D", [(5, 64), (1000, 768), (333, 384), (64, 128), (17, 1024)])
+def test_layernorm(ops, rows, D):
+    x = rnd(rows, D, seed=1) * 2 + 0.5
+    g = 1 + 0.1 * rnd(D, seed=2)
+    b = 0.1 * rnd(D, seed=3)
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-12)
+    ref = torch.nn.functional.layer_norm(x, (D,), g, b, 1e-12)
+    assert rel_err(y, ref) < 6e-3
+    assert rel_err(mean, x.mean(-1)) < 1e-5
+    dy = rnd(rows, D, seed=4).bfloat16()
+    dres = rnd(rows, D, seed=5)
+    dx, dxb, dg, db = ops.layernorm_bwd(dy, x, mean, rstd, g, dres)
+    xr = x.clone().requires_grad_(True)
+    gr = g.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-12).backward(dy.float())
+    assert rel_err(dx, xr.grad + dres) < 2e-5
+    assert rel_err(dxb, xr.grad + dres) < 6e-3
+    assert rel_err(dg, gr.grad) < 1e-4
+    assert rel_err(db, br.grad) < 1e-4
+
+
+def test_layernorm_row_remap(ops):
+    # decoder.norm reads the last n_mask rows of every volume
+    B, N, nmask, D = 2, 10, 6, 64
+    x = rnd(B * N, D, seed=1)
+    g, b = 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-5, rows=B * nmask, grp=(nmask, N, N - nmask))
+    ref = torch.nn.functional.layer_norm(x.view(B, N, D)[:, N - nmask:].reshape(-1, D), (D,), g, b, 1e-5)
+    assert rel_err(y, ref) < 6e-3
+
+
+def _attn_ref(qkv, B, S, H):
+    w = H * 64
+    q, k, v = (qkv.float()[:, i * w:(i + 1) * w].view(B, S, H, 64).transpose(1, 2) for i in range(3))
+    s = q @ k.transpose(-1, -2) * 0.125
+    return q, k, v, s
+
+
+@pytest.mark.parametrize("B,S,H", [(1, 32, 1), (2, 12, 2), (1, 100, 2), (2, 256, 1), (1, 1000, 3), (1, 2048, 2)])
+def test_attention_fwd_bwd(ops, B, S, H):
+    w = H * 64
+    qkv = rnd(B * S, 3 * w, seed=1).bfloat16()
+    O, lse = ops.attention_fwd(qkv, B, S, H)
+    qf = qkv.float().requires_grad_(True)
+    q, k, v, s = _attn_ref(qf, B, S, H)
+    p = torch.softmax(s, -1)
+    ref = (p @ v).transpose(1, 2).reshape(B * S, w)
+    assert rel_err(O, ref) < 1.5e-2
+    assert rms_err(O, ref) < 6e-3
+    assert rel_err(lse, torch.logsumexp(s, -1)) < 1e-4
+    dO = rnd(B * S, w, seed=2).bfloat16()
+    dqkv, delta = ops.attention_bwd(qkv, O, dO, lse, B, S, H)
+    ref.backward(dO.float())
+    assert rel_err(delta, (dO.float() * O.float()).view(B, S, H, 64).sum(-1).transpose(1, 2)) < 1e-4
+    for i, name in enumerate("qkv"):
+        a, b = dqkv[:, i * w:(i + 1) * w], qf.grad[:, i * w:(i + 1) * w]
+        assert rel_err(a, b) < 2.5e-2, name
+        assert rms_err(a, b) < 1e-2, name
+
+
+def test_attention_online_softmax_rescale(ops):
+    # spike one key per tile so the running max jumps at every tile boundary (exercises the rescale path)
+    B, S, H = 1, 512, 1
+    qkv = rnd(B * S, 192, seed=3).bfloat16()
+    for t in range(0, S, 64):
+        qkv[t + (t // 64) % 64, 64:128] *= (4 + t / 64)
+    O, lse = ops.attention_fwd(qkv, B, S, H)
+    q, k, v, s = _attn_ref(qkv, B, S, H)
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * S, 64)
+    assert rel_err(O, ref) < 1.5e-2
+    assert rel_err(lse, torch.logsumexp(s, -1)) < 1e-4
+
+
+@pytest.mark.parametrize("ps,ts", [(16, 16), (8, 8), (4, 8)])
+def test_bricks_stats_mse(ops, ps, ts):
+    B, T, H, W = 2, 32, 64, 64
+    pix = torch.rand(B, T, 1, H, W, generator=torch.Generator().manual_seed(0)).cuda()
+    gh, gw = H // ps, W // ps
+    N = (T // ts) * gh * gw
+    K = ts * ps * ps
+    nsel = max(2, N // 3)
+    idx = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b))[:nsel].sort().values for b in range(B)]).int().cuda()
+    # reference patchify: conv-weight order (kt,kh,kw) == label order (ts,ps,ps,C) for C = 1
+    f = pix.view(B, T // ts, ts, 1, gh, ps, gw, ps).permute(0, 1, 4, 6, 2, 5, 7, 3).reshape(B, N, K)
+    sel = torch.gather(f, 1, idx.long()[..., None].expand(-1, -1, K)).reshape(B * nsel, K)
+    out = ops.gather_bricks(pix, idx, nsel, ts, ps)
+    assert torch.equal(out, sel.bfloat16())
+    mean, rinv = ops.brick_stats(pix, idx, nsel, ts, ps)
+    assert rel_err(mean, sel.mean(-1)) < 1e-5
+    assert rel_err(rinv, 1 / (sel.var(-1, unbiased=True).sqrt() + 1e-6)) < 1e-4
+    labels = (sel - sel.mean(-1, keepdim=True)) / (sel.var(-1, unbiased=True, keepdim=True).sqrt() + 1e-6)
+    logits = rnd(B * nsel, K, seed=5).bfloat16()
+    loss = ops.mse_fwd(pix, idx, nsel, mean, rinv, logits, ts, ps)
+    ref = torch.nn.functional.mse_loss(logits.float(), labels)
+    assert abs(float(loss) - float(ref)) < 1e-5 * float(ref)
+    gs = torch.tensor([0.5], device="cuda")
+    dl = ops.mse_bwd(pix, idx, nsel, mean, rinv, logits, ts, ps, gs)
+    refd = 2 * (logits.float() - labels) / labels.numel() * 0.5
+    assert rel_err(dl, refd) < 6e-3
+
+
+def test_casts_and_colsum(ops):
+    x = rnd(96, 200, seed=1)
+    assert torch.equal(ops.cast_bf16(x), x.bfloat16())
+    assert torch.equal(ops.transpose_cast_bf16(x), x.t().contiguous().bfloat16())
+    X = rnd(1000, 264, seed=2).bfloat16()
+    assert rel_err(ops.colsum_bf16(X), X.float().sum(0)) < 1e-5
+
+
+def test_errors_are_loud(ops):
+    A = rnd(16, 12).bfloat16()  # K = 12 is not a multiple of 8
+    with pytest.raises(ValueError):
+        ops.gemm_nt(A, A)
+    with pytest.raises(Exception):
+        ops.gemm_nt(A.cpu(), A.cpu())
