@@ -1,0 +1,444 @@
+"""``SmbVideoMAEForPreTraining`` — the MI355X-native drop-in for the model class ``src/run_mim.py`` trains.
+
+Host-side mirror of ``VideoMAEForPreTraining`` (reference spec ``src/models/videomae/modeling_videomae.py:734-908``; the class
+``run_mim.py:13-21,345-357`` instantiates): same constructor (``Cls(config: VideoMAEConfig)`` / ``from_pretrained``), same
+``forward(pixel_values, bool_masked_pos)`` contract, same output object (``.loss`` first, ``.logits``), same errors, same
+state-dict names (pinned-era layout; transformers-5 ``query/key/value.bias`` checkpoints are accepted on
+load).  All arithmetic of the step — patch embedding, encoder, decoder, targets, loss, and the whole backward — runs in
+libsmbv.so (hand-written HIP for gfx950) through two C calls, ``smbv_mim_forward`` / ``smbv_mim_backward``; PyTorch only
+owns device memory, streams and the autograd edge.  There is no CPU or eager fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import collections.abc
+import ctypes as C
+import weakref
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import nn
+from transformers import PreTrainedModel, VideoMAEConfig
+from transformers.utils import ModelOutput
+
+from . import _lib
+from .masking import split_mask_indices
+
+
+@dataclass
+class SmbVideoMAEForPreTrainingOutput(ModelOutput):
+    """Same fields as the reference's ``VideoMAEForPreTrainingOutput`` (spec :74-91)."""
+
+    loss: Optional[torch.FloatTensor] = None
+    logits: Optional[torch.FloatTensor] = None
+    hidden_states: Optional[tuple] = None
+    attentions: Optional[tuple] = None
+
+
+def get_sinusoid_encoding_table(n_position: int, d_hid: int) -> torch.Tensor:
+    """Fixed sin-cos table, float64 numpy then fp32, ``[1, n_position, d_hid]`` (spec :95-106), vectorised."""
+    pos = np.arange(n_position, dtype=np.float64)[:, None]
+    j = np.arange(d_hid)
+    tab = pos / np.power(10000, 2 * (j // 2) / d_hid)[None, :]
+    tab[:, 0::2] = np.sin(tab[:, 0::2])
+    tab[:, 1::2] = np.cos(tab[:, 1::2])
+    return torch.from_numpy(tab.astype(np.float32)).unsqueeze(0)
+
+
+_LAYER_SUFFIXES = (  # (state-dict suffix, C field, shape code)
+    ("layernorm_before.weight", "ln1_w", "w"), ("layernorm_before.bias", "ln1_b", "w"),
+    ("attention.attention.query.weight", "q_w", "ww"), ("attention.attention.key.weight", "k_w", "ww"),
+    ("attention.attention.value.weight", "v_w", "ww"),
+    ("attention.attention.q_bias", "q_b", "w"), ("attention.attention.v_bias", "v_b", "w"),
+    ("attention.output.dense.weight", "proj_w", "ww"), ("attention.output.dense.bias", "proj_b", "w"),
+    ("layernorm_after.weight", "ln2_w", "w"), ("layernorm_after.bias", "ln2_b", "w"),
+    ("intermediate.dense.weight", "fc1_w", "fw"), ("intermediate.dense.bias", "fc1_b", "f"),
+    ("output.dense.weight", "fc2_w", "wf"), ("output.dense.bias", "fc2_b", "w"),
+)
+
+
+def param_table(config) -> "list[tuple[str, tuple, tuple]]":
+    """[(state-dict name, shape, C-struct path)] in canonical (forward) order."""
+    d, ff = config.hidden_size, config.intermediate_size
+    dd, dff = config.decoder_hidden_size, config.decoder_intermediate_size
+    ts, ps, c = int(config.tubelet_size), _pair(config.patch_size)[0], config.num_channels
+    out = [("videomae.embeddings.patch_embeddings.projection.weight", (d, c, ts, ps, ps), ("pe_w",)),
+           ("videomae.embeddings.patch_embeddings.projection.bias", (d,), ("pe_b",))]
+
+    def layer(prefix, group, i, w, f):
+        shp = {"w": (w,), "ww": (w, w), "fw": (f, w), "f": (f,), "wf": (w, f)}
+        for suf, field, code in _LAYER_SUFFIXES:
+            out.append((prefix + suf, shp[code], (group, i, field)))
+
+    for i in range(config.num_hidden_layers):
+        layer(f"videomae.encoder.layer.{i}.", "enc", i, d, ff)
+    out.append(("encoder_to_decoder.weight", (dd, d), ("e2d_w",)))
+    out.append(("mask_token", (1, 1, dd), ("mask_token",)))
+    for i in range(config.decoder_num_hidden_layers):
+        layer(f"decoder.decoder_layers.{i}.", "dec", i, dd, dff)
+    K = c * ts * ps * ps
+    out += [("decoder.norm.weight", (dd,), ("dnorm_w",)), ("decoder.norm.bias", (dd,), ("dnorm_b",)),
+            ("decoder.head.weight", (K, dd), ("head_w",)), ("decoder.head.bias", (K,), ("head_b",))]
+    return out
+
+
+def _pair(x):
+    return tuple(x) if isinstance(x, collections.abc.Iterable) else (x, x)
+
+
+class _Slots(nn.Module):
+    """Pure parameter container; the hierarchy only exists to reproduce the reference's state-dict names."""
+
+
+def _register(root: nn.Module, dotted: str, p: nn.Parameter):
+    mod = root
+    parts = dotted.split(".")
+    for part in parts[:-1]:
+        if part not in mod._modules:
+            mod.add_module(part, _Slots())
+        mod = mod._modules[part]
+    mod.register_parameter(parts[-1], p)
+
+
+def _set_struct(struct, path, value):
+    if len(path) == 1:
+        setattr(struct, path[0], value)
+    else:
+        setattr(getattr(struct, path[0])[path[1]], path[2], value)
+
+
+class _MIMStepFn(torch.autograd.Function):
+    """Autograd edge around the two C calls.  Inputs: every parameter (so autograd routes their gradients)."""
+
+    @staticmethod
+    def forward(ctx, model_ref, pixel_values, vis_idx, mask_idx, *params):
+        model = model_ref()
+        loss, logits, st = model._run_forward(pixel_values, vis_idx, mask_idx)
+        ctx.model_ref = model_ref
+        ctx.st = st
+        ctx.mark_non_differentiable(logits)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_logits):
+        model = ctx.model_ref()
+        grads = model._run_backward(ctx.st, grad_loss)
+        ctx.st = None
+        return (None, None, None, None, *grads)
+
+
+class SmbVideoMAEForPreTraining(PreTrainedModel):
+    config_class = VideoMAEConfig
+    base_model_prefix = "videomae"
+    main_input_name = "pixel_values"
+    supports_gradient_checkpointing = True
+    _supports_sdpa = True
+    _supports_flash_attn = True
+    _supports_attention_backend = True
+
+    def __init__(self, config: VideoMAEConfig):
+        super().__init__(config)
+        self.config = config
+        if config.num_channels != 1:
+            raise ValueError("smb_vision_amd: the MI355X MIM path is built for single-channel volumes (num_channels=1, as src/run_mim.py:318 sets)")
+        if getattr(config, "hidden_act", "gelu") != "gelu":
+            raise ValueError("smb_vision_amd: only hidden_act='gelu' (exact erf) is implemented")
+        if not getattr(config, "qkv_bias", True):
+            raise ValueError("smb_vision_amd: qkv_bias=False is not implemented")
+        if not getattr(config, "norm_pix_loss", True):
+            # with num_channels != 3 the reference raises here too (spec :869-872)
+            raise ValueError("Can't unnormalize non-RGB images. Consider setting config.norm_pix_loss to False.")
+        self._table = param_table(config)
+        for name, shape, _ in self._table:
+            _register(self, name, nn.Parameter(torch.empty(shape)))
+        self.image_size = _pair(config.image_size)
+        self.patch_size = _pair(config.patch_size)
+        if self.patch_size[0] != self.patch_size[1]:
+            raise ValueError("smb_vision_amd: square patches only")
+        self.tubelet_size = int(config.tubelet_size)
+        self.num_patches = (self.image_size[1] // self.patch_size[1]) * (self.image_size[0] // self.patch_size[0]) * (
+            config.num_frames // self.tubelet_size)
+        self.gradient_checkpointing = False  # accepted for API compatibility; activations stay resident (288 GB HBM)
+        # non-persistent, device-resident state
+        self._pos = None          # (pos_enc, pos_dec) on the parameter device
+        self._gflat = None        # flat fp32 gradient arena; param.grad are views into it
+        self._structs = None      # (ptr signature, MimTensors params, MimTensors grads)
+        self._ws = None           # workspace tensor
+        self._ws_key = None
+        self._n_masked = None     # cached token split (validated lazily, no per-step host sync)
+        self._pending_check = None
+        self._fwd_count = 0
+        self.dp = None            # optional DataParallelEngine (smb_vision_amd.dp)
+        self.reset_parameters()
+        self.post_init()
+
+    # ------------------------------------------------------------------------------------------------------------
+    # parameters
+    # ------------------------------------------------------------------------------------------------------------
+    def reset_parameters(self):
+        """_init_weights semantics of the reference (spec :495-505, :742, :247-248)."""
+        std = self.config.initializer_range
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if name.endswith("weight") and p.dim() >= 2:
+                    p.normal_(mean=0.0, std=std)
+                elif "layernorm" in name or name.startswith("decoder.norm"):
+                    p.fill_(1.0) if name.endswith("weight") else p.zero_()
+                else:
+                    p.zero_()
+
+    def _init_weights(self, module):
+        # parameters live in _Slots containers and are initialised by reset_parameters(); from_pretrained calls this only for
+        # containers whose parameters were missing from the checkpoint
+        if not isinstance(module, _Slots) and module is not self:
+            return
+        names = {id(p): n for n, p in self.named_parameters()}
+        std = self.config.initializer_range
+        with torch.no_grad():
+            for _, p in module.named_parameters(recurse=False):
+                if getattr(p, "_is_hf_initialized", False):
+                    continue
+                n = names.get(id(p), "")
+                if n.endswith("weight") and p.dim() >= 2:
+                    p.normal_(mean=0.0, std=std)
+                elif ("layernorm" in n or n.startswith("decoder.norm")) and n.endswith("weight"):
+                    p.fill_(1.0)
+                else:
+                    p.zero_()
+
+    def _set_gradient_checkpointing(self, enable: bool = True, gradient_checkpointing_func=None):
+        self.gradient_checkpointing = enable
+
+    def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None):
+        # HF Trainer calls this with --gradient_checkpointing (trainer.py:1401).  Accepted and recorded; the HIP path keeps all
+        # activations of the step resident in HBM (~5 GB at ViT-base, 512x512x320), so nothing is recomputed.
+        self.gradient_checkpointing = True
+
+    def gradient_checkpointing_disable(self):
+        self.gradient_checkpointing = False
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *model_args, **kwargs):
+        """As ``PreTrainedModel.from_pretrained`` (``src/run_mim.py:345-355``), additionally accepting checkpoints written by
+        transformers >= 5 whose attention has ``query/key/value.bias`` instead of ``q_bias/v_bias``."""
+        if "key_mapping" not in kwargs:
+            kwargs["key_mapping"] = dict(_HF5_KEY_MAPPING)
+        return super().from_pretrained(pretrained_model_name_or_path, *model_args, **kwargs)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        convert_state_dict_keys(state_dict, prefix)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        sd = dict(state_dict)
+        convert_state_dict_keys(sd, "")
+        return super().load_state_dict(sd, strict=strict, assign=assign)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # device state
+    # ------------------------------------------------------------------------------------------------------------
+    def _cfg_struct(self, B, n_masked):
+        c = self.config
+        s = _lib.MimCfg()
+        s.B, s.T, s.H, s.W = B, c.num_frames, self.image_size[0], self.image_size[1]
+        s.ps, s.ts = self.patch_size[0], self.tubelet_size
+        s.N, s.Nvis, s.Nmask = self.num_patches, self.num_patches - n_masked, n_masked
+        s.d, s.heads, s.ff, s.layers = c.hidden_size, c.num_attention_heads, c.intermediate_size, c.num_hidden_layers
+        s.dd, s.dheads, s.dff, s.dlayers = (c.decoder_hidden_size, c.decoder_num_attention_heads, c.decoder_intermediate_size,
+                                            c.decoder_num_hidden_layers)
+        s.ln_eps = c.layer_norm_eps
+        s.dec_norm_eps = 1e-5
+        return s
+
+    def _ordered_params(self):
+        sd = dict(self.named_parameters())
+        return [sd[name] for name, _, _ in self._table]
+
+    def _ensure_device_state(self, device):
+        params = self._ordered_params()
+        for p in params:
+            if p.device != device or p.dtype != torch.float32 or not p.is_contiguous():
+                raise _lib.SmbvError("smb_vision_amd: parameters must be contiguous fp32 tensors on the input's HIP device "
+                                     f"(found {p.dtype} on {p.device}); mixed precision is internal to the kernels")
+        if self._pos is None or self._pos[0].device != device:
+            self._pos = (get_sinusoid_encoding_table(self.num_patches, self.config.hidden_size)[0].to(device).contiguous(),
+                         get_sinusoid_encoding_table(self.num_patches, self.config.decoder_hidden_size)[0].to(device).contiguous())
+        if self._gflat is None or self._gflat.device != device:
+            offs, off = [], 0
+            for p in params:
+                offs.append(off)
+                off += (p.numel() + 63) // 64 * 64
+            self._goffs = offs
+            self._gflat = torch.zeros(off, dtype=torch.float32, device=device)
+            self._structs = None
+        sig = tuple(p.data_ptr() for p in params)
+        if self._structs is None or self._structs[0] != sig:
+            ps, gs = _lib.MimTensors(), _lib.MimTensors()
+            gbase = self._gflat.data_ptr()
+            for p, off, (_, _, path) in zip(params, self._goffs, self._table):
+                _set_struct(ps, path, p.data_ptr())
+                _set_struct(gs, path, gbase + 4 * off)
+            self._structs = (sig, ps, gs)
+        return params
+
+    def grad_views(self):
+        """Fresh per-parameter views into the flat gradient arena (canonical order)."""
+        return [self._gflat[off:off + p.numel()].view(p.shape) for p, off in zip(self._ordered_params(), self._goffs)]
+
+    def flat_grads(self) -> torch.Tensor:
+        return self._gflat
+
+    def grad_group_ranges(self):
+        """Element ranges of the flat gradient arena in the order smbv_mim_backward completes them (its event order):
+        head+decoder.norm, decoder layers (last first), mask_token+encoder_to_decoder, encoder layers (last first), patch embed."""
+        names = [n for n, _, _ in self._table]
+        sizes = [(p.numel() + 63) // 64 * 64 for p in self._ordered_params()]
+        offs = self._goffs
+        L, DL = self.config.num_hidden_layers, self.config.decoder_num_hidden_layers
+
+        def rng(pred):
+            idx = [i for i, n in enumerate(names) if pred(n)]
+            return (offs[idx[0]], offs[idx[-1]] + sizes[idx[-1]])
+
+        out = [rng(lambda n: n.startswith("decoder.norm") or n.startswith("decoder.head"))]
+        for i in reversed(range(DL)):
+            out.append(rng(lambda n, i=i: n.startswith(f"decoder.decoder_layers.{i}.")))
+        out.append(rng(lambda n: n in ("encoder_to_decoder.weight", "mask_token")))
+        for i in reversed(range(L)):
+            out.append(rng(lambda n, i=i: n.startswith(f"videomae.encoder.layer.{i}.")))
+        out.append(rng(lambda n: n.startswith("videomae.embeddings.")))
+        return out
+
+    # ------------------------------------------------------------------------------------------------------------
+    # the step
+    # ------------------------------------------------------------------------------------------------------------
+    def _token_split(self, bool_masked_pos, num_masked):
+        N = bool_masked_pos.shape[1]
+        if num_masked is None:
+            if self._pending_check is not None:
+                ev, host = self._pending_check
+                if ev.query():
+                    self._pending_check = None
+                    if int(host[0]) != 0:
+                        raise ValueError("bool_masked_pos: the number of masked tokens changed between steps or differs across the batch")
+            if self._n_masked is None:
+                counts = bool_masked_pos.sum(dim=1)
+                self._n_masked = int(counts[0])  # one host sync, first step only
+                if bool((counts != self._n_masked).any()):
+                    raise ValueError("bool_masked_pos: all samples in a batch must mask the same number of tokens")
+            elif self._pending_check is None:
+                host = torch.empty(1, dtype=torch.int32).pin_memory()
+                bad = (bool_masked_pos.sum(dim=1) != self._n_masked).any().to(torch.int32).reshape(1)
+                host.copy_(bad, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pending_check = (ev, host)
+            num_masked = self._n_masked
+        if not 0 < num_masked < N:
+            raise ValueError(f"bool_masked_pos must mask between 1 and {N - 1} tokens, got {num_masked}")
+        return num_masked
+
+    def _run_forward(self, pixel_values, vis_idx, mask_idx):
+        lib = _lib.load()
+        dev = pixel_values.device
+        B = pixel_values.shape[0]
+        n_masked = mask_idx.shape[1]
+        cfg = self._cfg_struct(B, n_masked)
+        need = lib.smbv_mim_workspace_bytes(C.byref(cfg))
+        if need == 0:
+            raise ValueError("smbv_mim_workspace_bytes: " + _lib.last_error())
+        key = (B, n_masked, dev)
+        if self._ws is None or self._ws_key != key or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._ws_key = key
+        K = self.tubelet_size * self.patch_size[0] ** 2
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        logits = torch.empty(B, n_masked, K, dtype=torch.bfloat16, device=dev)
+        io = _lib.MimIO()
+        io.pixel_values, io.vis_idx, io.mask_idx = pixel_values.data_ptr(), vis_idx.data_ptr(), mask_idx.data_ptr()
+        io.pos_enc, io.pos_dec = self._pos[0].data_ptr(), self._pos[1].data_ptr()
+        io.loss, io.logits, io.grad_scale = loss.data_ptr(), logits.data_ptr(), None
+        _, ps, gs = self._structs
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.smbv_mim_forward(C.byref(cfg), C.byref(ps), C.byref(io), self._ws.data_ptr(), self._ws.numel(), stream),
+                   "smbv_mim_forward")
+        self._fwd_count += 1
+        st = dict(cfg=cfg, io=io, step=self._fwd_count, keep=(pixel_values, vis_idx, mask_idx, logits, loss, self._ws))
+        return loss, logits, st
+
+    def _run_backward(self, st, grad_loss):
+        lib = _lib.load()
+        if st["step"] != self._fwd_count:
+            raise _lib.SmbvError("smb_vision_amd: backward() after a later forward() reused the step workspace "
+                                 "(one forward/backward pair at a time per model)")
+        gscale = grad_loss.detach().to(torch.float32).reshape(1).contiguous()
+        io = st["io"]
+        io.grad_scale = gscale.data_ptr()
+        _, ps, gs = self._structs
+        stream = torch.cuda.current_stream().cuda_stream
+        events, n_ev = None, 0
+        if self.dp is not None:
+            events, n_ev = self.dp.event_array()
+        _lib.check(lib.smbv_mim_backward(C.byref(st["cfg"]), C.byref(ps), C.byref(gs), C.byref(io), self._ws.data_ptr(), self._ws.numel(),
+                                         events, n_ev, stream), "smbv_mim_backward")
+        if self.dp is not None:
+            self.dp.allreduce_after_backward(self)
+        return self.grad_views()
+
+    def forward(self, pixel_values: torch.Tensor, bool_masked_pos: torch.Tensor, head_mask=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None, num_masked: Optional[int] = None, **kwargs):
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("smb_vision_amd: attention maps / hidden states are never materialised by the fused HIP path")
+        if pixel_values.dim() != 5:
+            raise ValueError("pixel_values must be [batch, frames, channels, height, width]")
+        B, T, Cc, H, W = pixel_values.shape
+        if Cc != self.config.num_channels:
+            raise ValueError("Make sure that the channel dimension of the pixel values match with the one set in the configuration.")
+        if H != self.image_size[0] or W != self.image_size[1]:
+            raise ValueError(f"Input image size ({H}*{W}) doesn't match model ({self.image_size[0]}*{self.image_size[1]}).")
+        if T != self.config.num_frames:
+            raise ValueError(f"Input depth ({T}) doesn't match model ({self.config.num_frames}).")
+        if bool_masked_pos is None:
+            raise ValueError("One must provided a boolean mask ")
+        if not pixel_values.is_cuda:
+            raise _lib.SmbvError("smb_vision_amd: pixel_values must live on a HIP device; there is no CPU fallback for the MIM hot path")
+        _lib.load()
+        dev = pixel_values.device
+        with torch.cuda.device(dev):
+            pixel_values = pixel_values.to(torch.float32).contiguous()
+            bool_masked_pos = bool_masked_pos.to(device=dev, dtype=torch.bool)
+            if bool_masked_pos.shape != (B, self.num_patches):
+                raise ValueError(f"bool_masked_pos must be [{B}, {self.num_patches}], got {tuple(bool_masked_pos.shape)}")
+            params = self._ensure_device_state(dev)
+            n_masked = self._token_split(bool_masked_pos, num_masked)
+            vis_idx, mask_idx = split_mask_indices(bool_masked_pos, n_masked)
+            if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+                loss, logits = _MIMStepFn.apply(weakref.ref(self), pixel_values, vis_idx, mask_idx, *params)
+            else:
+                loss, logits, _ = self._run_forward(pixel_values, vis_idx, mask_idx)
+        if return_dict is False:
+            return (loss, logits)
+        return SmbVideoMAEForPreTrainingOutput(loss=loss, logits=logits)
+
+
+_HF5_KEY_MAPPING = {
+    r"attention\.attention\.query\.bias$": "attention.attention.q_bias",
+    r"attention\.attention\.value\.bias$": "attention.attention.v_bias",
+}
+
+
+def convert_state_dict_keys(sd: dict, prefix: str = ""):
+    """Accept transformers-5 checkpoints: ``query.bias -> q_bias``, ``value.bias -> v_bias``; a ``key.bias`` adds the same
+    constant to every score of a query row, which softmax ignores, so it is dropped (exact)."""
+    for k in list(sd.keys()):
+        if not k.startswith(prefix):
+            continue
+        if k.endswith("attention.attention.query.bias"):
+            sd[k[: -len("query.bias")] + "q_bias"] = sd.pop(k)
+        elif k.endswith("attention.attention.value.bias"):
+            sd[k[: -len("value.bias")] + "v_bias"] = sd.pop(k)
+        elif k.endswith("attention.attention.key.bias"):
+            sd.pop(k)
+    return sd

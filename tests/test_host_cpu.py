@@ -1,0 +1,164 @@
+"""CPU: host logic of the product package — mask generator, index split, model-class surface (constructor, state-dict
+names, save/load in both layouts, errors), C-ABI library loads and exports every symbol of include/smbv.h."""
+import ctypes
+import os
+import re
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.mim_oracle import MIMConfig, param_shapes
+from smb_vision_amd import _lib
+from smb_vision_amd.masking import MaskGenerator, split_mask_indices
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+TINY = dict(image_size=64, num_frames=32, patch_size=16, tubelet_size=16, hidden_size=64, num_hidden_layers=2, num_attention_heads=1,
+            intermediate_size=256, decoder_hidden_size=64, decoder_num_hidden_layers=1, decoder_num_attention_heads=1,
+            decoder_intermediate_size=128)
+
+
+def test_library_exports_every_declared_symbol():
+    _lib.load()  # raises if the .so is missing or lacks a bound symbol
+    hdr = open(os.path.join(ROOT, "include", "smbv.h")).read()
+    declared = set(re.findall(r"\b(smbv_[a-z0-9_]+)\s*\(", hdr))
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"libsmbv.so does not export {name}"
+    assert declared == set(_lib.EXPORTS)
+    assert lib.smbv_version() >= 1000
+
+
+def test_bad_config_is_rejected_without_gpu():
+    lib = _lib.load()
+    cfg = _lib.MimCfg()
+    assert lib.smbv_mim_workspace_bytes(ctypes.byref(cfg)) == 0
+    assert "mim" in _lib.last_error()
+
+
+def test_workspace_size_vit_base():
+    lib = _lib.load()
+    cfg = _lib.MimCfg(B=1, T=320, H=512, W=512, ps=16, ts=16, N=20480, Nvis=7168, Nmask=13312, d=768, heads=12, ff=3072, layers=12,
+                      dd=384, dheads=6, dff=1536, dlayers=4, ln_eps=1e-12, dec_norm_eps=1e-5)
+    n = lib.smbv_mim_workspace_bytes(ctypes.byref(cfg))
+    assert 3e9 < n < 12e9
+
+
+def mask_cases():
+    z = np.load(os.path.join(G, "masks.npz"))
+    for k in z.files:
+        if k.endswith("_a"):
+            _, sz, dp, mps, ps, ratio, seed = k[:-2].split("_")
+            yield z, k[:-2], int(sz), int(dp), int(mps), int(ps), float(ratio), int(seed[4:])
+
+
+@pytest.mark.parametrize("case", list(mask_cases()), ids=lambda c: c[1])
+def test_product_mask_generator_bit_exact(case):
+    z, key, sz, dp, mps, ps, ratio, seed = case
+    n, nm = z[key + "_n"]
+    gen = MaskGenerator(input_size=sz, depth=dp, mask_patch_size=mps, model_patch_size=ps, mask_ratio=ratio)
+    assert gen.num_tokens == n and gen.num_masked == nm
+    np.random.seed(seed)
+    for suffix in ("_a", "_b"):
+        m = gen()
+        assert m.dtype == torch.bool and m.shape == (n,)
+        assert np.array_equal(m.numpy(), np.unpackbits(z[key + suffix])[:n].astype(bool))
+
+
+def test_mask_generator_errors():
+    with pytest.raises(ValueError, match="Input size"):
+        MaskGenerator(input_size=100, depth=32, mask_patch_size=16)
+    with pytest.raises(ValueError, match="Depth"):
+        MaskGenerator(input_size=64, depth=40, mask_patch_size=16)
+    with pytest.raises(ValueError, match="Mask patch size"):
+        MaskGenerator(input_size=96, depth=96, mask_patch_size=24, model_patch_size=16)
+
+
+def test_split_mask_indices_matches_boolean_indexing():
+    g = torch.Generator().manual_seed(0)
+    B, N, nm = 3, 64, 40
+    mask = torch.zeros(B, N, dtype=torch.bool)
+    for b in range(B):
+        mask[b, torch.randperm(N, generator=g)[:nm]] = True
+    vis, msk = split_mask_indices(mask, nm)
+    ar = torch.arange(N).expand(B, -1)
+    assert torch.equal(vis.long(), ar[~mask].reshape(B, -1)) and torch.equal(msk.long(), ar[mask].reshape(B, -1))
+    assert vis.dtype == torch.int32
+
+
+@pytest.fixture(scope="module")
+def model_and_cfg():
+    from transformers import VideoMAEConfig
+    from smb_vision_amd.modeling_videomae import SmbVideoMAEForPreTraining
+    cfg = VideoMAEConfig(num_channels=1, **TINY)
+    torch.manual_seed(0)
+    return SmbVideoMAEForPreTraining(cfg), cfg
+
+
+def test_state_dict_names_are_the_reference_layout(model_and_cfg):
+    model, _ = model_and_cfg
+    sd = model.state_dict()
+    ref = param_shapes(MIMConfig(**TINY))
+    assert set(sd) == set(ref)
+    assert all(tuple(sd[k].shape) == ref[k] for k in ref)
+    assert model.base_model_prefix == "videomae" and model.main_input_name == "pixel_values" and model.supports_gradient_checkpointing
+    # _init_weights semantics
+    assert float(sd["mask_token"].abs().sum()) == 0 and float(sd["videomae.encoder.layer.0.attention.attention.q_bias"].abs().sum()) == 0
+    assert float(sd["decoder.norm.weight"].min()) == 1.0
+    assert 0.015 < float(sd["decoder.head.weight"].std()) < 0.025
+
+
+def test_param_count_vit_base():
+    from transformers import VideoMAEConfig
+    from smb_vision_amd.modeling_videomae import param_table
+    cfg = VideoMAEConfig(image_size=512, patch_size=16, num_channels=1, num_frames=320, tubelet_size=16)
+    n = sum(int(np.prod(s)) for _, s, _ in param_table(cfg))
+    # SURVEY.md §8(a15) counts 97,171,840 with the transformers-5 layout, whose attention carries a (softmax-invariant) key bias;
+    # the pinned-era layout this class uses has none: 12*768 + 4*384 fewer.
+    assert n == 97_171_840 - (12 * 768 + 4 * 384)
+
+
+def test_save_load_roundtrip_and_hf5_layout(model_and_cfg):
+    from transformers import VideoMAEForPreTraining
+    from smb_vision_amd.modeling_videomae import SmbVideoMAEForPreTraining
+    model, cfg = model_and_cfg
+    with tempfile.TemporaryDirectory() as d:
+        model.save_pretrained(d)
+        m2 = SmbVideoMAEForPreTraining.from_pretrained(d, config=cfg)
+        for (k, a), b in zip(model.state_dict().items(), m2.state_dict().values()):
+            assert torch.equal(a, b), k
+    hf = VideoMAEForPreTraining(cfg)
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if n.endswith("bias"):
+                p.normal_()
+    with tempfile.TemporaryDirectory() as d:
+        hf.save_pretrained(d)
+        m3 = SmbVideoMAEForPreTraining.from_pretrained(d, config=cfg)
+    hsd, sd = hf.state_dict(), m3.state_dict()
+    a = "videomae.encoder.layer.1.attention.attention."
+    assert torch.equal(sd[a + "q_bias"], hsd[a + "query.bias"]) and torch.equal(sd[a + "v_bias"], hsd[a + "value.bias"])
+    assert torch.equal(sd["decoder.head.weight"], hsd["decoder.head.weight"])
+    # plain load_state_dict accepts it too
+    model.load_state_dict(hsd)
+
+
+def test_errors_mirror_the_reference(model_and_cfg):
+    from transformers import VideoMAEConfig
+    from smb_vision_amd.modeling_videomae import SmbVideoMAEForPreTraining
+    model, cfg = model_and_cfg
+    mask = torch.zeros(1, 32, dtype=torch.bool)
+    with pytest.raises(ValueError, match="channel dimension"):
+        model(torch.zeros(1, 32, 3, 64, 64), mask)
+    with pytest.raises(ValueError, match="doesn't match model"):
+        model(torch.zeros(1, 32, 1, 32, 32), mask)
+    with pytest.raises(ValueError, match="boolean mask"):
+        model(torch.zeros(1, 32, 1, 64, 64), None)
+    with pytest.raises(_lib.SmbvError, match="no CPU fallback"):
+        model(torch.zeros(1, 32, 1, 64, 64), mask)  # the product path never falls back to the CPU
+    with pytest.raises(ValueError):
+        SmbVideoMAEForPreTraining(VideoMAEConfig(num_channels=1, norm_pix_loss=False, **TINY))
+    model.gradient_checkpointing_enable()
+    assert model.gradient_checkpointing

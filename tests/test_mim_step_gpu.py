@@ -1,0 +1,146 @@
+"""GPU parity of the whole MIM train step (SmbVideoMAEForPreTraining -> smbv_mim_forward / smbv_mim_backward in libsmbv.so)
+against (a) the golden vectors of the reference model class (fp32, CPU) and (b) the CPU oracle on fresh seeded inputs.
+
+Stated tolerances (north_star: "within a stated fp tolerance (mask indices bit-exact)").  The HIP path follows the
+reference's bf16-autocast policy (bf16 GEMM/attention operands, fp32 accumulation / LayerNorm / softmax / loss), the
+goldens are pure fp32, so the comparison carries bf16 operand rounding (2^-9 relative per operand):
+  loss   : |d| <= 5e-3 * |loss|
+  logits : max|d| <= 3e-2 * max|logits|, rms(d) <= 1e-2 * rms(logits)
+  grads  : per tensor, ||d||_2 <= 6e-2 * ||g||_2  (and cosine >= 0.998)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+from safetensors import safe_open
+
+from oracle.mim_oracle import MIMConfig, init_params, mim_step
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load_golden(name):
+    blob = {}
+    with safe_open(os.path.join(G, name + ".safetensors"), "pt") as f:
+        meta = f.metadata()
+        for k in f.keys():
+            blob[k] = f.get_tensor(k)
+    return blob, eval(meta["config"])
+
+
+def build_model(c, params):
+    from transformers import VideoMAEConfig
+    from smb_vision_amd.modeling_videomae import SmbVideoMAEForPreTraining
+    model = SmbVideoMAEForPreTraining(VideoMAEConfig(num_channels=1, **c))
+    model.load_state_dict(params, strict=True)
+    return model.cuda().train()
+
+
+def run_step(model, pix, mask, scale=None):
+    model.zero_grad(set_to_none=True)
+    out = model(pixel_values=pix.cuda(), bool_masked_pos=mask.cuda())
+    loss = out.loss if scale is None else out.loss * scale
+    loss.backward()
+    torch.cuda.synchronize()
+    return out.loss.detach().cpu(), out.logits.detach().float().cpu(), {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
+
+
+def check_against(loss, logits, grads, ref_loss, ref_logits, ref_grads, tl=5e-3, tg=6e-2):
+    assert abs(float(loss) - float(ref_loss)) <= tl * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    d = logits - ref_logits
+    assert float(d.abs().max()) <= 3e-2 * float(ref_logits.abs().max())
+    assert float(d.pow(2).mean().sqrt()) <= 1e-2 * float(ref_logits.pow(2).mean().sqrt())
+    worst = ("", 0.0)
+    for k, ref in ref_grads.items():
+        g = grads[k]
+        assert g.shape == ref.shape, k
+        n = float(ref.norm())
+        if n < 1e-10:
+            assert float(g.norm()) < 1e-6, k
+            continue
+        rel = float((g - ref).norm()) / n
+        cos = float((g * ref).sum() / (g.norm() * ref.norm()))
+        if rel > worst[1]:
+            worst = (k, rel)
+        assert rel <= tg and cos >= 0.998, (k, rel, cos)
+    return worst
+
+
+@pytest.mark.parametrize("name", ["mim_tiny_p16", "mim_small_p8"])
+def test_step_matches_reference_golden(name):
+    blob, c = load_golden(name)
+    params = {k[6:]: v for k, v in blob.items() if k.startswith("param.")}
+    model = build_model(c, params)
+    pix, mask = blob["in.pixel_values"], blob["in.bool_masked_pos"].bool()
+    loss, logits, grads = run_step(model, pix, mask)
+    ref_grads = {k[5:]: v for k, v in blob.items() if k.startswith("grad.")}
+    worst = check_against(loss, logits, grads, blob["out.loss"], blob["out.logits"], ref_grads)
+    print(name, "loss", float(loss), "ref", float(blob["out.loss"]), "worst grad", worst)
+
+
+def test_step_matches_oracle_mid_size_and_is_deterministic():
+    # 128x128x64 volume, patch 16 -> N = 256 tokens; 2 heads; ragged tiles everywhere (Nvis = 104)
+    c = dict(image_size=128, num_frames=64, patch_size=16, tubelet_size=16, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+             intermediate_size=512, decoder_hidden_size=64, decoder_num_hidden_layers=2, decoder_num_attention_heads=1,
+             decoder_intermediate_size=256)
+    cfg = MIMConfig(**c)
+    params = init_params(cfg, seed=7, nonzero_small=True)
+    from smb_vision_amd.masking import MaskGenerator
+    gen = MaskGenerator(128, 64, 16, 16, 0.59)
+    np.random.seed(3)
+    B = 2
+    mask = torch.stack([gen() for _ in range(B)])
+    pix = torch.rand(B, 64, 1, 128, 128, generator=torch.Generator().manual_seed(5))
+    ref_loss, ref_logits, ref_grads = mim_step(params, cfg, pix, mask)
+    model = build_model(c, params)
+    loss, logits, grads = run_step(model, pix, mask)
+    check_against(loss, logits, grads, ref_loss, ref_logits, ref_grads)
+    # tighter: against the oracle with the same bf16 rounding points
+    e_loss, e_logits, e_grads = mim_step(params, cfg, pix, mask, emulate_bf16=True)
+    assert abs(float(loss) - float(e_loss)) <= 1e-3 * float(e_loss)
+    # bitwise reproducible (no float atomics anywhere in the step)
+    loss2, logits2, grads2 = run_step(model, pix, mask)
+    assert torch.equal(loss, loss2) and torch.equal(logits, logits2)
+    for k in grads:
+        assert torch.equal(grads[k], grads2[k]), k
+    # gradients are linear in the upstream scale (HF Trainer divides the loss under gradient accumulation)
+    _, _, grads_half = run_step(model, pix, mask, scale=0.5)
+    for k in ("decoder.head.weight", "videomae.encoder.layer.0.attention.attention.query.weight", "mask_token"):
+        assert torch.allclose(grads_half[k], 0.5 * grads[k], rtol=2e-2, atol=1e-9), k
+
+
+def test_eval_forward_and_errors():
+    blob, c = load_golden("mim_tiny_p16")
+    params = {k[6:]: v for k, v in blob.items() if k.startswith("param.")}
+    model = build_model(c, params).eval()
+    with torch.no_grad():
+        out = model(pixel_values=blob["in.pixel_values"].cuda(), bool_masked_pos=blob["in.bool_masked_pos"].bool().cuda())
+    assert not out.loss.requires_grad and out.logits.shape == (2, 20, 4096)
+    assert abs(float(out.loss) - float(blob["out.loss"])) < 5e-3
+    with pytest.raises(ValueError, match="doesn't match model"):
+        model(pixel_values=torch.zeros(1, 32, 1, 32, 32).cuda(), bool_masked_pos=torch.zeros(1, 32, dtype=torch.bool).cuda())
+    bad = blob["in.bool_masked_pos"].bool().clone()
+    bad[1] = False
+    bad[1, :3] = True
+    model2 = build_model(c, params)
+    with pytest.raises(ValueError, match="same number"):
+        model2(pixel_values=blob["in.pixel_values"].cuda(), bool_masked_pos=bad.cuda())
+
+
+def test_optimizer_step_decreases_loss():
+    blob, c = load_golden("mim_small_p8")
+    params = {k[6:]: v for k, v in blob.items() if k.startswith("param.")}
+    model = build_model(c, params)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    pix, mask = blob["in.pixel_values"].cuda(), blob["in.bool_masked_pos"].bool().cuda()
+    losses = []
+    for _ in range(8):
+        opt.zero_grad(set_to_none=True)
+        out = model(pixel_values=pix, bool_masked_pos=mask)
+        out.loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        losses.append(float(out.loss))
+    assert losses[-1] < losses[0] - 0.02, losses
