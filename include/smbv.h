@@ -76,7 +76,7 @@ int smbv_attention_fwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* 
                        int B, int S, int H, int Dh, float scale, smbv_stream stream);
 int smbv_attention_bwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* dO,
                        int ldo, const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S,
-                       int H, int Dh, float scale, smbv_stream stream);
+                       int H, int Dh, float scale, int parts /* bit0 delta, bit1 dK/dV, bit2 dQ; 7 = all */, smbv_stream stream);
 
 /* Brick readers over pixel_values fp32 [B,T,1,H,W] (spec :172-177,190-191 Conv3d patchify; :835-867 labels; :896-897 MSE).
  * idx: int32 token ids (0..N-1) of the selected bricks, `per_batch` per volume, rows = B*per_batch. */

@@ -184,6 +184,10 @@ def patch_embed(pixel_values, w, b, cfg: MIMConfig, emu=False):
     return _linear(x, w.reshape(w.shape[0], -1), b, emu)
 
 
+SDPA = False  # bench.py's cpu_baseline leg sets this: same function through torch's fused CPU kernel (the reference's default
+              # `_attn_implementation` is "sdpa", dispatched at spec :270-289); the explicit form below is the parity oracle.
+
+
 def attention(x, p, prefix, heads, emu=False):
     """q/k/v linears (k bias == 0), fp32 softmax(QK^T * Dh^-0.5) V (spec :196-223, :258-296)."""
     a = prefix + "attention.attention."
@@ -193,6 +197,8 @@ def attention(x, p, prefix, heads, emu=False):
     k = _linear(x, p[a + "key.weight"], None, emu)
     v = _linear(x, p[a + "value.weight"], p[a + "v_bias"], emu)
     q, k, v = (_r(t, emu).view(B, S, heads, dh).transpose(1, 2) for t in (q, k, v))
+    if SDPA and not emu:
+        return F.scaled_dot_product_attention(q, k, v, scale=dh ** -0.5).transpose(1, 2).reshape(B, S, D)
     s = torch.matmul(q, k.transpose(-1, -2)) * (dh ** -0.5)
     pr = torch.softmax(s, dim=-1, dtype=torch.float32)
     o = torch.matmul(_r(pr, emu), v).transpose(1, 2).reshape(B, S, D)

@@ -301,19 +301,27 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const bf16_t* __restrict__
 }
 
 int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
-                  float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, hipStream_t st) {
+                  float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, hipStream_t st) {
   if (Dh != 64) { set_error("attention_bwd: head_dim %d not supported (only 64)", Dh); return SMBV_ERR_SHAPE; }
   if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 7) || (ldd & 3)) { set_error("attention_bwd: bad shape"); return SMBV_ERR_SHAPE; }
   if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)dO) & 15) || (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 7)) { set_error("attention_bwd: alignment"); return SMBV_ERR_ALIGN; }
   const long pairs = (long)B * S * H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(pairs * 8, 256)), dim3(256), 0, st, O, dO, ldo, delta, B, S, H);
-  int rc = check_launch("attn_delta");
-  if (rc) return rc;
-  hipLaunchKernelGGL(attn_dkv_kernel, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, H, scale);
-  rc = check_launch("attn_dkv");
-  if (rc) return rc;
-  hipLaunchKernelGGL(attn_dq_kernel, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, H, scale);
-  return check_launch("attn_dq");
+  int rc = SMBV_OK;
+  if (parts & 1) {
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(pairs * 8, 256)), dim3(256), 0, st, O, dO, ldo, delta, B, S, H);
+    rc = check_launch("attn_delta");
+    if (rc) return rc;
+  }
+  if (parts & 2) {
+    hipLaunchKernelGGL(attn_dkv_kernel, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, H, scale);
+    rc = check_launch("attn_dkv");
+    if (rc) return rc;
+  }
+  if (parts & 4) {
+    hipLaunchKernelGGL(attn_dq_kernel, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, H, scale);
+    rc = check_launch("attn_dq");
+  }
+  return rc;
 }
 
 }  // namespace smbv

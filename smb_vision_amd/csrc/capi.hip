@@ -88,9 +88,9 @@ int smbv_attention_fwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* 
 }
 int smbv_attention_bwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* dO, int ldo,
                        const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S, int H, int Dh, float scale,
-                       smbv_stream stream) {
+                       int parts, smbv_stream stream) {
   if (!Q || !K || !V || !O || !dO || !LSE || !delta || !dQ || !dK || !dV) { set_error("smbv_attention_bwd: null operand"); return SMBV_ERR_ARG; }
-  return attention_bwd(Q, K, V, ld, O, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, H, Dh, scale, (hipStream_t)stream);
+  return attention_bwd(Q, K, V, ld, O, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, H, Dh, scale, parts, (hipStream_t)stream);
 }
 
 int smbv_gather_bricks(const float* pix, const int32_t* idx, int rows, int per_batch, smbv_bf16* out, int T, int H, int W, int ts, int ps, smbv_stream stream) {

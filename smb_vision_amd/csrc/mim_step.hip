@@ -207,7 +207,7 @@ static int layer_bwd(const smbv_layer_ptrs& p, const smbv_layer_ptrs& gr, LayerW
   }
   // attention
   RC(attention_bwd(L.qkv, L.qkv + w, L.qkv + 2 * w, 3 * w, L.attn_o, W.d_o, w, L.lse, W.delta, W.d_qkv, W.d_qkv + w, W.d_qkv + 2 * w, 3 * w, B, S,
-                   H, 64, 0.125f, st));
+                   H, 64, 0.125f, 7, st));
   // QKV
   RC(colsum_bf16(W.d_qkv, 3 * w, M, w, gr.q_b, 0, 0, 0, W.scratch, W.scratch_bytes, st));
   RC(colsum_bf16(W.d_qkv + 2 * w, 3 * w, M, w, gr.v_b, 0, 0, 0, W.scratch, W.scratch_bytes, st));

@@ -111,16 +111,15 @@ def attention_fwd(qkv, B, S, H, scale=None):
     return O, lse
 
 
-def attention_bwd(qkv, O, dO, lse, B, S, H, scale=None):
+def attention_bwd(qkv, O, dO, lse, B, S, H, scale=None, parts=7, out=None):
     _need_gpu(qkv, O, dO, lse)
     lib = _lib.load()
     w = H * 64
     scale = scale if scale is not None else 64 ** -0.5
-    dqkv = torch.zeros_like(qkv)
-    delta = torch.empty(B, H, S, dtype=torch.float32, device=qkv.device)
+    dqkv, delta = out if out is not None else (torch.zeros_like(qkv), torch.empty(B, H, S, dtype=torch.float32, device=qkv.device))
     base, dbase = qkv.data_ptr(), dqkv.data_ptr()
     check(lib.smbv_attention_bwd(base, base + 2 * w, base + 4 * w, qkv.stride(0), _p(O), _p(dO), w, _p(lse), _p(delta), dbase, dbase + 2 * w,
-                                 dbase + 4 * w, dqkv.stride(0), B, S, H, 64, scale, _stream()), "smbv_attention_bwd")
+                                 dbase + 4 * w, dqkv.stride(0), B, S, H, 64, scale, parts, _stream()), "smbv_attention_bwd")
     return dqkv, delta
 
 
