@@ -75,50 +75,90 @@ int gather_rows_bf16(const bf16_t* in, bf16_t* out, int rows, int D, long grp_in
   return check_launch("gather_rows_bf16");
 }
 
+// Deterministic column reduction of a partial-sum matrix part[nrows][ncols] -> out0[0:split) | out1[split:ncols).
+// 256 threads = 32 column lanes (float4 each -> 128 columns per block) x 8 row lanes, combined through LDS.
+__global__ __launch_bounds__(256) void reduce_cols_kernel(const float* __restrict__ part, int nrows, int ncols, float* __restrict__ out0,
+                                                          float* __restrict__ out1, int split) {
+  __shared__ f32x4 red[8][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c4 = blockIdx.x * 32 + cl;  // float4 column index
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (c4 * 4 < ncols)
+    for (int r = rl; r < nrows; r += 8) acc += *(const f32x4*)(part + (size_t)r * ncols + 4 * c4);
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c4 * 4 < ncols) {
+#pragma unroll
+    for (int i = 1; i < 8; i++) acc += red[i][cl];
+    const int c = 4 * c4;
+    if (c < split) *(f32x4*)(out0 + c) = acc;
+    else *(f32x4*)(out1 + (c - split)) = acc;
+  }
+}
+
+int reduce_cols(const float* part, int nrows, int ncols, float* out0, float* out1, int split, hipStream_t st) {
+  if ((ncols & 3) || (split & 3)) { set_error("reduce_cols: ncols/split must be multiples of 4"); return SMBV_ERR_SHAPE; }
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3(cdiv(ncols, 128)), dim3(256), 0, st, part, nrows, ncols, out0, out1, split);
+  return check_launch("reduce_cols");
+}
+
 // column sums over rows (bias gradients, mask_token gradient): out[n] = sum_m X[map(m)][n]; two deterministic stages.
+// Stage 1: block = 16 column groups (8 columns = 16 B of bf16 / 2 x 16 B of fp32 each -> 128 columns) x 16 row lanes.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int ld, int M, int N, float* __restrict__ part, int mchunk,
                                                      long grp_in, long grp_out, long row_off) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[16][129];
+  const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int n0 = blockIdx.x * 128 + cg * 8;
   const int z = blockIdx.y;
-  if (n >= N) return;
   const int m0 = z * mchunk, m1 = min(M, m0 + mchunk);
-  float s = 0.f;
-  for (int m = m0; m < m1; m++) {
-    size_t r = m;
-    if (grp_in > 0) r = (size_t)(m / grp_in) * grp_out + (m % grp_in) + row_off;
-    if constexpr (sizeof(T) == 2) s += bf2f(X[r * ld + n]);
-    else s += X[r * ld + n];
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (n0 < N) {
+    for (int m = m0 + rl; m < m1; m += 16) {
+      size_t r = m;
+      if (grp_in > 0) r = (size_t)(m / grp_in) * grp_out + (m % grp_in) + row_off;
+      if constexpr (sizeof(T) == 2) {
+        const u32x4 v = *(const u32x4*)(X + r * ld + n0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { a[2 * i] += bf_lo(v[i]); a[2 * i + 1] += bf_hi(v[i]); }
+      } else {
+        const f32x4 v0 = *(const f32x4*)(X + r * ld + n0), v1 = *(const f32x4*)(X + r * ld + n0 + 4);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { a[i] += v0[i]; a[4 + i] += v1[i]; }
+      }
+    }
   }
-  part[(size_t)z * N + n] = s;
-}
-
-__global__ void colsum_reduce_kernel(const float* __restrict__ part, int nz, int N, float* __restrict__ out) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  float s = 0.f;
-  for (int z = 0; z < nz; z++) s += part[(size_t)z * N + n];
-  out[n] = s;
+#pragma unroll
+  for (int i = 0; i < 8; i++) red[rl][cg * 8 + i] = a[i];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int n = blockIdx.x * 128 + threadIdx.x;
+    if (n < N) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; i++) s += red[i][threadIdx.x];
+      part[(size_t)z * N + n] = s;
+    }
+  }
 }
 
 static int colsum_splits(int M, int N) {
-  const int cb = cdiv(N, 256);
-  int z = std::max(1, std::min(cdiv(M, 64), cdiv(1024, cb)));
-  return z;
+  const int cb = cdiv(N, 128);
+  return std::max(1, std::min(std::min(cdiv(M, 128), 64), cdiv(768, cb)));
 }
 size_t colsum_workspace_bytes(int M, int N) { return (size_t)colsum_splits(M, N) * N * sizeof(float); }
 
 template <typename T>
 static int colsum_impl(const T* X, int ld, int M, int N, float* out, long grp_in, long grp_out, long row_off, void* ws, size_t ws_bytes, hipStream_t st) {
-  if (M <= 0 || N <= 0) { set_error("colsum: empty"); return SMBV_ERR_SHAPE; }
+  if (M <= 0 || N <= 0 || (N & 7) || (ld & 7)) { set_error("colsum: need M,N > 0 and N, ld multiples of 8 (M=%d N=%d ld=%d)", M, N, ld); return SMBV_ERR_SHAPE; }
+  if ((uintptr_t)X & 15) { set_error("colsum: alignment"); return SMBV_ERR_ALIGN; }
   const int nz = colsum_splits(M, N);
   if (!ws || ws_bytes < (size_t)nz * N * sizeof(float)) { set_error("colsum: workspace too small"); return SMBV_ERR_WORKSPACE; }
   const int mchunk = cdiv(M, nz);
-  hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(N, 256), nz), dim3(256), 0, st, X, ld, M, N, (float*)ws, mchunk, grp_in, grp_out, row_off);
+  hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(N, 128), nz), dim3(256), 0, st, X, ld, M, N, (float*)ws, mchunk, grp_in, grp_out, row_off);
   int rc = check_launch("colsum");
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, (const float*)ws, nz, N, out);
-  return check_launch("colsum_reduce");
+  return reduce_cols((const float*)ws, nz, N, out, out, N, st);
 }
 
 int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, long grp_in, long grp_out, long row_off, void* ws, size_t ws_bytes, hipStream_t st) {

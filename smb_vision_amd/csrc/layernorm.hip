@@ -157,18 +157,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int D, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
-  float a = 0.f, b = 0.f;
-  for (int i = 0; i < nblk; i++) {
-    a += part[((size_t)i * 2 + 0) * D + c];
-    b += part[((size_t)i * 2 + 1) * D + c];
-  }
-  dgamma[c] = a;
-  dbeta[c] = b;
-}
-
 static int ln_bwd_blocks(int rows) { return std::max(1, std::min(512, cdiv(rows, 4))); }
 size_t layernorm_bwd_workspace_bytes(int rows, int D) { return (size_t)ln_bwd_blocks(rows) * 2 * D * sizeof(float); }
 
@@ -187,8 +175,7 @@ int layernorm_bwd(const bf16_t* dy, const float* x, const float* mean, const flo
 #undef LN_B
   int rc = check_launch("layernorm_bwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(D, 256)), dim3(256), 0, st, part, nblk, D, dgamma, dbeta);
-  return check_launch("layernorm_bwd_reduce");
+  return reduce_cols(part, nblk, 2 * D, dgamma, dbeta, D, st);
 }
 
 }  // namespace smbv

@@ -57,5 +57,6 @@ int gather_rows_bf16(const bf16_t* in, bf16_t* out, int rows, int D, long grp_in
 int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, long grp_in, long grp_out, long row_off, void* ws, size_t ws_bytes, hipStream_t st);
 int colsum_f32(const float* X, int ld, int M, int N, float* out, long grp_in, long grp_out, long row_off, void* ws, size_t ws_bytes, hipStream_t st);
 size_t colsum_workspace_bytes(int M, int N);
+int reduce_cols(const float* part, int nrows, int ncols, float* out0, float* out1, int split, hipStream_t st);
 
 }  // namespace smbv
