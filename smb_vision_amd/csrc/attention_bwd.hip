@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void attn_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO,
                                                        int ldo, const float* __restrict__ LSE, const float* __restrict__ delta,
                                                        bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int ldd, int S, int H,
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const bf16_t* __restrict_
       const f32x4 de = *(const f32x4*)(sst + 32 + 8 * rg + 4 * h2);
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        const float p = exp2f(s[4 * rg + e] * c - ls[e]);
+        const float p = fast_exp2(s[4 * rg + e] * c - ls[e]);
         s[4 * rg + e] = p;
         dp[4 * rg + e] = p * (dp[4 * rg + e] - de[e]);
       }
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const bf16_t* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void attn_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(256, 2) void attn_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                       const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO, int ldo,
                                                       const float* __restrict__ LSE, const float* __restrict__ delta,
                                                       bf16_t* __restrict__ dQ, int ldd, int S, int H, float scale) {
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const bf16_t* __restrict__
       }
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        float p = exp2f(s[i] * c - lse2);
+        float p = fast_exp2(s[i] * c - lse2);
         if (ragged) {
           const int key = kt * 64 + 32 * kt2 + (i & 3) + 8 * (i >> 2) + 4 * h2;
           if (key >= S) p = 0.f;

@@ -23,7 +23,7 @@ __device__ __forceinline__ int swz_k64(int row, int chunk) { return row * 128 + 
 // V image: 128-B rows, 32-B columns XOR-ed with bit1 of (key>>1) so that the 4 keys of a tr-read block hit distinct banks
 __device__ __forceinline__ int swz_v64(int key, int c32) { return key * 128 + ((c32 ^ (((key >> 1) & 1) << 1)) << 5); }
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ V, int ld, bf16_t* __restrict__ O, int ldo,
                                                        float* __restrict__ LSE, int S, int H, float scale) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 64 * 128];  // [buf][K|V][64 keys][128 B]
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     for (int i = 0; i < 16; i++) mx = fmaxf(mx, s[1][i]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_i, mx);  // finite: every tile holds at least one valid key
-    const float alpha = exp2f((m_i - m_new) * c);
+    const float alpha = fast_exp2((m_i - m_new) * c);
     const float mc = m_new * c;
     m_i = m_new;
     float rowsum = 0.f;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     for (int kt2 = 0; kt2 < 2; kt2++)
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        const float p = exp2f(s[kt2][i] * c - mc);
+        const float p = fast_exp2(s[kt2][i] * c - mc);
         s[kt2][i] = p;
         rowsum += p;
       }

@@ -25,7 +25,7 @@ __device__ __forceinline__ int swz_nt(int row, int chunk) { return row * 128 + (
 // ---------------------------------------------------------------------------------------------------------------
 // NT
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
                                                       int ldb, int M, int N, int K, int tiles_m, GemmEpi e) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * BM * BK * 2];  // [buf][A|B][128*64 bf16] = 64 KiB
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
@@ -153,7 +153,7 @@ int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, in
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int sw_tn(int m) { return (m & 3) | (((m >> 3) & 1) << 2); }
 
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y,
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y,
                                                       int ldy, int M, int N1, int N2, float* __restrict__ out, int ldo,
                                                       int tiles_1, int mchunk, size_t slab_stride) {
   // LDS: [buf][X|Y][64 m][128 n] bf16 (256-B rows) = 2*2*16 KiB

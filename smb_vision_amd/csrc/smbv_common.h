@@ -55,6 +55,9 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// raw v_exp_f32 (2^x): no denormal-range fix-up; callers pass x <= ~0 where a flushed tiny result is exact enough
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
