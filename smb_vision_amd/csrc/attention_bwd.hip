@@ -15,12 +15,21 @@
 #include "smbv_kernels.h"
 
 namespace smbv {
+extern int g_variant;
+bool attn_prefer_3waves(long blocks);
 
 // 128-byte-row LDS image usable for ds_read_b128 row reads (16 rows x same chunk) AND ds_read_b64_tr_b16 blocks
 // (4 consecutive rows x 32 B): chunk16 ^= f((row>>1)&7), f(x) = ((x&1)<<2) | (x>>1).
 __device__ __forceinline__ int swz128(int row, int c16) {
   const int x = (row >> 1) & 7;
   return row * 128 + ((c16 ^ (((x & 1) << 2) | (x >> 1))) << 4);
+}
+
+__device__ __forceinline__ bf16x8 scale_frag(u32x4 v, float c) {
+  u32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; i++) o[i] = pack_bf16(bf_lo(v[i]) * c, bf_hi(v[i]) * c);
+  return __builtin_bit_cast(bf16x8, o);
 }
 
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO, int ldo,
@@ -50,7 +59,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   }
 }
 
-__global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void attn_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO,
                                                        int ldo, const float* __restrict__ LSE, const float* __restrict__ delta,
                                                        bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int ldd, int S, int H,
@@ -76,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restri
       a = *(const u32x4*)(K + (row0 + key) * ld + hoff + 16 * ks + 8 * h2);
       bb = *(const u32x4*)(V + (row0 + key) * ld + hoff + 16 * ks + 8 * h2);
     }
-    kf[ks] = __builtin_bit_cast(bf16x8, a);
+    kf[ks] = scale_frag(a, c);  // scores leave the MFMA in the exp2 domain
     vf[ks] = __builtin_bit_cast(bf16x8, bb);
   }
   f32x16 dkt[2], dvt[2];
@@ -91,15 +101,15 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restri
     const bool ok = (q0 + row) < S;
     rq = ok ? *(const u32x4*)(Q + (row0 + q0 + row) * ld + hoff + ch * 8) : (u32x4){0, 0, 0, 0};
     rdo = ok ? *(const u32x4*)(dO + (row0 + q0 + row) * ldo + hoff + ch * 8) : (u32x4){0, 0, 0, 0};
-    if (t < 32) rstat = (q0 + t < S) ? lse_p[q0 + t] * 1.4426950408889634f : INFINITY;
-    else if (t < 64) rstat = (q0 + t - 32 < S) ? del_p[q0 + t - 32] : 0.f;
+    if (t < 32) rstat = (q0 + t < S) ? -lse_p[q0 + t] * 1.4426950408889634f : -INFINITY;  // padded rows: p = exp2(-inf) = 0
+    else if (t < 64) rstat = (q0 + t - 32 < S) ? -del_p[q0 + t - 32] : 0.f;
   };
   auto lstore = [&](int buf) {
     unsigned char* s = smem + buf * BUF;
     const int row = t >> 3, ch = t & 7;
     *(u32x4*)(s + swz128(row, ch)) = rq;
     *(u32x4*)(s + 4096 + swz128(row, ch)) = rdo;
-    if (t < 64) ((float*)(s + 8192))[t] = rstat;  // [0..31] lse2, [32..63] delta
+    if (t < 64) ((float*)(s + 8192))[t] = rstat;  // [0..31] -lse*log2e, [32..63] -delta
   };
 
   const int nq = (S + 31) / 32;
@@ -114,9 +124,15 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restri
     const unsigned char* sdo = sq + 4096;
     const float* sst = (const float*)(sq + 8192);
 
+    // accumulators start at the row constants: S' = c*q.k - lse*log2e, dP' = dO.v - delta (rows 8*rg + 4*h2 + 0..3)
     f32x16 s, dp;
 #pragma unroll
-    for (int i = 0; i < 16; i++) { s[i] = 0.f; dp[i] = 0.f; }
+    for (int rg = 0; rg < 4; rg++) {
+      const f32x4 ls = *(const f32x4*)(sst + 8 * rg + 4 * h2);
+      const f32x4 de = *(const f32x4*)(sst + 32 + 8 * rg + 4 * h2);
+#pragma unroll
+      for (int e = 0; e < 4; e++) { s[4 * rg + e] = ls[e]; dp[4 * rg + e] = de[e]; }
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
       const bf16x8 qa = *(const bf16x8*)(sq + swz128(r, 2 * ks + h2));
@@ -124,17 +140,11 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restri
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);     // [q][key]
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);   // [q][key]
     }
-    // row constants for this lane's 16 rows: rows 8*rg + 4*h2 + (0..3)
 #pragma unroll
-    for (int rg = 0; rg < 4; rg++) {
-      const f32x4 ls = *(const f32x4*)(sst + 8 * rg + 4 * h2);
-      const f32x4 de = *(const f32x4*)(sst + 32 + 8 * rg + 4 * h2);
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const float p = fast_exp2(s[4 * rg + e] * c - ls[e]);
-        s[4 * rg + e] = p;
-        dp[4 * rg + e] = p * (dp[4 * rg + e] - de[e]);
-      }
+    for (int i = 0; i < 16; i++) {
+      const float p = fast_exp2(s[i]);
+      s[i] = p;
+      dp[i] *= p;
     }
 #pragma unroll
     for (int s2 = 0; s2 < 2; s2++) {
@@ -177,7 +187,8 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(const bf16_t* __restri
   }
 }
 
-__global__ __launch_bounds__(256, 2) void attn_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void attn_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                       const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO, int ldo,
                                                       const float* __restrict__ LSE, const float* __restrict__ delta,
                                                       bf16_t* __restrict__ dQ, int ldd, int S, int H, float scale) {
@@ -198,14 +209,17 @@ __global__ __launch_bounds__(256, 2) void attn_dq_kernel(const bf16_t* __restric
       a = *(const u32x4*)(Q + (row0 + q) * ld + hoff + 16 * ks + 8 * h2);
       bb = *(const u32x4*)(dO + (row0 + q) * ldo + hoff + 16 * ks + 8 * h2);
     }
-    qf[ks] = __builtin_bit_cast(bf16x8, a);
+    qf[ks] = scale_frag(a, c);  // scores leave the MFMA in the exp2 domain
     dof[ks] = __builtin_bit_cast(bf16x8, bb);
   }
-  float lse2 = INFINITY, dl = 0.f;
+  float nlse2 = -INFINITY, ndl = 0.f;  // padded queries: p = exp2(-inf) = 0
   if (q < S) {
-    lse2 = LSE[((size_t)b * H + head) * S + q] * 1.4426950408889634f;
-    dl = delta[((size_t)b * H + head) * S + q];
+    nlse2 = -LSE[((size_t)b * H + head) * S + q] * 1.4426950408889634f;
+    ndl = -delta[((size_t)b * H + head) * S + q];
   }
+  f32x16 sinit, dinit;  // persistent C inputs: S'^T = c*k.q - lse*log2e, dP'^T = v.dO - delta
+#pragma unroll
+  for (int i = 0; i < 16; i++) { sinit[i] = nlse2; dinit[i] = ndl; }
   f32x16 dqt[2];
 #pragma unroll
   for (int i = 0; i < 16; i++) { dqt[0][i] = 0.f; dqt[1][i] = 0.f; }
@@ -248,22 +262,20 @@ __global__ __launch_bounds__(256, 2) void attn_dq_kernel(const bf16_t* __restric
     for (int kt2 = 0; kt2 < 2; kt2++) {
       f32x16 s, dp;
 #pragma unroll
-      for (int i = 0; i < 16; i++) { s[i] = 0.f; dp[i] = 0.f; }
-#pragma unroll
       for (int ks = 0; ks < 4; ks++) {
         const bf16x8 ka = *(const bf16x8*)(sk + swz128(32 * kt2 + r, 2 * ks + h2));
         const bf16x8 va = *(const bf16x8*)(sv + swz128(32 * kt2 + r, 2 * ks + h2));
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], s, 0, 0, 0);      // [key][q]
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dp, 0, 0, 0);   // [key][q]
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], ks == 0 ? sinit : s, 0, 0, 0);      // [key][q]
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], ks == 0 ? dinit : dp, 0, 0, 0);   // [key][q]
       }
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        float p = fast_exp2(s[i] * c - lse2);
+        float p = fast_exp2(s[i]);
         if (ragged) {
           const int key = kt * 64 + 32 * kt2 + (i & 3) + 8 * (i >> 2) + 4 * h2;
           if (key >= S) p = 0.f;
         }
-        dp[i] = p * (dp[i] - dl);
+        dp[i] *= p;
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; s2++) {
@@ -313,12 +325,15 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     if (rc) return rc;
   }
   if (parts & 2) {
-    hipLaunchKernelGGL(attn_dkv_kernel, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, H, scale);
+    const bool w3 = (g_variant & 4) || (!(g_variant & 16) && attn_prefer_3waves((long)cdiv(S, 128) * H * B));
+    if (w3) hipLaunchKernelGGL(attn_dkv_kernel<3>, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, H, scale);
+    else hipLaunchKernelGGL(attn_dkv_kernel<2>, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, H, scale);
     rc = check_launch("attn_dkv");
     if (rc) return rc;
   }
   if (parts & 4) {
-    hipLaunchKernelGGL(attn_dq_kernel, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, H, scale);
+    if (g_variant & 8) hipLaunchKernelGGL(attn_dq_kernel<3>, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, H, scale);
+    else hipLaunchKernelGGL(attn_dq_kernel<2>, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, H, scale);
     rc = check_launch("attn_dq");
   }
   return rc;

@@ -13,7 +13,13 @@
 //   O^T[d][q]   += V^T * P^T   the S^T accumulator, exponentiated and packed to bf16, IS the B operand (its rows are the
 //                              contraction index); A = V^T fragment fetched with ds_read_b64_tr_b16 from the row-major
 //                              V image -> no P round trip through LDS and no transposed copy of V.
-// Softmax statistics in fp32; p = exp2(s*c - m*c) with c = scale*log2(e).
+// VALU diet (the loop is VALU-issue bound at head_dim 64, not MFMA bound):
+//   * Q is pre-multiplied by scale*log2(e) once, so scores come out of the MFMA in the exp2 domain;
+//   * the running reference -m sits in a persistent 16-register block used as the C input of the first QK MFMA of each
+//     chain, so p = exp2(acc) needs no per-element subtract;
+//   * the reference is only moved (and O, l rescaled) when a tile's maximum exceeds it by more than 2^THR (deferred
+//     max): exp2 arguments stay <= THR, exact in fp32; tile 0 always rebases.
+// Softmax statistics in fp32.
 #include "smbv_common.h"
 #include "smbv_kernels.h"
 
@@ -23,9 +29,19 @@ __device__ __forceinline__ int swz_k64(int row, int chunk) { return row * 128 + 
 // V image: 128-B rows, 32-B columns XOR-ed with bit1 of (key>>1) so that the 4 keys of a tr-read block hit distinct banks
 __device__ __forceinline__ int swz_v64(int key, int c32) { return key * 128 + ((c32 ^ (((key >> 1) & 1) << 1)) << 5); }
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                       const bf16_t* __restrict__ V, int ld, bf16_t* __restrict__ O, int ldo,
-                                                       float* __restrict__ LSE, int S, int H, float scale) {
+static constexpr float ATTN_DEFER_THR = 6.0f;  // log2 units
+
+__device__ __forceinline__ bf16x8 scale_bf16x8(u32x4 v, float c) {
+  u32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; i++) o[i] = pack_bf16(bf_lo(v[i]) * c, bf_hi(v[i]) * c);
+  return __builtin_bit_cast(bf16x8, o);
+}
+
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                          const bf16_t* __restrict__ V, int ld, bf16_t* __restrict__ O, int ldo,
+                                                          float* __restrict__ LSE, int S, int H, float scale) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 64 * 128];  // [buf][K|V][64 keys][128 B]
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int r = l & 31, h2 = l >> 5;
@@ -40,13 +56,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   for (int ks = 0; ks < 4; ks++) {
     u32x4 v = {0, 0, 0, 0};
     if (q < S) v = *(const u32x4*)(Q + (row0 + q) * ld + hoff + 16 * ks + 8 * h2);
-    qf[ks] = __builtin_bit_cast(bf16x8, v);
+    qf[ks] = scale_bf16x8(v, c);
   }
 
-  f32x16 ot[2];
+  f32x16 ot[2], cneg;
 #pragma unroll
-  for (int i = 0; i < 16; i++) { ot[0][i] = 0.f; ot[1][i] = 0.f; }
-  float m_i = -INFINITY, l_i = 0.f;
+  for (int i = 0; i < 16; i++) { ot[0][i] = 0.f; ot[1][i] = 0.f; cneg[i] = 0.f; }
+  float m2 = 0.f, l_i = 0.f;  // m2: reference exponent (log2 domain); cneg == -m2 in every register
 
   u32x4 rk[2], rv[2];
   auto gload = [&](int kt) {
@@ -86,11 +102,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
     for (int kt2 = 0; kt2 < 2; kt2++) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) s[kt2][i] = 0.f;
-#pragma unroll
       for (int ks = 0; ks < 4; ks++) {
         const bf16x8 kf = *(const bf16x8*)(sk + swz_k64(32 * kt2 + r, 2 * ks + h2));
-        s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt2], 0, 0, 0);
+        s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? cneg : s[kt2], 0, 0, 0);  // c*q.k - m2
       }
     }
     if (kt * 64 + 64 > S) {  // ragged last tile: keys >= S get -inf
@@ -107,23 +121,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     for (int i = 1; i < 16; i++) mx = fmaxf(mx, s[0][i]);
 #pragma unroll
     for (int i = 0; i < 16; i++) mx = fmaxf(mx, s[1][i]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_i, mx);  // finite: every tile holds at least one valid key
-    const float alpha = fast_exp2((m_i - m_new) * c);
-    const float mc = m_new * c;
-    m_i = m_new;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // finite: every tile holds at least one valid key
+    const bool rebase = (kt == 0) || (mx > ATTN_DEFER_THR);
+    if (__builtin_amdgcn_ballot_w64(rebase) != 0) {  // wave-uniform, rare after the first tiles
+      const float d = rebase ? mx : 0.f;
+      const float alpha = fast_exp2(-d);
+      m2 += d;
+      l_i *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        ot[0][i] *= alpha;
+        ot[1][i] *= alpha;
+        s[0][i] -= d;
+        s[1][i] -= d;
+        cneg[i] = -m2;
+      }
+    }
     float rowsum = 0.f;
 #pragma unroll
     for (int kt2 = 0; kt2 < 2; kt2++)
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        const float p = fast_exp2(s[kt2][i] * c - mc);
+        const float p = fast_exp2(s[kt2][i]);
         s[kt2][i] = p;
         rowsum += p;
       }
-    l_i = l_i * alpha + rowsum;
-#pragma unroll
-    for (int i = 0; i < 16; i++) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
+    l_i += rowsum;
 
 #pragma unroll
     for (int kt2 = 0; kt2 < 2; kt2++)
@@ -159,17 +182,27 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         u32x2 pk = {pack_bf16(ot[dt][4 * rg] * inv, ot[dt][4 * rg + 1] * inv), pack_bf16(ot[dt][4 * rg + 2] * inv, ot[dt][4 * rg + 3] * inv)};
         *(u32x2*)(op + d0) = pk;
       }
-    if (h2 == 0) LSE[((size_t)b * H + head) * S + q] = m_i * scale + __logf(l_tot);
+    // natural-log LSE of the scaled scores: (m2 + log2(l)) / log2(e)
+    if (h2 == 0) LSE[((size_t)b * H + head) * S + q] = (m2 + __log2f(l_tot)) * 0.6931471805599453f;
   }
 }
+
+int g_variant = 0;  // tuning / A-B hook (tools/attn_ab.py): bit1 force 3 waves/SIMD fwd, bit2 dkv, bit3 dq, bit4 force 2 everywhere
+
+// A block-per-CU round holds 2 (<=256 VGPR) or 3 (<=168 VGPR) 4-wave blocks per CU.  The 3-wave build is a little slower per
+// block but wins whenever it saves a whole round of blocks (e.g. encoder: 56 x 12 = 672 blocks fit 768 slots, not 512).
+bool attn_prefer_3waves(long blocks) { return cdiv(blocks, 768) < cdiv(blocks, 512); }
 
 int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf16_t* O, int ldo, float* LSE, int B, int S, int H, int Dh,
                   float scale, hipStream_t st) {
   if (Dh != 64) { set_error("attention_fwd: head_dim %d not supported (only 64)", Dh); return SMBV_ERR_SHAPE; }
   if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 3)) { set_error("attention_fwd: bad shape B=%d S=%d H=%d ld=%d ldo=%d", B, S, H, ld, ldo); return SMBV_ERR_SHAPE; }
   if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || ((uintptr_t)O & 7)) { set_error("attention_fwd: alignment"); return SMBV_ERR_ALIGN; }
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, H, scale);
+  const bool w3 = (g_variant & 2) || (!(g_variant & 16) && attn_prefer_3waves((long)cdiv(S, 128) * H * B));
+  if (w3) hipLaunchKernelGGL(attn_fwd_kernel<3>, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, H, scale);
+  else hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, H, scale);
   return check_launch("attention_fwd");
 }
 
 }  // namespace smbv
+extern "C" void smbv_set_variant(int v) { smbv::g_variant = v; }
