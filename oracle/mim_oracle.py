@@ -20,7 +20,8 @@ Specification text followed (reference file:line, relative to /root/reference):
 Pinning: the reference's own tests hold NO value-level fixture for this path; the
 oracle is pinned against outputs of the reference's model class (``transformers.VideoMAEForPreTraining``
 as called by ``src/run_mim.py:13-21,345-357``) executed in the build container, committed as
-``tests/golden/mim_tiny.safetensors`` by ``tests/golden/make_golden.py``.
+``tests/golden/mim_tiny_p16.safetensors`` / ``mim_small_p8.safetensors`` by ``tests/golden/make_golden.py``
+(checked by ``tests/test_oracle_cpu.py``: loss 1e-5, logits 1e-4, every gradient 1e-4 relative).
 
 Parameter names are the pinned-era (vendored) state-dict names.
 """

@@ -1,0 +1,99 @@
+"""CPU: the data-parallel engine's bucketing and averaging with world_size-2 gloo processes (the N>1 path of bench.py;
+on the GPU the same code runs over RCCL with HIP events gating each bucket on a side stream)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from smb_vision_amd.dp import DataParallelEngine, allreduce_mean_, merge_ranges
+
+
+def test_merge_ranges_covers_everything_in_completion_order():
+    # completion order of a 2-layer encoder / 1-layer decoder model: head, dec0, e2d, enc1, enc0, patch-embed (arena is in forward order)
+    ranges = [(900, 1000), (700, 900), (600, 700), (300, 600), (100, 300), (0, 100)]
+    b = merge_ranges(ranges, 250)
+    assert b == [(700, 1000, 1), (300, 700, 3), (0, 300, 5)]
+    covered = sorted((a, e) for a, e, _ in b)
+    assert covered[0][0] == 0 and covered[-1][1] == 1000 and all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+    # every bucket is gated on the LAST group that completes inside it
+    for a, e, last in b:
+        assert ranges[last][0] == a or ranges[last][1] == e
+    assert merge_ranges(ranges, 1) == [(a, e, i) for i, (a, e) in enumerate(ranges)]
+    assert merge_ranges(ranges, 10 ** 9) == [(0, 1000, 5)]
+
+
+class FakeModel:
+    """Stands in for SmbVideoMAEForPreTraining on the CPU: a flat fp32 gradient arena + completion-order group ranges."""
+
+    def __init__(self, n, ranges):
+        self._g = torch.zeros(n)
+        self._r = ranges
+        self.dp = None
+
+    def flat_grads(self):
+        return self._g
+
+    def grad_group_ranges(self):
+        return self._r
+
+    def parameters(self):
+        return [self._g]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 1000
+        ranges = [(900, 1000), (700, 900), (600, 700), (300, 600), (100, 300), (0, 100)]
+        model = FakeModel(n, ranges)
+        eng = DataParallelEngine(model, bucket_bytes=4 * 250)
+        assert model.dp is eng
+        g = torch.Generator().manual_seed(100 + rank)
+        local = torch.randn(n, generator=g)
+        model.flat_grads().copy_(local)
+        eng.allreduce_after_backward(model)
+        # reference: plain mean over ranks of the whole arena
+        ref = local.clone()
+        allreduce_mean_(ref)
+        q.put((rank, bool(torch.allclose(model.flat_grads(), ref, rtol=0, atol=1e-7)), model.flat_grads().sum().item()))
+        # parameter broadcast makes replicas identical
+        p = torch.full((n,), float(rank))
+        model._g = p
+        eng.broadcast_parameters(model, src=0)
+        q.put((rank, bool((p == 0).all()), 0.0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = [q.get(timeout=10) for _ in range(4)]
+    assert all(ok for _, ok, _ in res)
+    sums = [s for r, ok, s in res if s != 0.0]
+    assert len(sums) == 2 and abs(sums[0] - sums[1]) < 1e-5  # both ranks hold the same averaged gradients
+
+
+def test_engine_requires_process_group():
+    with pytest.raises(RuntimeError):
+        DataParallelEngine(FakeModel(4, [(0, 4)]))
