@@ -134,6 +134,165 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// NT, LDS-DMA staging (K % 64 == 0): A/B tiles go global -> LDS with buffer_load ... lds (1 KiB per wave-instruction,
+// no VGPR round trip, no ds_write); rows beyond M/N come back as zeros from the buffer bounds check.  The LDS image
+// is lane-linear per instruction, so the XOR swizzle is applied to the per-lane SOURCE address and again on the read.
+// XCD-aware tile order: each XCD gets a contiguous chunk of the (tile_n fastest) tile list, so its L2 keeps a few A
+// panels while it sweeps the (small, Infinity-Cache-resident) weight matrix.
+// ---------------------------------------------------------------------------------------------------------------
+// Epilogue through LDS: each wave parks its 64x64 fp32 accumulator tile (two 32-row halves, 272-B padded rows) in its own 16 KiB
+// of the (now idle) staging buffers and re-reads it row-wise, so that every global access of the epilogue - residual / position
+// rows, saved pre-activations, fp32 and bf16 outputs - is a fully coalesced 16/32-byte-per-lane row segment instead of
+// 8-byte fragments scattered over 16 rows.  (With K = 384..768 the scattered form cost as much as the whole main loop.)
+__device__ __forceinline__ void epilogue_nt_lds(f32x4 (&acc)[4][4], unsigned char* smem, int w, int m0, int n0, int wm, int wn, int l, int M,
+                                                int N, const GemmEpi& e_in) {
+  constexpr int LDW = 68;
+  const GemmEpi e = e_in;  // by-value copy: keeps the lambda below from pinning the kernel-argument struct in memory
+  float* ws = (float*)(smem + w * 16384);
+  const int c8 = l & 7, r8 = l >> 3;
+  const int n = n0 + wn * 64 + c8 * 8;
+  const bool ncol = n < N;
+  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+  if (e.bias && ncol) { b0 = *(const f32x4*)(e.bias + n); b1 = *(const f32x4*)(e.bias + n + 4); }
+  auto do_half = [&](const int half, const f32x4 (&a0)[4], const f32x4 (&a1)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      *(f32x4*)(ws + (l & 15) * LDW + j * 16 + 4 * (l >> 4)) = a0[j];
+      *(f32x4*)(ws + (16 + (l & 15)) * LDW + j * 16 + 4 * (l >> 4)) = a1[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int r = it * 8 + r8;
+      const int m = m0 + wm * 64 + half * 32 + r;
+      f32x4 v0 = *(const f32x4*)(ws + r * LDW + c8 * 8), v1 = *(const f32x4*)(ws + r * LDW + c8 * 8 + 4);
+      if (m < M && ncol) {
+        size_t orow = (size_t)m;
+        if (e.grp_in > 0) orow = (size_t)(m / e.grp_in) * e.grp_out + (m % e.grp_in);
+        v0 = v0 * e.alpha + b0;
+        v1 = v1 * e.alpha + b1;
+        if (e.rowadd) {
+          const float* radd = e.rowadd + (size_t)(e.rowidx ? e.rowidx[m] : m) * e.ldr + n;
+          v0 += *(const f32x4*)radd;
+          v1 += *(const f32x4*)(radd + 4);
+        }
+        if (e.dgelu_pre) {
+          const u32x4 p = *(const u32x4*)(e.dgelu_pre + (size_t)m * e.ld_pre + n);
+          v0[0] *= gelu_erf_grad(bf_lo(p[0])); v0[1] *= gelu_erf_grad(bf_hi(p[0]));
+          v0[2] *= gelu_erf_grad(bf_lo(p[1])); v0[3] *= gelu_erf_grad(bf_hi(p[1]));
+          v1[0] *= gelu_erf_grad(bf_lo(p[2])); v1[1] *= gelu_erf_grad(bf_hi(p[2]));
+          v1[2] *= gelu_erf_grad(bf_lo(p[3])); v1[3] *= gelu_erf_grad(bf_hi(p[3]));
+        }
+        if (e.act_gelu) {
+          if (e.aux_pre) {
+            u32x4 p = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
+            *(u32x4*)(e.aux_pre + orow * e.ld_aux + n) = p;
+            // GELU is applied to the bf16-rounded pre-activation (what autocast's bf16 linear output feeds gelu)
+            v0[0] = bf_lo(p[0]); v0[1] = bf_hi(p[0]); v0[2] = bf_lo(p[1]); v0[3] = bf_hi(p[1]);
+            v1[0] = bf_lo(p[2]); v1[1] = bf_hi(p[2]); v1[2] = bf_lo(p[3]); v1[3] = bf_hi(p[3]);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) { v0[q] = gelu_erf(v0[q]); v1[q] = gelu_erf(v1[q]); }
+        }
+        if (e.out_f32) {
+          *(f32x4*)(e.out_f32 + orow * e.ld_of + n) = v0;
+          *(f32x4*)(e.out_f32 + orow * e.ld_of + n + 4) = v1;
+        }
+        if (e.out_bf16) {
+          u32x4 p = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
+          *(u32x4*)(e.out_bf16 + orow * e.ld_ob + n) = p;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  do_half(0, acc[0], acc[1]);
+  do_half(1, acc[2], acc[3]);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
+                                                             int M, int N, int K, int tiles_m, int tiles_n, GemmEpi e, int dbg) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * BM * BK * 2];  // [buf][A|B][128 rows][128 B]
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  // bijective XCD remap (blocks b, b+8, ... share an XCD): XCD x owns a contiguous chunk of the tile list
+  const int nwg = tiles_m * tiles_n, bid = blockIdx.x;
+  const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
+  const int tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+  const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nk = K / BK;
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(((size_t)(M - 1) * lda + K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(((size_t)(N - 1) * ldb + K) * 2), 0x00020000);
+  // this lane's source offsets for the 4 pieces (8 rows each) its wave stages per operand
+  // piece i (i = 0..3) of this wave covers tile rows (4w + i)*8 .. +7; lane -> (row_in = l>>3, chunk position = l&7).
+  // (row >> 1) & 7 == (4*(i&1) + (row_in >> 1)) & 7, so only two distinct source-chunk permutations exist per lane.
+  const int rin = l >> 3, cpos = l & 7;
+  const int cs_even = cpos ^ ((rin >> 1) & 7), cs_odd = cpos ^ ((4 + (rin >> 1)) & 7);
+  const int row_base = w * 32 + rin;
+  const int oa_e = ((m0 + row_base) * lda + cs_even * 8) * 2, oa_o = ((m0 + row_base + 8) * lda + cs_odd * 8) * 2;
+  const int ob_e = ((n0 + row_base) * ldb + cs_even * 8) * 2, ob_o = ((n0 + row_base + 8) * ldb + cs_odd * 8) * 2;
+  const int sa16 = lda * 32, sb16 = ldb * 32;  // 16 rows further, in bytes
+  auto stage = [=](int buf, int kt) __attribute__((always_inline)) {
+    unsigned char* sa = smem + buf * (2 * BM * BK * 2) + w * 4096;
+    unsigned char* sb = sa + BM * BK * 2;
+    const int kb = kt * BK * 2;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(sa), 16, oa_e + kb, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(sb), 16, ob_e + kb, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(sa + 1024), 16, oa_o + kb, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(sb + 1024), 16, ob_o + kb, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(sa + 2048), 16, oa_e + sa16 + kb, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(sb + 2048), 16, ob_e + sb16 + kb, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(sa + 3072), 16, oa_o + sa16 + kb, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(sb + 3072), 16, ob_o + sb16 + kb, 0, 0, 0);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  __syncthreads();  // (hipcc drains the pending LDS-DMA with vmcnt(0) in front of the barrier)
+  for (int kt = 0; kt < nk; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+    const unsigned char* sa = smem + buf * (2 * BM * BK * 2);
+    const unsigned char* sb = sa + BM * BK * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      bf16x8 af[4], bfr[4];
+      const int ch = (l >> 4) + 4 * ks;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int ar = wm * 64 + i * 16 + (l & 15);
+        const int br = wn * 64 + i * 16 + (l & 15);
+        af[i] = *(const bf16x8*)(sa + swz_nt(ar, ch));
+        bfr[i] = *(const bf16x8*)(sb + swz_nt(br, ch));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // D[n][m]
+    }
+    __syncthreads();
+  }
+  if (dbg == 1) { if (acc[0][0][0] == 1234.5f) e.out_f32[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; return; }
+  epilogue_nt_lds(acc, smem, w, m0, n0, wm, wn, l, M, N, e);
+}
+
+extern int g_variant;
+
 int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt: empty problem M=%d N=%d K=%d", M, N, K); return SMBV_ERR_SHAPE; }
   if ((K & 7) || (lda & 7) || (ldb & 7) || (N & 3)) { set_error("gemm_nt: K,lda,ldb must be multiples of 8 and N of 4 (K=%d lda=%d ldb=%d N=%d)", K, lda, ldb, N); return SMBV_ERR_SHAPE; }
@@ -144,6 +303,13 @@ int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, in
     set_error("gemm_nt: epilogue operand alignment/stride"); return SMBV_ERR_ALIGN;
   }
   const int tm = cdiv(M, BM), tn = cdiv(N, BN);
+  const bool dma_ok = (K % BK == 0) && (N % 8 == 0) && (!e.out_bf16 || ((e.ld_ob & 7) == 0 && ((uintptr_t)e.out_bf16 & 15) == 0)) &&
+                      (!e.aux_pre || ((e.ld_aux & 7) == 0 && ((uintptr_t)e.aux_pre & 15) == 0)) &&
+                      (!e.dgelu_pre || ((e.ld_pre & 7) == 0 && ((uintptr_t)e.dgelu_pre & 15) == 0)) && ((size_t)M * lda * 2 < (1ull << 31)) && ((size_t)N * ldb * 2 < (1ull << 31));
+  if (dma_ok && !(g_variant & 32)) {
+    hipLaunchKernelGGL(gemm_nt_dma_kernel, dim3(tm * tn), dim3(256), 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, (g_variant & 64) ? 1 : ((g_variant & 128) ? 2 : 0));
+    return check_launch("gemm_nt_dma");
+  }
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(tm * tn), dim3(256), 0, st, A, lda, B, ldb, M, N, K, tm, e);
   return check_launch("gemm_nt");
 }

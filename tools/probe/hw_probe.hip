@@ -50,13 +50,25 @@ __global__ void k_tr(const u16* in, u16* out) {
 }
 // global_load_lds 16B: lane i loads 16 B from src + perm(i)*16 and LDS gets it at base + i*16.
 __global__ void k_glds(const unsigned* src, unsigned* out) {
-  __shared__ __attribute__((aligned(16))) unsigned lds[2 * 256];
+  __shared__ __attribute__((aligned(16))) unsigned lds[4 * 256];
   int l = threadIdx.x;
   int w = l >> 6, lane = l & 63;
   int srcchunk = (lane ^ 5) + 64 * w;  // permuted source
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + srcchunk * 4),
                                    (__attribute__((address_space(3))) void*)(lds + w * 256), 16, 0, 0);
   __builtin_amdgcn_s_waitcnt(0);  // drain everything
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int e = 0; e < 4; e++) out[l * 4 + e] = lds[l * 4 + e];
+}
+// raw_buffer_load_lds 16B with bounds: records beyond num_records must land as zeros
+__global__ void k_blds(const unsigned* src, unsigned* out, int valid_bytes) {
+  __shared__ __attribute__((aligned(16))) unsigned lds[4 * 256];
+  int l = threadIdx.x;
+  int w = l >> 6, lane = l & 63;
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, valid_bytes, 0x00020000);
+  int srcchunk = (lane ^ 3) + 64 * w;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + w * 256), 16, srcchunk * 16, 0, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int e = 0; e < 4; e++) out[l * 4 + e] = lds[l * 4 + e];
@@ -132,6 +144,19 @@ int main() {
     int bad = 0;
     for (int l = 0; l < 256; l++) for (int e = 0; e < 4; e++) { int w = l >> 6, lane = l & 63; int sc = (lane ^ 5) + 64 * w; if (O[l * 4 + e] != S[sc * 4 + e]) bad++; }
     printf("global_load_lds dwordx4 semantics: %s (%d bad)\n", bad ? "FAIL" : "PASS", bad); fails += bad != 0;
+  }
+  {  // buffer_load lds with bounds
+    std::vector<unsigned> S(256 * 4); for (int i = 0; i < 1024; i++) S[i] = i * 7 + 5;
+    unsigned *dS, *dO; CK(hipMalloc(&dS, 4096)); CK(hipMalloc(&dO, 4096));
+    CK(hipMemcpy(dS, S.data(), 4096, hipMemcpyHostToDevice));
+    CK(hipMemset(dO, 0xff, 4096));
+    const int valid = 3000;  // bytes; chunks at offset >= 3000-15 are (partly) out of range
+    k_blds<<<1, 256>>>(dS, dO, valid); CK(hipDeviceSynchronize());
+    std::vector<unsigned> O(1024); CK(hipMemcpy(O.data(), dO, 4096, hipMemcpyDeviceToHost));
+    int bad = 0, zeros = 0;
+    for (int l = 0; l < 256; l++) for (int e = 0; e < 4; e++) { int w = l >> 6, lane = l & 63; int sc = (lane ^ 3) + 64 * w; int byte = sc * 16 + e * 4;
+      unsigned exp = (byte + 4 <= valid) ? S[sc * 4 + e] : 0u; if (O[l * 4 + e] != exp) bad++; if (byte + 4 > valid) zeros++; }
+    printf("raw_buffer_load_lds dwordx4 + bounds->0 semantics: %s (%d bad, %d expected zeros)\n", bad ? "FAIL" : "PASS", bad, zeros); fails += bad != 0;
   }
   {  // acc as operand
     std::vector<u16> A1(512), B1t(512), B2t(1024); std::vector<float> A1f(512), B1f(512), B2f(1024);
