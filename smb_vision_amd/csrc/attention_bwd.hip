@@ -13,6 +13,7 @@
 // float atomics would be bound by the ~1.3 TB/s atomic rate at S = 20,480: see DESIGN.md).
 #include "smbv_common.h"
 #include "smbv_kernels.h"
+#include <type_traits>
 
 namespace smbv {
 extern int g_variant;
@@ -59,14 +60,17 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   }
 }
 
-template <int MINW>
+template <int MINW, int QT>
 __global__ __launch_bounds__(256, MINW) void attn_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO,
                                                        int ldo, const float* __restrict__ LSE, const float* __restrict__ delta,
                                                        bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int ldd, int S, int H,
                                                        float scale) {
-  // LDS per buffer: Q [32][128 B] 4 KiB | dO 4 KiB | lse2 [32] f32 | delta [32] f32
-  constexpr int BUF = 4096 + 4096 + 128 + 128;
+  // One iteration = 64 queries (two 32-row sub-tiles): half the barriers and twice the work per global-load round trip of
+  // a 32-query iteration (the kernel was parked in waits 55 % of its wave-cycles).
+  // LDS per buffer: Q [64][128 B] 8 KiB | dO 8 KiB | -lse*log2e [64] f32 | -delta [64] f32
+  constexpr int NS = QT / 32;  // 32-row sub-tiles per iteration
+  constexpr int BUF = 2 * QT * 128 + 2 * QT * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int r = l & 31, h2 = l >> 5;
@@ -93,26 +97,32 @@ __global__ __launch_bounds__(256, MINW) void attn_dkv_kernel(const bf16_t* __res
 #pragma unroll
   for (int i = 0; i < 16; i++) { dkt[0][i] = 0.f; dkt[1][i] = 0.f; dvt[0][i] = 0.f; dvt[1][i] = 0.f; }
 
-  u32x4 rq, rdo;
+  u32x4 rq[NS], rdo[NS];
   float rstat = 0.f;
   auto gload = [&](int qt) {
-    const int q0 = qt * 32;
-    const int row = t >> 3, ch = t & 7;
-    const bool ok = (q0 + row) < S;
-    rq = ok ? *(const u32x4*)(Q + (row0 + q0 + row) * ld + hoff + ch * 8) : (u32x4){0, 0, 0, 0};
-    rdo = ok ? *(const u32x4*)(dO + (row0 + q0 + row) * ldo + hoff + ch * 8) : (u32x4){0, 0, 0, 0};
-    if (t < 32) rstat = (q0 + t < S) ? -lse_p[q0 + t] * 1.4426950408889634f : -INFINITY;  // padded rows: p = exp2(-inf) = 0
-    else if (t < 64) rstat = (q0 + t - 32 < S) ? -del_p[q0 + t - 32] : 0.f;
+    const int q0 = qt * QT;
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+      const int id = t + 256 * i, row = id >> 3, ch = id & 7;
+      const bool ok = (q0 + row) < S;
+      rq[i] = ok ? *(const u32x4*)(Q + (row0 + q0 + row) * ld + hoff + ch * 8) : (u32x4){0, 0, 0, 0};
+      rdo[i] = ok ? *(const u32x4*)(dO + (row0 + q0 + row) * ldo + hoff + ch * 8) : (u32x4){0, 0, 0, 0};
+    }
+    if (t < QT) rstat = (q0 + t < S) ? -lse_p[q0 + t] * 1.4426950408889634f : -INFINITY;  // padded rows: p = exp2(-inf) = 0
+    else if (t < 2 * QT) rstat = (q0 + t - QT < S) ? -del_p[q0 + t - QT] : 0.f;
   };
   auto lstore = [&](int buf) {
     unsigned char* s = smem + buf * BUF;
-    const int row = t >> 3, ch = t & 7;
-    *(u32x4*)(s + swz128(row, ch)) = rq;
-    *(u32x4*)(s + 4096 + swz128(row, ch)) = rdo;
-    if (t < 64) ((float*)(s + 8192))[t] = rstat;  // [0..31] -lse*log2e, [32..63] -delta
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+      const int id = t + 256 * i, row = id >> 3, ch = id & 7;
+      *(u32x4*)(s + swz128(row, ch)) = rq[i];
+      *(u32x4*)(s + QT * 128 + swz128(row, ch)) = rdo[i];
+    }
+    if (t < 2 * QT) ((float*)(s + 2 * QT * 128))[t] = rstat;  // [0..QT) -lse*log2e, [QT..2QT) -delta
   };
 
-  const int nq = (S + 31) / 32;
+  const int nq = (S + QT - 1) / QT;
   gload(0);
   lstore(0);
   __syncthreads();
@@ -121,50 +131,53 @@ __global__ __launch_bounds__(256, MINW) void attn_dkv_kernel(const bf16_t* __res
     const int buf = qt & 1;
     if (qt + 1 < nq) gload(qt + 1);
     const unsigned char* sq = smem + buf * BUF;
-    const unsigned char* sdo = sq + 4096;
-    const float* sst = (const float*)(sq + 8192);
-
-    // accumulators start at the row constants: S' = c*q.k - lse*log2e, dP' = dO.v - delta (rows 8*rg + 4*h2 + 0..3)
-    f32x16 s, dp;
+    const unsigned char* sdo = sq + QT * 128;
+    const float* sst = (const float*)(sq + 2 * QT * 128);
 #pragma unroll
-    for (int rg = 0; rg < 4; rg++) {
-      const f32x4 ls = *(const f32x4*)(sst + 8 * rg + 4 * h2);
-      const f32x4 de = *(const f32x4*)(sst + 32 + 8 * rg + 4 * h2);
+    for (int sub = 0; sub < NS; sub++) {
+      const int rb = 32 * sub;  // first query row of this sub-tile inside the LDS images
+      // accumulators start at the row constants: S' = c*q.k - lse*log2e, dP' = dO.v - delta (rows 8*rg + 4*h2 + 0..3)
+      f32x16 s, dp;
 #pragma unroll
-      for (int e = 0; e < 4; e++) { s[4 * rg + e] = ls[e]; dp[4 * rg + e] = de[e]; }
-    }
+      for (int rg = 0; rg < 4; rg++) {
+        const f32x4 ls = *(const f32x4*)(sst + rb + 8 * rg + 4 * h2);
+        const f32x4 de = *(const f32x4*)(sst + QT + rb + 8 * rg + 4 * h2);
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-      const bf16x8 qa = *(const bf16x8*)(sq + swz128(r, 2 * ks + h2));
-      const bf16x8 da = *(const bf16x8*)(sdo + swz128(r, 2 * ks + h2));
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);     // [q][key]
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);   // [q][key]
-    }
+        for (int e = 0; e < 4; e++) { s[4 * rg + e] = ls[e]; dp[4 * rg + e] = de[e]; }
+      }
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const float p = fast_exp2(s[i]);
-      s[i] = p;
-      dp[i] *= p;
-    }
+      for (int ks = 0; ks < 4; ks++) {
+        const bf16x8 qa = *(const bf16x8*)(sq + swz128(rb + r, 2 * ks + h2));
+        const bf16x8 da = *(const bf16x8*)(sdo + swz128(rb + r, 2 * ks + h2));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);     // [q][key]
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);   // [q][key]
+      }
 #pragma unroll
-    for (int s2 = 0; s2 < 2; s2++) {
-      bf16x8 pf, dsf;
+      for (int i = 0; i < 16; i++) {
+        const float p = fast_exp2(s[i]);
+        s[i] = p;
+        dp[i] *= p;
+      }
 #pragma unroll
-      for (int j = 0; j < 8; j++) { pf[j] = (__bf16)s[8 * s2 + j]; dsf[j] = (__bf16)dp[8 * s2 + j]; }
-      const int qb = 16 * s2 + 4 * h2 + qq;
+      for (int s2 = 0; s2 < 2; s2++) {
+        bf16x8 pf, dsf;
 #pragma unroll
-      for (int dt = 0; dt < 2; dt++) {
-        const int c16 = 4 * dt + 2 * g1 + (pp >> 1);
-        const int sub = 8 * (pp & 1);
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        const s16x4 a0 = lds_read_tr16(sdo + swz128(qb, c16) + sub);
-        const s16x4 a1 = lds_read_tr16(sdo + swz128(qb + 8, c16) + sub);
-        const s16x8 aa = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aa), pf, dvt[dt], 0, 0, 0);
-        const s16x4 b0 = lds_read_tr16(sq + swz128(qb, c16) + sub);
-        const s16x4 b1 = lds_read_tr16(sq + swz128(qb + 8, c16) + sub);
-        const s16x8 bb = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bb), dsf, dkt[dt], 0, 0, 0);
+        for (int j = 0; j < 8; j++) { pf[j] = (__bf16)s[8 * s2 + j]; dsf[j] = (__bf16)dp[8 * s2 + j]; }
+        const int qb = rb + 16 * s2 + 4 * h2 + qq;
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++) {
+          const int c16 = 4 * dt + 2 * g1 + (pp >> 1);
+          const int sb8 = 8 * (pp & 1);
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x4 a0 = lds_read_tr16(sdo + swz128(qb, c16) + sb8);
+          const s16x4 a1 = lds_read_tr16(sdo + swz128(qb + 8, c16) + sb8);
+          const s16x8 aa = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aa), pf, dvt[dt], 0, 0, 0);
+          const s16x4 b0 = lds_read_tr16(sq + swz128(qb, c16) + sb8);
+          const s16x4 b1 = lds_read_tr16(sq + swz128(qb + 8, c16) + sb8);
+          const s16x8 bb = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+          dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bb), dsf, dkt[dt], 0, 0, 0);
+        }
       }
     }
     if (qt + 1 < nq) lstore(buf ^ 1);
@@ -187,12 +200,13 @@ __global__ __launch_bounds__(256, MINW) void attn_dkv_kernel(const bf16_t* __res
   }
 }
 
-template <int MINW>
+template <int MINW, int KT>
 __global__ __launch_bounds__(256, MINW) void attn_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                       const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO, int ldo,
                                                       const float* __restrict__ LSE, const float* __restrict__ delta,
                                                       bf16_t* __restrict__ dQ, int ldd, int S, int H, float scale) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 64 * 128];  // [buf][K|V][64 keys][128 B]
+  constexpr int NL = KT / 32;  // 16-B chunks per thread per operand per tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * KT * 128];  // [buf][K|V][KT keys][128 B]
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int r = l & 31, h2 = l >> 5;
   const int head = blockIdx.y, b = blockIdx.z;
@@ -224,11 +238,11 @@ __global__ __launch_bounds__(256, MINW) void attn_dq_kernel(const bf16_t* __rest
 #pragma unroll
   for (int i = 0; i < 16; i++) { dqt[0][i] = 0.f; dqt[1][i] = 0.f; }
 
-  u32x4 rk[2], rv[2];
+  u32x4 rk[NL], rv[NL];
   auto gload = [&](int kt) {
-    const int k0 = kt * 64;
+    const int k0 = kt * KT;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < NL; i++) {
       const int id = t + 256 * i, row = id >> 3, ch = id & 7;
       const bool ok = (k0 + row) < S;
       const size_t off = (row0 + k0 + row) * ld + hoff + ch * 8;
@@ -237,17 +251,17 @@ __global__ __launch_bounds__(256, MINW) void attn_dq_kernel(const bf16_t* __rest
     }
   };
   auto lstore = [&](int buf) {
-    unsigned char* sk = smem + buf * (2 * 64 * 128);
-    unsigned char* sv = sk + 64 * 128;
+    unsigned char* sk = smem + buf * (2 * KT * 128);
+    unsigned char* sv = sk + KT * 128;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < NL; i++) {
       const int id = t + 256 * i, row = id >> 3, ch = id & 7;
       *(u32x4*)(sk + swz128(row, ch)) = rk[i];
       *(u32x4*)(sv + swz128(row, ch)) = rv[i];
     }
   };
 
-  const int nt = (S + 63) / 64;
+  const int nt = (S + KT - 1) / KT;
   gload(0);
   lstore(0);
   __syncthreads();
@@ -255,12 +269,12 @@ __global__ __launch_bounds__(256, MINW) void attn_dq_kernel(const bf16_t* __rest
   for (int kt = 0; kt < nt; kt++) {
     const int buf = kt & 1;
     if (kt + 1 < nt) gload(kt + 1);
-    const unsigned char* sk = smem + buf * (2 * 64 * 128);
-    const unsigned char* sv = sk + 64 * 128;
-    const bool ragged = kt * 64 + 64 > S;
-#pragma unroll
-    for (int kt2 = 0; kt2 < 2; kt2++) {
-      f32x16 s, dp;
+    const unsigned char* sk = smem + buf * (2 * KT * 128);
+    const unsigned char* sv = sk + KT * 128;
+    // Software pipeline over the 32-key sub-tiles: the S/dP MFMAs of sub-tile j+1 are issued before the exp/multiply/convert
+    // VALU work and the dQ MFMAs of sub-tile j, so one wave keeps the matrix pipe busy while it does its own softmax math
+    // (the un-pipelined loop spent 36 % of its wave-cycles stalled on instruction issue).
+    auto qk = [&](const int kt2, f32x16& s, f32x16& dp) __attribute__((always_inline)) {
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) {
         const bf16x8 ka = *(const bf16x8*)(sk + swz128(32 * kt2 + r, 2 * ks + h2));
@@ -268,15 +282,12 @@ __global__ __launch_bounds__(256, MINW) void attn_dq_kernel(const bf16_t* __rest
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], ks == 0 ? sinit : s, 0, 0, 0);      // [key][q]
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], ks == 0 ? dinit : dp, 0, 0, 0);   // [key][q]
       }
+    };
+    // keys >= S (ragged last tile) need no mask here: their K rows are staged as zeros, so whatever dS they get is multiplied by
+    // a zero K row in dQ^T += K^T dS^T.
+    auto tail = [&](const int kt2, f32x16& s, f32x16& dp) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        float p = fast_exp2(s[i]);
-        if (ragged) {
-          const int key = kt * 64 + 32 * kt2 + (i & 3) + 8 * (i >> 2) + 4 * h2;
-          if (key >= S) p = 0.f;
-        }
-        dp[i] *= p;
-      }
+      for (int i = 0; i < 16; i++) dp[i] *= fast_exp2(s[i]);
 #pragma unroll
       for (int s2 = 0; s2 < 2; s2++) {
         bf16x8 dsf;
@@ -294,6 +305,15 @@ __global__ __launch_bounds__(256, MINW) void attn_dq_kernel(const bf16_t* __rest
           dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aa), dsf, dqt[dt], 0, 0, 0);
         }
       }
+    };
+    f32x16 sA, dpA, sB, dpB;
+    qk(0, sA, dpA);
+#pragma unroll
+    for (int j = 0; j < KT / 32; j += 2) {
+      qk(j + 1, sB, dpB);
+      tail(j, sA, dpA);
+      if (j + 2 < KT / 32) qk(j + 2, sA, dpA);
+      tail(j + 1, sB, dpB);
     }
     if (kt + 1 < nt) lstore(buf ^ 1);
     __syncthreads();
@@ -326,14 +346,19 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
   }
   if (parts & 2) {
     const bool w3 = (g_variant & 4) || (!(g_variant & 16) && attn_prefer_3waves((long)cdiv(S, 128) * H * B));
-    if (w3) hipLaunchKernelGGL(attn_dkv_kernel<3>, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, H, scale);
-    else hipLaunchKernelGGL(attn_dkv_kernel<2>, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, H, scale);
+#define DKV(W, QT) hipLaunchKernelGGL((attn_dkv_kernel<W, QT>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, H, scale)
+    if (w3) DKV(3, 32);
+    else if (g_variant & 256) DKV(2, 32);
+    else DKV(2, 64);
+#undef DKV
     rc = check_launch("attn_dkv");
     if (rc) return rc;
   }
   if (parts & 4) {
-    if (g_variant & 8) hipLaunchKernelGGL(attn_dq_kernel<3>, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, H, scale);
-    else hipLaunchKernelGGL(attn_dq_kernel<2>, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, H, scale);
+#define DQ(W, KT) hipLaunchKernelGGL((attn_dq_kernel<W, KT>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, H, scale)
+    if (g_variant & 512) DQ(2, 64);
+    else DQ(2, 128);
+#undef DQ
     rc = check_launch("attn_dq");
   }
   return rc;
