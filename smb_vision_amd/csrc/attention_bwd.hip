@@ -119,7 +119,13 @@ __global__ __launch_bounds__(256, MINW) void attn_dkv_kernel(const bf16_t* __res
       *(u32x4*)(s + swz128(row, ch)) = rq[i];
       *(u32x4*)(s + QT * 128 + swz128(row, ch)) = rdo[i];
     }
-    if (t < 2 * QT) ((float*)(s + 2 * QT * 128))[t] = rstat;  // [0..QT) -lse*log2e, [QT..2QT) -delta
+    // row constants, arranged so that each lane half reads its 16 accumulator rows (8*rg + 4*h2 + e) of a 32-row sub-tile as ONE
+    // contiguous 64-byte vector: position = 32*sub + 16*h2 + 4*rg + e
+    if (t < 2 * QT) {
+      const int rr = t % QT;
+      const int pos = (rr & ~31) + 16 * ((rr >> 2) & 1) + 4 * ((rr & 31) >> 3) + (rr & 3);
+      ((float*)(s + 2 * QT * 128))[(t / QT) * QT + pos] = rstat;  // [0..QT) -lse*log2e, [QT..2QT) -delta
+    }
   };
 
   const int nq = (S + QT - 1) / QT;
@@ -137,14 +143,8 @@ __global__ __launch_bounds__(256, MINW) void attn_dkv_kernel(const bf16_t* __res
     for (int sub = 0; sub < NS; sub++) {
       const int rb = 32 * sub;  // first query row of this sub-tile inside the LDS images
       // accumulators start at the row constants: S' = c*q.k - lse*log2e, dP' = dO.v - delta (rows 8*rg + 4*h2 + 0..3)
-      f32x16 s, dp;
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const f32x4 ls = *(const f32x4*)(sst + rb + 8 * rg + 4 * h2);
-        const f32x4 de = *(const f32x4*)(sst + QT + rb + 8 * rg + 4 * h2);
-#pragma unroll
-        for (int e = 0; e < 4; e++) { s[4 * rg + e] = ls[e]; dp[4 * rg + e] = de[e]; }
-      }
+      f32x16 s = *(const f32x16*)(sst + rb + 16 * h2);
+      f32x16 dp = *(const f32x16*)(sst + QT + rb + 16 * h2);
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) {
         const bf16x8 qa = *(const bf16x8*)(sq + swz128(rb + r, 2 * ks + h2));
@@ -345,11 +345,11 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     if (rc) return rc;
   }
   if (parts & 2) {
-    const bool w3 = (g_variant & 4) || (!(g_variant & 16) && attn_prefer_3waves((long)cdiv(S, 128) * H * B));
 #define DKV(W, QT) hipLaunchKernelGGL((attn_dkv_kernel<W, QT>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, H, scale)
-    if (w3) DKV(3, 32);
-    else if (g_variant & 256) DKV(2, 32);
-    else DKV(2, 64);
+    // measured (tools/attn_ab.py): 128-query iterations at 2 waves/SIMD beat 64/32-query ones and the 3-wave build on both shapes
+    if (g_variant & 4) DKV(3, 32);
+    else if (g_variant & 256) DKV(2, 64);
+    else DKV(2, 128);
 #undef DKV
     rc = check_launch("attn_dkv");
     if (rc) return rc;
