@@ -19,6 +19,7 @@
 namespace smbv {
 
 static constexpr int BM = 128, BN = 128, BK = 64;
+extern int g_variant;  // tuning / A-B hook, see attention_fwd.hip
 
 __device__ __forceinline__ int swz_nt(int row, int chunk) { return row * 128 + (((chunk) ^ ((row >> 1) & 7)) << 4); }
 
@@ -291,8 +292,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(const bf16_t* __res
   epilogue_nt_lds(acc, smem, w, m0, n0, wm, wn, l, M, N, e);
 }
 
-extern int g_variant;
-
 int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt: empty problem M=%d N=%d K=%d", M, N, K); return SMBV_ERR_SHAPE; }
   if ((K & 7) || (lda & 7) || (ldb & 7) || (N & 3)) { set_error("gemm_nt: K,lda,ldb must be multiples of 8 and N of 4 (K=%d lda=%d ldb=%d N=%d)", K, lda, ldb, N); return SMBV_ERR_SHAPE; }
@@ -415,6 +414,102 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
   }
 }
 
+// TN with LDS-DMA staging (N1, N2 multiples of 128): 4 rows x 256 B per wave-instruction; the 32-byte-column XOR swizzle is
+// applied to the per-lane source address; rows beyond this split's token range read as zeros through the buffer bounds check.
+__global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y, int ldy,
+                                                             int M, int N1, int N2, float* __restrict__ out, int ldo, int tiles_1,
+                                                             int mchunk, size_t slab_stride) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * BK * 128 * 2];
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int w1 = w >> 1, w2 = w & 1;
+  const int tile_1 = blockIdx.x % tiles_1, tile_2 = blockIdx.x / tiles_1;
+  const int a0 = tile_1 * 128, b0 = tile_2 * 128;
+  const int z = blockIdx.y;
+  const int mbeg = z * mchunk, mend = min(M, mbeg + mchunk);
+  const int nk = (mend - mbeg + BK - 1) / BK;
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, mend > 0 ? (int)(((size_t)(mend - 1) * ldx + N1) * 2) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)Y, 0, mend > 0 ? (int)(((size_t)(mend - 1) * ldy + N2) * 2) : 0, 0x00020000);
+  // piece i (0..3) of wave w covers tile rows 16w + 4i .. +3; lane -> (row_in = l>>4, 16-B chunk position = l&15)
+  const int rin = l >> 4, cp = l & 15;
+  int ox[4], oy[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int row = 16 * w + 4 * i + rin;
+    const int sw = (rin & 3) | (((i >> 1) & 1) << 2);            // == sw_tn(row)
+    const int csrc = 2 * ((cp >> 1) ^ sw) + (cp & 1);
+    ox[i] = ((mbeg + row) * ldx + a0 + csrc * 8) * 2;
+    oy[i] = ((mbeg + row) * ldy + b0 + csrc * 8) * 2;
+  }
+  const int ox0 = ox[0], ox1 = ox[1], ox2 = ox[2], ox3 = ox[3], oy0 = oy[0], oy1 = oy[1], oy2 = oy[2], oy3 = oy[3];
+  const int kx = BK * ldx * 2, ky = BK * ldy * 2;
+  auto stage = [=](int buf, int kt) __attribute__((always_inline)) {
+    unsigned char* sx = smem + buf * (2 * BK * 256) + w * 4096;
+    unsigned char* sy = sx + BK * 256;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sx), 16, ox0 + kt * kx, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (__attribute__((address_space(3))) void*)(sy), 16, oy0 + kt * ky, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sx + 1024), 16, ox1 + kt * kx, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (__attribute__((address_space(3))) void*)(sy + 1024), 16, oy1 + kt * ky, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sx + 2048), 16, ox2 + kt * kx, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (__attribute__((address_space(3))) void*)(sy + 2048), 16, oy2 + kt * ky, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sx + 3072), 16, ox3 + kt * kx, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (__attribute__((address_space(3))) void*)(sy + 3072), 16, oy3 + kt * ky, 0, 0, 0);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) stage(0, 0);
+  __syncthreads();
+  const int g = l >> 4, q = (l >> 2) & 3, p = l & 3;
+  for (int kt = 0; kt < nk; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+    const unsigned char* sx = smem + buf * (2 * BK * 256);
+    const unsigned char* sy = sx + BK * 256;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      bf16x8 xf[4], yf[4];
+      const int mA = 32 * ks + 8 * g + q, mB = mA + 4;
+      const int swA = sw_tn(mA), swB = sw_tn(mB);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int nt1 = w1 * 4 + i, nt2 = w2 * 4 + i;
+        s16x4 x0 = lds_read_tr16(sx + mA * 256 + 32 * (nt1 ^ swA) + 8 * p);
+        s16x4 x1 = lds_read_tr16(sx + mB * 256 + 32 * (nt1 ^ swB) + 8 * p);
+        s16x4 y0 = lds_read_tr16(sy + mA * 256 + 32 * (nt2 ^ swA) + 8 * p);
+        s16x4 y1 = lds_read_tr16(sy + mB * 256 + 32 * (nt2 ^ swB) + 8 * p);
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 xx = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        s16x8 yy = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+        xf[i] = __builtin_bit_cast(bf16x8, xx);
+        yf[i] = __builtin_bit_cast(bf16x8, yy);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[j], xf[i], acc[i][j], 0, 0, 0);  // D[n2][n1]
+    }
+    __syncthreads();
+  }
+
+  float* o = out + (size_t)z * slab_stride;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int n1 = a0 + w1 * 64 + i * 16 + (l & 15);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int n2 = b0 + w2 * 64 + j * 16 + 4 * (l >> 4);
+      *(f32x4*)(o + (size_t)n1 * ldo + n2) = acc[i][j];
+    }
+  }
+}
+
 __global__ void reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ slabs, int nslab, size_t n4, size_t slab_stride4) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     f32x4 s = ((const f32x4*)slabs)[i];
@@ -423,11 +518,23 @@ __global__ void reduce_slabs_kernel(float* __restrict__ out, const float* __rest
   }
 }
 
+// Token-range splits: blocks = tiles * s must fill the 512 block slots (2 per CU) of ONE round as well as possible - a grid of
+// 576 blocks costs two rounds - while every block keeps a loop of at least ~16 K-steps (1024 tokens; 512 for tiny outputs).
 int gemm_tn_splits(int M, int N1, int N2) {
   const int tiles = cdiv(N1, 128) * cdiv(N2, 128);
-  int s = 1;
-  while (tiles * s < 384 && s < 32 && M / (s * 2) >= 256) s *= 2;
-  return s;
+  int best = 1;
+  double best_eff = 0.0;
+  for (int pass = 0; pass < 2 && best_eff < 0.55; pass++) {
+    const int min_rows = pass == 0 ? 1024 : 512;
+    for (int s = 1; s <= 32; s++) {
+      if (s > 1 && M / s < min_rows) break;
+      const long blocks = (long)tiles * s;
+      const long rounds = (blocks + 511) / 512;
+      const double eff = (double)blocks / (double)(rounds * 512);
+      if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
+    }
+  }
+  return best;
 }
 
 size_t gemm_tn_workspace_bytes(int M, int N1, int N2) {
@@ -441,14 +548,17 @@ int gemm_tn(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int M, int N1, i
   if (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)out) & 15) { set_error("gemm_tn: operands must be 16-byte aligned"); return SMBV_ERR_ALIGN; }
   const int s = gemm_tn_splits(M, N1, N2);
   const int t1 = cdiv(N1, 128), t2 = cdiv(N2, 128);
+  const bool dma = (N1 % 128 == 0) && (N2 % 128 == 0) && ((size_t)M * ldx * 2 < (1ull << 31)) && ((size_t)M * ldy * 2 < (1ull << 31)) && !(g_variant & 32);
   if (s == 1) {
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(t1 * t2, 1), dim3(256), 0, st, X, ldx, Y, ldy, M, N1, N2, out, N2, t1, ((M + 63) / 64) * 64, (size_t)0);
+    if (dma) hipLaunchKernelGGL(gemm_tn_dma_kernel, dim3(t1 * t2, 1), dim3(256), 0, st, X, ldx, Y, ldy, M, N1, N2, out, N2, t1, ((M + 63) / 64) * 64, (size_t)0);
+    else hipLaunchKernelGGL(gemm_tn_kernel, dim3(t1 * t2, 1), dim3(256), 0, st, X, ldx, Y, ldy, M, N1, N2, out, N2, t1, ((M + 63) / 64) * 64, (size_t)0);
     return check_launch("gemm_tn");
   }
   const size_t need = (size_t)s * N1 * N2 * sizeof(float);
   if (!ws || ws_bytes < need || ((uintptr_t)ws & 15)) { set_error("gemm_tn: workspace too small (%zu < %zu)", ws_bytes, need); return SMBV_ERR_WORKSPACE; }
   int mchunk = cdiv(cdiv(M, s), 64) * 64;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(t1 * t2, s), dim3(256), 0, st, X, ldx, Y, ldy, M, N1, N2, (float*)ws, N2, t1, mchunk, (size_t)N1 * N2);
+  if (dma) hipLaunchKernelGGL(gemm_tn_dma_kernel, dim3(t1 * t2, s), dim3(256), 0, st, X, ldx, Y, ldy, M, N1, N2, (float*)ws, N2, t1, mchunk, (size_t)N1 * N2);
+  else hipLaunchKernelGGL(gemm_tn_kernel, dim3(t1 * t2, s), dim3(256), 0, st, X, ldx, Y, ldy, M, N1, N2, (float*)ws, N2, t1, mchunk, (size_t)N1 * N2);
   int rc = check_launch("gemm_tn");
   if (rc) return rc;
   const size_t n4 = (size_t)N1 * N2 / 4;
