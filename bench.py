@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward only (diagnostic; not the metric)")
     ap.add_argument("--tiny", action="store_true", help="64x64x32 smoke shape (diagnostic; not the metric)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse the N>1 path on one GPU)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -145,11 +146,14 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the MIM hot path has no CPU fallback")
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     cfg_kw = dict(VIT_BASE)
     if args.tiny:
@@ -194,6 +198,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t)
     final_loss = float(loss.detach())
+    in_sync = None
+    if world > 1:  # replicas must hold identical parameters after K averaged steps (outside the timed region)
+        cs = torch.stack([p.detach().double().sum() for p in params]).sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool((hi - lo).abs().item() <= 1e-9 * max(1.0, abs(float(hi))))
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -205,7 +216,8 @@ def main():
             "config": {"workload": "ViT-base MIM, 512x512x320 volume, patch_size=16, mask_ratio=0.65 (mask_patch 32), B=1/GPU, "
                                    "fwd+loss+bwd+clip+AdamW" + ("" if opt is not None else " [NO OPTIMIZER: diagnostic]")
                                    + (" [TINY: diagnostic]" if args.tiny else ""),
-                       "tokens": model.num_patches, "masked": n_masked, "parallelism": f"dp{world}", "final_loss": final_loss},
+                       "tokens": model.num_patches, "masked": n_masked, "parallelism": f"dp{world}", "final_loss": final_loss,
+                       "replicas_in_sync": in_sync},
         }
         step_tf = STEP_TFLOP / (ms * 1e-3) if not args.tiny else None
         if not args.no_kernel_roofline and not args.tiny:
