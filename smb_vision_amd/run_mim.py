@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""MIM pre-training entry point on the MI355X path — the harness of reference ``src/run_mim.py`` with the model class swapped.
+
+Same skeleton as the reference script (``src/run_mim.py:222-471``): ``HfArgumentParser`` over (Model, Data, Training) argument
+dataclasses → dataset → ``VideoMAEConfig`` patched with ``num_channels=1, num_frames=depth, tubelet_size=patch_size, image_size``
+(``:302-330``) → model → ``collate_fn`` producing ``{"pixel_values", "bool_masked_pos"}`` (``:194-219``) → HF ``Trainer`` →
+``train`` / ``save_model`` / metrics.  Differences, all on purpose:
+
+* the model is ``SmbVideoMAEForPreTraining`` (HIP kernels behind the same interface);
+* the dataset here is synthetic and in-memory (``SyntheticVolumeDataset``: U[0,1) volumes in the post-``ScaleIntensityRanged`` range,
+  ``(D,1,H,W)`` layout of ``PermuteImage``, masks from the bit-exact ``MaskGenerator``): NIfTI/MONAI ingestion is out of scope
+   and absent from this image; plug a real dataset in by returning the same two keys;
+* nothing touches the network (no telemetry, no hub names: pass local paths only).
+
+    python -m smb_vision_amd.run_mim --output_dir /tmp/mim --image_size 64 --depth 32 --patch_size 16 --mask_patch_size 16 \
+        --mask_ratio 0.6 --max_steps 10 --per_device_train_batch_size 2 --report_to none --bf16 true
+"""
+from __future__ import annotations
+
+import logging
+import os
+import sys
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+from transformers import HfArgumentParser, Trainer, TrainingArguments, VideoMAEConfig, set_seed
+
+from .masking import MaskGenerator
+from .modeling_videomae import SmbVideoMAEForPreTraining
+
+logger = logging.getLogger(__name__)
+os.environ.setdefault("HF_HUB_OFFLINE", "1")
+os.environ.setdefault("TRANSFORMERS_OFFLINE", "1")
+os.environ.setdefault("WANDB_MODE", "disabled")
+
+
+@dataclass
+class DataTrainingArguments:
+    """Subset of the reference's DataTrainingArguments that shapes the hot path (``src/run_mim.py:45-110``)."""
+
+    image_size: int = field(default=224, metadata={"help": "The size (resolution) of each image."})
+    depth: int = field(default=160, metadata={"help": "The depth of each volume."})
+    patch_size: int = field(default=16, metadata={"help": "The size (resolution) of each patch."})
+    mask_patch_size: int = field(default=32, metadata={"help": "The size of the square patches to use for masking."})
+    mask_ratio: float = field(default=0.5, metadata={"help": "Percentage of patches to mask."})
+    num_train_volumes: int = field(default=16, metadata={"help": "Synthetic volumes per epoch."})
+    data_seed_offset: int = field(default=1234, metadata={"help": "Seed of the synthetic volumes."})
+
+
+@dataclass
+class ModelArguments:
+    """``src/run_mim.py:113-192`` (local paths only)."""
+
+    model_name_or_path: Optional[str] = field(default=None, metadata={"help": "LOCAL checkpoint directory to start from."})
+    config_name_or_path: Optional[str] = field(default=None, metadata={"help": "LOCAL config.json directory (else VideoMAEConfig())."})
+    hidden_size: Optional[int] = None
+    num_hidden_layers: Optional[int] = None
+    num_attention_heads: Optional[int] = None
+    intermediate_size: Optional[int] = None
+    decoder_hidden_size: Optional[int] = None
+    decoder_num_hidden_layers: Optional[int] = None
+    decoder_num_attention_heads: Optional[int] = None
+    decoder_intermediate_size: Optional[int] = None
+
+
+class SyntheticVolumeDataset(Dataset):
+    """Items shaped like the reference pipeline's output (``src/dataloader/mim.py:142-185``): ``image`` f32 (D,1,H,W) in [0,1],
+    ``mask`` bool (N,).  As with MONAI's deterministic ``GenerateMask`` transform, the mask is drawn when the item is produced."""
+
+    def __init__(self, n, image_size, depth, mask_generator, seed):
+        self.n, self.image_size, self.depth, self.gen, self.seed = n, image_size, depth, mask_generator, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed + i)
+        return {"image": torch.rand(self.depth, 1, self.image_size, self.image_size, generator=g), "mask": self.gen()}
+
+
+def collate_fn(examples):
+    """``src/run_mim.py:194-219``."""
+    pixel_values = torch.stack([e["image"] for e in examples])
+    mask = torch.stack([e["mask"] for e in examples])
+    return {"pixel_values": pixel_values, "bool_masked_pos": mask}
+
+
+def main(argv=None):
+    parser = HfArgumentParser((ModelArguments, DataTrainingArguments, TrainingArguments))
+    model_args, data_args, training_args = parser.parse_args_into_dataclasses(args=argv)
+    logging.basicConfig(format="%(asctime)s - %(levelname)s - %(name)s - %(message)s", level=logging.INFO, handlers=[logging.StreamHandler(sys.stdout)])
+    set_seed(training_args.seed)
+    training_args.remove_unused_columns = False
+
+    gen = MaskGenerator(input_size=data_args.image_size, depth=data_args.depth, mask_patch_size=data_args.mask_patch_size,
+                        model_patch_size=data_args.patch_size, mask_ratio=data_args.mask_ratio)
+    np.random.seed(training_args.seed)
+    train = SyntheticVolumeDataset(data_args.num_train_volumes, data_args.image_size, data_args.depth, gen, data_args.data_seed_offset)
+
+    config = VideoMAEConfig.from_pretrained(model_args.config_name_or_path) if model_args.config_name_or_path else VideoMAEConfig()
+    config.update({"num_channels": 1, "num_frames": data_args.depth, "tubelet_size": data_args.patch_size, "image_size": data_args.image_size,
+                   "patch_size": data_args.patch_size})
+    for k in ("hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size", "decoder_hidden_size",
+              "decoder_num_hidden_layers", "decoder_num_attention_heads", "decoder_intermediate_size"):
+        if getattr(model_args, k) is not None:
+            setattr(config, k, getattr(model_args, k))
+    if model_args.model_name_or_path:
+        model = SmbVideoMAEForPreTraining.from_pretrained(model_args.model_name_or_path, config=config)
+    else:
+        logger.info("Training new model from scratch")
+        model = SmbVideoMAEForPreTraining(config)
+
+    trainer = Trainer(model=model, args=training_args, train_dataset=train, data_collator=collate_fn)
+    result = trainer.train()
+    trainer.save_model()
+    trainer.log_metrics("train", result.metrics)
+    trainer.save_metrics("train", result.metrics)
+    trainer.save_state()
+    return result.metrics
+
+
+if __name__ == "__main__":
+    main()

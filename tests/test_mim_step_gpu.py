@@ -144,3 +144,20 @@ def test_optimizer_step_decreases_loss():
         opt.step()
         losses.append(float(out.loss))
     assert losses[-1] < losses[0] - 0.02, losses
+
+
+def test_hf_trainer_runs_the_drop_in(tmp_path):
+    """The reference's harness shape (src/run_mim.py): HfArgumentParser -> VideoMAEConfig patch -> model -> HF Trainer.train()."""
+    from smb_vision_amd.run_mim import main
+    metrics = main(["--output_dir", str(tmp_path), "--image_size", "64", "--depth", "32", "--patch_size", "16", "--mask_patch_size", "16",
+                    "--mask_ratio", "0.6", "--max_steps", "6", "--per_device_train_batch_size", "2", "--report_to", "none", "--bf16", "true",
+                    "--hidden_size", "128", "--num_hidden_layers", "2", "--num_attention_heads", "2", "--intermediate_size", "256",
+                    "--decoder_hidden_size", "64", "--decoder_num_hidden_layers", "1", "--decoder_num_attention_heads", "1",
+                    "--decoder_intermediate_size", "128", "--learning_rate", "1e-3", "--logging_steps", "1", "--save_strategy", "no",
+                    "--gradient_checkpointing", "true", "--max_grad_norm", "1.0", "--dataloader_num_workers", "0"])
+    assert metrics["train_loss"] > 0 and metrics["train_loss"] < 1.2
+    assert os.path.exists(os.path.join(tmp_path, "model.safetensors"))
+    from transformers import VideoMAEConfig
+    from smb_vision_amd.modeling_videomae import SmbVideoMAEForPreTraining
+    m = SmbVideoMAEForPreTraining.from_pretrained(str(tmp_path))
+    assert m.config.num_frames == 32
