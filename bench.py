@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward only (diagnostic; not the metric)")
+    ap.add_argument("--torch-optimizer", action="store_true", help="clip_grad_norm_ + torch fused AdamW instead of the fused HIP optimizer tail")
     ap.add_argument("--tiny", action="store_true", help="64x64x32 smoke shape (diagnostic; not the metric)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse the N>1 path on one GPU)")
     args = ap.parse_args()
@@ -161,7 +162,13 @@ def main():
                       decoder_hidden_size=64, decoder_num_attention_heads=1, decoder_num_hidden_layers=1, decoder_intermediate_size=256)
     model, pix, mask, n_masked = build(rank, device, cfg_kw)
     params = [p for p in model.parameters()]
-    opt = None if args.no_optimizer else torch.optim.AdamW(params, lr=1.5e-4, betas=(0.9, 0.95), weight_decay=0.05, fused=True)
+    opt = None
+    if not args.no_optimizer:
+        if args.torch_optimizer:
+            opt = torch.optim.AdamW(params, lr=1.5e-4, betas=(0.9, 0.95), weight_decay=0.05, fused=True)
+        else:  # fused global-norm clip + AdamW in libsmbv.so (same arithmetic as clip_grad_norm_ + torch AdamW; tests/test_ops_gpu.py)
+            from smb_vision_amd.optim import SmbvAdamW
+            opt = SmbvAdamW(params, lr=1.5e-4, betas=(0.9, 0.95), weight_decay=0.05, max_grad_norm=1.0)
     dp = None
     if world > 1:
         from smb_vision_amd.dp import DataParallelEngine
@@ -172,7 +179,8 @@ def main():
         out = model(pixel_values=pix, bool_masked_pos=mask, num_masked=n_masked)
         out.loss.backward()
         if opt is not None:
-            torch.nn.utils.clip_grad_norm_(params, 1.0, foreach=True)
+            if args.torch_optimizer:
+                torch.nn.utils.clip_grad_norm_(params, 1.0, foreach=True)
             opt.step()
             opt.zero_grad(set_to_none=True)
         else:

@@ -152,6 +152,29 @@ int smbv_mim_forward(const smbv_mim_cfg* cfg, const smbv_mim_tensors* params, co
 int smbv_mim_backward(const smbv_mim_cfg* cfg, const smbv_mim_tensors* params, const smbv_mim_tensors* grads, const smbv_mim_io* io,
                       void* ws, size_t ws_bytes, void** events, int n_events, smbv_stream stream);
 
+/* ---- fused optimizer tail: clip_grad_norm_ + AdamW as HF Trainer runs them for the reference
+ *      (site-packages/transformers/trainer.py:2539, :1785; --max_grad_norm / adamw_torch of scripts/training/run_mim.sh) ---- */
+
+/* One contiguous piece (<= 2^31 elements; 16-byte aligned pointers) of one parameter tensor. The table lives in DEVICE memory. */
+typedef struct smbv_adam_chunk {
+  float* p; const float* g; float* m; float* v;   /* parameter, gradient, exp_avg, exp_avg_sq */
+  int32_t n;                                     /* elements in this chunk */
+  int32_t group;                                 /* index into smbv_adam_hyper.lr / .weight_decay (parameter group) */
+} smbv_adam_chunk;
+
+typedef struct smbv_adam_hyper {
+  float lr[8], weight_decay[8];
+  float beta1, beta2, eps;
+  float bias_corr1, bias_corr2;                  /* 1 - beta^t, computed by the host */
+  float max_grad_norm;                           /* <= 0: no clipping */
+} smbv_adam_hyper;
+
+/* out_sq[0] = sum over all chunks of g^2 (deterministic two-stage reduction); partial: fp32 [nchunks] scratch. */
+int smbv_grad_sqnorm(const smbv_adam_chunk* chunks_dev, int nchunks, float* partial, float* out_sq, smbv_stream stream);
+/* p, m, v updated in place; the clip coefficient min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) is applied on the fly (g untouched). */
+int smbv_adamw_step(const smbv_adam_chunk* chunks_dev, int nchunks, const smbv_adam_hyper* hyper /* host */, const float* gnorm_sq,
+                    smbv_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,15 @@ class MimIO(C.Structure):
                 ("loss", c_f), ("logits", c_f), ("grad_scale", c_f)]
 
 
+class AdamChunk(C.Structure):
+    _fields_ = [("p", c_f), ("g", c_f), ("m", c_f), ("v", c_f), ("n", C.c_int32), ("group", C.c_int32)]
+
+
+class AdamHyper(C.Structure):
+    _fields_ = [("lr", C.c_float * 8), ("weight_decay", C.c_float * 8), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("bias_corr1", C.c_float), ("bias_corr2", C.c_float), ("max_grad_norm", C.c_float)]
+
+
 _SIGS = {
     "smbv_version": (C.c_int, []),
     "smbv_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
@@ -66,6 +75,8 @@ _SIGS = {
     "smbv_transpose_cast_f32_bf16": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
     "smbv_colsum_bf16": (C.c_int, [c_f, C.c_int, C.c_int, C.c_int, c_f, c_f, C.c_size_t, c_f]),
     "smbv_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "smbv_grad_sqnorm": (C.c_int, [c_f, C.c_int, c_f, c_f, c_f]),
+    "smbv_adamw_step": (C.c_int, [c_f, C.c_int, C.POINTER(AdamHyper), c_f, c_f]),
     "smbv_mim_workspace_bytes": (C.c_size_t, [C.POINTER(MimCfg)]),
     "smbv_mim_forward": (C.c_int, [C.POINTER(MimCfg), C.POINTER(MimTensors), C.POINTER(MimIO), c_f, C.c_size_t, c_f]),
     "smbv_mim_backward": (C.c_int, [C.POINTER(MimCfg), C.POINTER(MimTensors), C.POINTER(MimTensors), C.POINTER(MimIO), c_f, C.c_size_t,

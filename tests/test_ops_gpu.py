@@ -218,3 +218,26 @@ def test_errors_are_loud(ops):
         ops.gemm_nt(A, A)
     with pytest.raises(Exception):
         ops.gemm_nt(A.cpu(), A.cpu())
+
+
+def test_fused_adamw_matches_torch():
+    from smb_vision_amd.optim import SmbvAdamW
+    torch.manual_seed(0)
+    shapes = [(300, 77), (5,), (64, 3, 4, 4), (70001,), (1, 1, 96)]
+    pa = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    groups = lambda ps: [{"params": ps[:2], "weight_decay": 0.05}, {"params": ps[2:], "weight_decay": 0.0, "lr": 3e-3}]
+    oa = SmbvAdamW(groups(pa), lr=1e-2, betas=(0.9, 0.95), eps=1e-8, max_grad_norm=1.0)
+    ob = torch.optim.AdamW(groups(pb), lr=1e-2, betas=(0.9, 0.95), eps=1e-8)
+    for it in range(4):
+        for a, b in zip(pa, pb):
+            g = torch.randn_like(a) * (3.0 if it % 2 == 0 else 0.01)  # exercise both the clipped and the unclipped branch
+            a.grad, b.grad = g.clone(), g.clone()
+        norm = torch.nn.utils.clip_grad_norm_(pb, 1.0)
+        ob.step()
+        oa.step()
+        assert abs(float(oa.last_grad_norm.sqrt()) - float(norm)) <= 1e-5 * float(norm)
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), it
+    sa, sb = oa.state[pa[3]], ob.state[pb[3]]
+    assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-12) and float(sa["step"]) == 4
