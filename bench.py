@@ -85,6 +85,20 @@ def kernel_roofline(device, iters=5):
     return res
 
 
+def cpu_threads():
+    """Host threads for the CPU leg: the cgroup CPU quota when there is one (a 1-GPU box gets a 16-CPU share of a 256-thread
+    host; running 256 threads inside it is 2-3x slower), else the affinity mask, capped at 64."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    env = os.environ.get("SMBV_CPU_THREADS")
+    return int(env) if env else min(n, 64) if n <= 64 else 16
+
+
 def cpu_baseline(threads):
     """Oracle (port) timed on the host: bounded sample, extrapolated (see module docstring)."""
     import oracle.mim_oracle as o
@@ -231,15 +245,20 @@ def main():
         if not args.no_kernel_roofline and not args.tiny:
             kr = kernel_roofline(device)
             dom = kr["attn_dkv_kernel"]
+            traffic = None
+            try:  # PMC-measured fabric bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes), committed under profiles/
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_attn_dkv_traffic.json")))["traffic_bytes_per_launch"]
+            except Exception:
+                pass
             line["roofline"] = {"bound": "mfma", "kernel": "attn_dkv_kernel (decoder, S=20480, H=6, Dh=64)", "achieved": dom["tflops"],
-                                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / MFMA_PEAK_TFLOPS, "traffic": None,
+                                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic,
                                 "launch_ms": dom["ms"], "flop_per_launch": dom["flop"],
                                 "other": {"attn_dq_kernel": {"launch_ms": kr["attn_dq_kernel"]["ms"], "achieved": kr["attn_dq_kernel"]["tflops"]}},
                                 "step": {"achieved": step_tf / world * 1.0 if step_tf else None, "flop_per_volume_T": STEP_TFLOP,
                                          "frac": (step_tf / MFMA_PEAK_TFLOPS) if step_tf else None}}
         if world == 1 and not args.no_cpu_baseline and not args.tiny:
             try:
-                line["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
+                line["cpu_baseline"] = cpu_baseline(cpu_threads())
             except Exception as e:  # the baseline leg must never take the bench line down
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
