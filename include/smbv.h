@@ -71,12 +71,14 @@ int smbv_layernorm_bwd(const smbv_bf16* dy, const float* x, const float* mean, c
 size_t smbv_layernorm_bwd_workspace_bytes(int rows, int D);
 
 /* softmax_fp32(Q K^T * scale) V, head_dim 64 (spec :196-223, dispatched at :270-289).  Q,K,V: column slices of one
- * token-major [B*S, ld] matrix (head h at columns h*64..); O: [B*S, ldo]; LSE/delta: fp32 [B,H,S]. */
+ * token-major [B*S, ld] matrix (head h at columns h*64..); O: [B*S, ldo]; LSE/delta: fp32 [B,H,Sq].
+ * Sq/q_off: only the queries q_off .. q_off+Sq-1 of every sequence are computed (keys/values: all S); Sq <= 0 means all.
+ * (The last decoder block only needs its masked tokens' outputs: spec :717-718 keeps hidden_states[:, -return_token_num:].) */
 int smbv_attention_fwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, smbv_bf16* O, int ldo, float* LSE,
-                       int B, int S, int H, int Dh, float scale, smbv_stream stream);
+                       int B, int S, int H, int Dh, float scale, int Sq, int q_off, smbv_stream stream);
 int smbv_attention_bwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* dO,
                        int ldo, const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S,
-                       int H, int Dh, float scale, int parts /* bit0 delta, bit1 dK/dV, bit2 dQ; 7 = all */, smbv_stream stream);
+                       int H, int Dh, float scale, int parts /* bit0 delta, bit1 dK/dV, bit2 dQ; 7 = all */, int Sq, int q_off, smbv_stream stream);
 
 /* Brick readers over pixel_values fp32 [B,T,1,H,W] (spec :172-177,190-191 Conv3d patchify; :835-867 labels; :896-897 MSE).
  * idx: int32 token ids (0..N-1) of the selected bricks, `per_batch` per volume, rows = B*per_batch. */

@@ -34,15 +34,16 @@ __device__ __forceinline__ bf16x8 scale_frag(u32x4 v, float c) {
 }
 
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO, int ldo,
-                                                         float* __restrict__ delta, int B, int S, int H) {
+                                                         float* __restrict__ delta, int B, int S, int Sq, int qoff, int H) {
   // 8 lanes per (row, head): 16 B each
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   const long pair = gid >> 3;
   const int sub = gid & 7;
-  const long total = (long)B * S * H;
+  const long total = (long)B * Sq * H;
   float acc = 0.f;
   if (pair < total) {
-    const long row = pair / H;
+    const long rq = pair / H;
+    const long row = (rq / Sq) * S + qoff + (rq % Sq);
     const int head = pair % H;
     const u32x4 o = *(const u32x4*)(O + row * ldo + head * 64 + sub * 8);
     const u32x4 g = *(const u32x4*)(dO + row * ldo + head * 64 + sub * 8);
@@ -53,10 +54,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   acc += __shfl_xor(acc, 2, 64);
   acc += __shfl_xor(acc, 4, 64);
   if (pair < total && sub == 0) {
-    const long row = pair / H;
+    const long rq = pair / H;
     const int head = pair % H;
-    const long b = row / S, s = row % S;
-    delta[(b * H + head) * S + s] = acc;
+    const long b = rq / Sq, s = rq % Sq;
+    delta[(b * H + head) * Sq + s] = acc;
   }
 }
 
@@ -64,8 +65,8 @@ template <int MINW, int QT>
 __global__ __launch_bounds__(256, MINW) void attn_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO,
                                                        int ldo, const float* __restrict__ LSE, const float* __restrict__ delta,
-                                                       bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int ldd, int S, int H,
-                                                       float scale) {
+                                                       bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int ldd, int S, int Sq, int qoff,
+                                                       int H, float scale) {
   // One iteration = 64 queries (two 32-row sub-tiles): half the barriers and twice the work per global-load round trip of
   // a 32-query iteration (the kernel was parked in waits 55 % of its wave-cycles).
   // LDS per buffer: Q [64][128 B] 8 KiB | dO 8 KiB | -lse*log2e [64] f32 | -delta [64] f32
@@ -79,8 +80,8 @@ __global__ __launch_bounds__(256, MINW) void attn_dkv_kernel(const bf16_t* __res
   const int key = blockIdx.x * 128 + w * 32 + r;
   const int hoff = head * 64;
   const float c = scale * 1.4426950408889634f;
-  const float* lse_p = LSE + ((size_t)b * H + head) * S;
-  const float* del_p = delta + ((size_t)b * H + head) * S;
+  const float* lse_p = LSE + ((size_t)b * H + head) * Sq;
+  const float* del_p = delta + ((size_t)b * H + head) * Sq;
 
   bf16x8 kf[4], vf[4];
 #pragma unroll
@@ -104,12 +105,12 @@ __global__ __launch_bounds__(256, MINW) void attn_dkv_kernel(const bf16_t* __res
 #pragma unroll
     for (int i = 0; i < NS; i++) {
       const int id = t + 256 * i, row = id >> 3, ch = id & 7;
-      const bool ok = (q0 + row) < S;
-      rq[i] = ok ? *(const u32x4*)(Q + (row0 + q0 + row) * ld + hoff + ch * 8) : (u32x4){0, 0, 0, 0};
-      rdo[i] = ok ? *(const u32x4*)(dO + (row0 + q0 + row) * ldo + hoff + ch * 8) : (u32x4){0, 0, 0, 0};
+      const bool ok = (q0 + row) < Sq;
+      rq[i] = ok ? *(const u32x4*)(Q + (row0 + qoff + q0 + row) * ld + hoff + ch * 8) : (u32x4){0, 0, 0, 0};
+      rdo[i] = ok ? *(const u32x4*)(dO + (row0 + qoff + q0 + row) * ldo + hoff + ch * 8) : (u32x4){0, 0, 0, 0};
     }
-    if (t < QT) rstat = (q0 + t < S) ? -lse_p[q0 + t] * 1.4426950408889634f : -INFINITY;  // padded rows: p = exp2(-inf) = 0
-    else if (t < 2 * QT) rstat = (q0 + t - QT < S) ? -del_p[q0 + t - QT] : 0.f;
+    if (t < QT) rstat = (q0 + t < Sq) ? -lse_p[q0 + t] * 1.4426950408889634f : -INFINITY;  // padded rows: p = exp2(-inf) = 0
+    else if (t < 2 * QT) rstat = (q0 + t - QT < Sq) ? -del_p[q0 + t - QT] : 0.f;
   };
   auto lstore = [&](int buf) {
     unsigned char* s = smem + buf * BUF;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256, MINW) void attn_dkv_kernel(const bf16_t* __res
     }
   };
 
-  const int nq = (S + QT - 1) / QT;
+  const int nq = (Sq + QT - 1) / QT;
   gload(0);
   lstore(0);
   __syncthreads();
@@ -204,7 +205,7 @@ template <int MINW, int KT>
 __global__ __launch_bounds__(256, MINW) void attn_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                       const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO, int ldo,
                                                       const float* __restrict__ LSE, const float* __restrict__ delta,
-                                                      bf16_t* __restrict__ dQ, int ldd, int S, int H, float scale) {
+                                                      bf16_t* __restrict__ dQ, int ldd, int S, int Sq, int qoff, int H, float scale) {
   constexpr int NL = KT / 32;  // 16-B chunks per thread per operand per tile
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * KT * 128];  // [buf][K|V][KT keys][128 B]
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
@@ -219,17 +220,17 @@ __global__ __launch_bounds__(256, MINW) void attn_dq_kernel(const bf16_t* __rest
 #pragma unroll
   for (int ks = 0; ks < 4; ks++) {
     u32x4 a = {0, 0, 0, 0}, bb = {0, 0, 0, 0};
-    if (q < S) {
-      a = *(const u32x4*)(Q + (row0 + q) * ld + hoff + 16 * ks + 8 * h2);
-      bb = *(const u32x4*)(dO + (row0 + q) * ldo + hoff + 16 * ks + 8 * h2);
+    if (q < Sq) {
+      a = *(const u32x4*)(Q + (row0 + qoff + q) * ld + hoff + 16 * ks + 8 * h2);
+      bb = *(const u32x4*)(dO + (row0 + qoff + q) * ldo + hoff + 16 * ks + 8 * h2);
     }
     qf[ks] = scale_frag(a, c);  // scores leave the MFMA in the exp2 domain
     dof[ks] = __builtin_bit_cast(bf16x8, bb);
   }
   float nlse2 = -INFINITY, ndl = 0.f;  // padded queries: p = exp2(-inf) = 0
-  if (q < S) {
-    nlse2 = -LSE[((size_t)b * H + head) * S + q] * 1.4426950408889634f;
-    ndl = -delta[((size_t)b * H + head) * S + q];
+  if (q < Sq) {
+    nlse2 = -LSE[((size_t)b * H + head) * Sq + q] * 1.4426950408889634f;
+    ndl = -delta[((size_t)b * H + head) * Sq + q];
   }
   f32x16 sinit, dinit;  // persistent C inputs: S'^T = c*k.q - lse*log2e, dP'^T = v.dO - delta
 #pragma unroll
@@ -319,8 +320,8 @@ __global__ __launch_bounds__(256, MINW) void attn_dq_kernel(const bf16_t* __rest
     __syncthreads();
   }
 
-  if (q < S) {
-    bf16_t* qp = dQ + (row0 + q) * ldd + hoff;
+  if (q < Sq) {
+    bf16_t* qp = dQ + (row0 + qoff + q) * ldd + hoff;
 #pragma unroll
     for (int dt = 0; dt < 2; dt++)
 #pragma unroll
@@ -333,19 +334,21 @@ __global__ __launch_bounds__(256, MINW) void attn_dq_kernel(const bf16_t* __rest
 }
 
 int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
-                  float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, hipStream_t st) {
+                  float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st) {
+  if (Sq <= 0) { Sq = S; qoff = 0; }
+  if (qoff < 0 || qoff + Sq > S) { set_error("attention_bwd: query range outside the sequence"); return SMBV_ERR_SHAPE; }
   if (Dh != 64) { set_error("attention_bwd: head_dim %d not supported (only 64)", Dh); return SMBV_ERR_SHAPE; }
   if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 7) || (ldd & 3)) { set_error("attention_bwd: bad shape"); return SMBV_ERR_SHAPE; }
   if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)dO) & 15) || (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 7)) { set_error("attention_bwd: alignment"); return SMBV_ERR_ALIGN; }
-  const long pairs = (long)B * S * H;
+  const long pairs = (long)B * Sq * H;
   int rc = SMBV_OK;
   if (parts & 1) {
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(pairs * 8, 256)), dim3(256), 0, st, O, dO, ldo, delta, B, S, H);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(pairs * 8, 256)), dim3(256), 0, st, O, dO, ldo, delta, B, S, Sq, qoff, H);
     rc = check_launch("attn_delta");
     if (rc) return rc;
   }
   if (parts & 2) {
-#define DKV(W, QT) hipLaunchKernelGGL((attn_dkv_kernel<W, QT>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, H, scale)
+#define DKV(W, QT) hipLaunchKernelGGL((attn_dkv_kernel<W, QT>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale)
     // measured (tools/attn_ab.py): 128-query iterations at 2 waves/SIMD beat 64/32-query ones and the 3-wave build on both shapes
     if (g_variant & 4) DKV(3, 32);
     else if (g_variant & 256) DKV(2, 64);
@@ -355,7 +358,7 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     if (rc) return rc;
   }
   if (parts & 4) {
-#define DQ(W, KT) hipLaunchKernelGGL((attn_dq_kernel<W, KT>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, H, scale)
+#define DQ(W, KT) hipLaunchKernelGGL((attn_dq_kernel<W, KT>), dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale)
     if (g_variant & 512) DQ(2, 64);
     else DQ(2, 128);
 #undef DQ

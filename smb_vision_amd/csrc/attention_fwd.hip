@@ -41,7 +41,7 @@ __device__ __forceinline__ bf16x8 scale_bf16x8(u32x4 v, float c) {
 template <int MINW>
 __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                           const bf16_t* __restrict__ V, int ld, bf16_t* __restrict__ O, int ldo,
-                                                          float* __restrict__ LSE, int S, int H, float scale) {
+                                                          float* __restrict__ LSE, int S, int Sq, int qoff, int H, float scale) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 64 * 128];  // [buf][K|V][64 keys][128 B]
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int r = l & 31, h2 = l >> 5;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __res
 #pragma unroll
   for (int ks = 0; ks < 4; ks++) {
     u32x4 v = {0, 0, 0, 0};
-    if (q < S) v = *(const u32x4*)(Q + (row0 + q) * ld + hoff + 16 * ks + 8 * h2);
+    if (q < Sq) v = *(const u32x4*)(Q + (row0 + qoff + q) * ld + hoff + 16 * ks + 8 * h2);
     qf[ks] = scale_bf16x8(v, c);
   }
 
@@ -172,8 +172,8 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __res
 
   const float l_tot = l_i + __shfl_xor(l_i, 32, 64);
   const float inv = 1.0f / l_tot;
-  if (q < S) {
-    bf16_t* op = O + (row0 + q) * ldo + hoff;
+  if (q < Sq) {
+    bf16_t* op = O + (row0 + qoff + q) * ldo + hoff;
 #pragma unroll
     for (int dt = 0; dt < 2; dt++)
 #pragma unroll
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __res
         *(u32x2*)(op + d0) = pk;
       }
     // natural-log LSE of the scaled scores: (m2 + log2(l)) / log2(e)
-    if (h2 == 0) LSE[((size_t)b * H + head) * S + q] = (m2 + __log2f(l_tot)) * 0.6931471805599453f;
+    if (h2 == 0) LSE[((size_t)b * H + head) * Sq + q] = (m2 + __log2f(l_tot)) * 0.6931471805599453f;
   }
 }
 
@@ -194,13 +194,15 @@ int g_variant = 0;  // tuning / A-B hook (tools/attn_ab.py): bit1 force 3 waves/
 bool attn_prefer_3waves(long blocks) { return cdiv(blocks, 768) < cdiv(blocks, 512); }
 
 int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf16_t* O, int ldo, float* LSE, int B, int S, int H, int Dh,
-                  float scale, hipStream_t st) {
+                  float scale, int Sq, int qoff, hipStream_t st) {
+  if (Sq <= 0) { Sq = S; qoff = 0; }
+  if (qoff < 0 || qoff + Sq > S) { set_error("attention_fwd: query range [%d, %d) outside the sequence (%d)", qoff, qoff + Sq, S); return SMBV_ERR_SHAPE; }
   if (Dh != 64) { set_error("attention_fwd: head_dim %d not supported (only 64)", Dh); return SMBV_ERR_SHAPE; }
   if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 3)) { set_error("attention_fwd: bad shape B=%d S=%d H=%d ld=%d ldo=%d", B, S, H, ld, ldo); return SMBV_ERR_SHAPE; }
   if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || ((uintptr_t)O & 7)) { set_error("attention_fwd: alignment"); return SMBV_ERR_ALIGN; }
-  const bool w3 = (g_variant & 2) || (!(g_variant & 16) && attn_prefer_3waves((long)cdiv(S, 128) * H * B));
-  if (w3) hipLaunchKernelGGL(attn_fwd_kernel<3>, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, H, scale);
-  else hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, H, scale);
+  const bool w3 = (g_variant & 2) || (!(g_variant & 16) && attn_prefer_3waves((long)cdiv(Sq, 128) * H * B));
+  if (w3) hipLaunchKernelGGL(attn_fwd_kernel<3>, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale);
+  else hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale);
   return check_launch("attention_fwd");
 }
 

@@ -82,15 +82,15 @@ int smbv_layernorm_bwd(const smbv_bf16* dy, const float* x, const float* mean, c
 size_t smbv_layernorm_bwd_workspace_bytes(int rows, int D) { return layernorm_bwd_workspace_bytes(rows, D); }
 
 int smbv_attention_fwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, smbv_bf16* O, int ldo, float* LSE, int B, int S, int H,
-                       int Dh, float scale, smbv_stream stream) {
+                       int Dh, float scale, int Sq, int q_off, smbv_stream stream) {
   if (!Q || !K || !V || !O || !LSE) { set_error("smbv_attention_fwd: null operand"); return SMBV_ERR_ARG; }
-  return attention_fwd(Q, K, V, ld, O, ldo, LSE, B, S, H, Dh, scale, (hipStream_t)stream);
+  return attention_fwd(Q, K, V, ld, O, ldo, LSE, B, S, H, Dh, scale, Sq, q_off, (hipStream_t)stream);
 }
 int smbv_attention_bwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* dO, int ldo,
                        const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S, int H, int Dh, float scale,
-                       int parts, smbv_stream stream) {
+                       int parts, int Sq, int q_off, smbv_stream stream) {
   if (!Q || !K || !V || !O || !dO || !LSE || !delta || !dQ || !dK || !dV) { set_error("smbv_attention_bwd: null operand"); return SMBV_ERR_ARG; }
-  return attention_bwd(Q, K, V, ld, O, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, H, Dh, scale, parts, (hipStream_t)stream);
+  return attention_bwd(Q, K, V, ld, O, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, H, Dh, scale, parts, Sq, q_off, (hipStream_t)stream);
 }
 
 int smbv_gather_bricks(const float* pix, const int32_t* idx, int rows, int per_batch, smbv_bf16* out, int T, int H, int W, int ts, int ps, smbv_stream stream) {

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
     size_t orow = (size_t)m;
     if (e.grp_in > 0) orow = (size_t)(m / e.grp_in) * e.grp_out + (m % e.grp_in);
     const float* radd = nullptr;
-    if (e.rowadd) radd = e.rowadd + (size_t)(e.rowidx ? e.rowidx[m] : m) * e.ldr;
+    if (e.rowadd) radd = e.rowadd + (size_t)(e.rowidx ? e.rowidx[m] : (e.radd_grp_in > 0 ? (m / e.radd_grp_in) * e.radd_grp_out + m % e.radd_grp_in + e.radd_off : m)) * e.ldr;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int n = n0 + wn * 64 + j * 16 + 4 * (l >> 4);
@@ -177,7 +177,7 @@ __device__ __forceinline__ void epilogue_nt_lds(f32x4 (&acc)[4][4], unsigned cha
         v0 = v0 * e.alpha + b0;
         v1 = v1 * e.alpha + b1;
         if (e.rowadd) {
-          const float* radd = e.rowadd + (size_t)(e.rowidx ? e.rowidx[m] : m) * e.ldr + n;
+          const float* radd = e.rowadd + (size_t)(e.rowidx ? e.rowidx[m] : (e.radd_grp_in > 0 ? (m / e.radd_grp_in) * e.radd_grp_out + m % e.radd_grp_in + e.radd_off : m)) * e.ldr + n;
           v0 += *(const f32x4*)radd;
           v1 += *(const f32x4*)(radd + 4);
         }

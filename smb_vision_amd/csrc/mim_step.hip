@@ -30,7 +30,7 @@ struct MimWs {
   float *meanf, *rstdf, *bmean, *brinv, *row_partial;
   // backward scratch
   float *g0, *g1, *delta;
-  bf16_t *gb0, *gb1, *dlogits, *d_act, *d_ln, *d_o, *d_qkv, *d_vis;
+  bf16_t *gb0, *gb1, *dlogits, *d_act, *d_ln, *d_o, *d_qkv, *d_vis, *gath0, *gath1;
   void* scratch;  // gemm_tn slabs / ln-bwd partials / colsum partials (max of all uses)
   size_t scratch_bytes;
   size_t total;
@@ -118,6 +118,8 @@ static void carve(const smbv_mim_cfg& c, void* base, MimWs& w) {
   w.d_o = cv.take<bf16_t>(gw);
   w.d_qkv = cv.take<bf16_t>(3 * gw);
   w.d_vis = cv.take<bf16_t>(R * c.dd);
+  w.gath0 = cv.take<bf16_t>(Rm * c.dd);
+  w.gath1 = cv.take<bf16_t>(Rm * c.dd);
   size_t sb = 0;
   auto tn = [&](size_t M, int n1, int n2) { sb = std::max(sb, gemm_tn_workspace_bytes((int)M, n1, n2)); };
   tn(R, c.d, c.ff); tn(R, c.ff, c.d); tn(R, c.d, c.d); tn(R, 3 * c.d, c.d); tn(R, c.d, K); tn(R, c.dd, c.d);
@@ -153,14 +155,45 @@ static int prep_layer(const smbv_layer_ptrs& p, LayerWs& L, int w, int ff, hipSt
 }
 
 // one pre-LN block forward (spec :405-431) over `rows` = B*S tokens of width w
+// Sq > 0: only the tokens qoff..qoff+Sq-1 of every sequence are needed downstream (last decoder block: spec :717-718 keeps the
+// last N_mask tokens).  LN1/QKV still run on all tokens (every token is a key/value); attention queries, the output projection
+// and the MLP run on the Sq tokens only.  x_mid / x_out keep the full [B*S, w] layout (rows outside the range are not written);
+// ln2 / pre / act are compact [B*Sq, .].
 static int layer_fwd(const smbv_layer_ptrs& p, LayerWs& L, const float* x_in, float* x_out, bf16_t* x_out_bf16, size_t rows, int w, int ff,
-                     int B, int S, int H, float eps, hipStream_t st) {
+                     int B, int S, int H, float eps, MimWs& W, int Sq, int qoff, hipStream_t st) {
+  if (Sq > 0) {
+    const int Mq = B * Sq;
+    RC(layernorm_fwd(x_in, p.ln1_w, p.ln1_b, L.ln1, L.mean1, L.rstd1, (int)rows, w, eps, 0, 0, 0, st));
+    {
+      GemmEpi e; e.bias = L.bqkv; e.out_bf16 = L.qkv; e.ld_ob = 3 * w;
+      RC(gemm_nt(L.ln1, w, L.wqkv, w, (int)rows, 3 * w, w, e, st));
+    }
+    RC(attention_fwd(L.qkv, L.qkv + w, L.qkv + 2 * w, 3 * w, L.attn_o, w, L.lse, B, S, H, 64, 0.125f, Sq, qoff, st));
+    const bf16_t* a_rows = L.attn_o + (size_t)qoff * w;  // contiguous for B == 1
+    if (B > 1) { RC(gather_rows_bf16(L.attn_o, W.gath0, Mq, w, Sq, S, qoff, st)); a_rows = W.gath0; }
+    {
+      GemmEpi e; e.bias = p.proj_b; e.rowadd = x_in; e.ldr = w; e.radd_grp_in = Sq; e.radd_grp_out = S; e.radd_off = qoff;
+      e.out_f32 = L.x_mid + (size_t)qoff * w; e.ld_of = w; e.grp_in = Sq; e.grp_out = S;
+      RC(gemm_nt(a_rows, w, L.proj, w, Mq, w, w, e, st));
+    }
+    RC(layernorm_fwd(L.x_mid, p.ln2_w, p.ln2_b, L.ln2, L.mean2, L.rstd2, Mq, w, eps, Sq, S, qoff, st));
+    {
+      GemmEpi e; e.bias = p.fc1_b; e.act_gelu = 1; e.aux_pre = L.pre; e.ld_aux = ff; e.out_bf16 = L.act; e.ld_ob = ff;
+      RC(gemm_nt(L.ln2, w, L.fc1, w, Mq, ff, w, e, st));
+    }
+    {
+      GemmEpi e; e.bias = p.fc2_b; e.rowadd = L.x_mid; e.ldr = w; e.radd_grp_in = Sq; e.radd_grp_out = S; e.radd_off = qoff;
+      e.out_f32 = x_out + (size_t)qoff * w; e.ld_of = w; e.grp_in = Sq; e.grp_out = S;
+      RC(gemm_nt(L.act, ff, L.fc2, ff, Mq, w, ff, e, st));
+    }
+    return SMBV_OK;
+  }
   RC(layernorm_fwd(x_in, p.ln1_w, p.ln1_b, L.ln1, L.mean1, L.rstd1, (int)rows, w, eps, 0, 0, 0, st));
   {
     GemmEpi e; e.bias = L.bqkv; e.out_bf16 = L.qkv; e.ld_ob = 3 * w;
     RC(gemm_nt(L.ln1, w, L.wqkv, w, (int)rows, 3 * w, w, e, st));
   }
-  RC(attention_fwd(L.qkv, L.qkv + w, L.qkv + 2 * w, 3 * w, L.attn_o, w, L.lse, B, S, H, 64, 0.125f, st));
+  RC(attention_fwd(L.qkv, L.qkv + w, L.qkv + 2 * w, 3 * w, L.attn_o, w, L.lse, B, S, H, 64, 0.125f, 0, 0, st));
   {
     GemmEpi e; e.bias = p.proj_b; e.rowadd = x_in; e.ldr = w; e.out_f32 = L.x_mid; e.ld_of = w;
     RC(gemm_nt(L.attn_o, w, L.proj, w, (int)rows, w, w, e, st));
@@ -179,6 +212,69 @@ static int layer_fwd(const smbv_layer_ptrs& p, LayerWs& L, const float* x_in, fl
 
 // backward of one block. in: g (fp32) / gb (bf16) = grad wrt the block output; out: same pair overwritten with the grad
 // wrt the block input. g2/gb2 are the ping-pong partners.
+// backward of a block whose forward ran with a query range (see layer_fwd): g/gb hold the gradient of the Sq tokens in the full
+// layout (zeros elsewhere); ln2/pre/act are compact.
+static int layer_bwd_ranged(const smbv_layer_ptrs& p, const smbv_layer_ptrs& gr, LayerWs& L, MimWs& W, const float* x_in, float* g, bf16_t* gb,
+                            float* g2, bf16_t* gb2, size_t rows, int w, int ff, int B, int S, int H, int Sq, int qoff, hipStream_t st) {
+  const int M = (int)rows, Mq = B * Sq;
+  const bf16_t* gbc = gb + (size_t)qoff * w;  // compact view of the ranged rows (contiguous for B == 1)
+  if (B > 1) { RC(gather_rows_bf16(gb, W.gath0, Mq, w, Sq, S, qoff, st)); gbc = W.gath0; }
+  // FC2
+  RC(colsum_bf16(gbc, w, Mq, w, gr.fc2_b, 0, 0, 0, W.scratch, W.scratch_bytes, st));
+  RC(gemm_tn(gbc, w, L.act, ff, Mq, w, ff, gr.fc2_w, W.scratch, W.scratch_bytes, st));
+  {
+    GemmEpi e; e.dgelu_pre = L.pre; e.ld_pre = ff; e.out_bf16 = W.d_act; e.ld_ob = ff;
+    RC(gemm_nt(gbc, w, L.fc2_t, w, Mq, ff, w, e, st));
+  }
+  // FC1
+  RC(colsum_bf16(W.d_act, ff, Mq, ff, gr.fc1_b, 0, 0, 0, W.scratch, W.scratch_bytes, st));
+  RC(gemm_tn(W.d_act, ff, L.ln2, w, Mq, ff, w, gr.fc1_w, W.scratch, W.scratch_bytes, st));
+  {
+    GemmEpi e; e.out_bf16 = W.d_ln; e.ld_ob = w;
+    RC(gemm_nt(W.d_act, ff, L.fc1_t, ff, Mq, w, ff, e, st));
+  }
+  // LN2 (+ residual) on the ranged rows; every other row of g2 is zero
+  HIPRC(hipMemsetAsync(g2, 0, rows * w * sizeof(float), st));
+  HIPRC(hipMemsetAsync(gb2, 0, rows * w * sizeof(bf16_t), st));
+  RC(layernorm_bwd(W.d_ln, L.x_mid, L.mean2, L.rstd2, p.ln2_w, g, g2, gb2, gr.ln2_w, gr.ln2_b, Mq, w, Sq, S, qoff, W.scratch, W.scratch_bytes, st));
+  // attention output projection
+  const bf16_t* g2c = gb2 + (size_t)qoff * w;
+  const bf16_t* aoc = L.attn_o + (size_t)qoff * w;
+  if (B > 1) {
+    RC(gather_rows_bf16(gb2, W.gath0, Mq, w, Sq, S, qoff, st));
+    RC(gather_rows_bf16(L.attn_o, W.gath1, Mq, w, Sq, S, qoff, st));
+    g2c = W.gath0; aoc = W.gath1;
+  }
+  RC(colsum_bf16(g2c, w, Mq, w, gr.proj_b, 0, 0, 0, W.scratch, W.scratch_bytes, st));
+  RC(gemm_tn(g2c, w, aoc, w, Mq, w, w, gr.proj_w, W.scratch, W.scratch_bytes, st));
+  {
+    GemmEpi e; e.out_bf16 = W.d_o + (size_t)qoff * w; e.ld_ob = w; e.grp_in = Sq; e.grp_out = S;
+    RC(gemm_nt(g2c, w, L.proj_t, w, Mq, w, w, e, st));
+  }
+  // attention: dQ only exists for the ranged queries (zero elsewhere); dK/dV for every token
+  HIPRC(hipMemsetAsync(W.d_qkv, 0, rows * 3 * w * sizeof(bf16_t), st));
+  RC(attention_bwd(L.qkv, L.qkv + w, L.qkv + 2 * w, 3 * w, L.attn_o, W.d_o, w, L.lse, W.delta, W.d_qkv, W.d_qkv + w, W.d_qkv + 2 * w, 3 * w, B, S,
+                   H, 64, 0.125f, 7, Sq, qoff, st));
+  // QKV
+  RC(colsum_bf16(W.d_qkv, 3 * w, M, w, gr.q_b, 0, 0, 0, W.scratch, W.scratch_bytes, st));
+  RC(colsum_bf16(W.d_qkv + 2 * w, 3 * w, M, w, gr.v_b, 0, 0, 0, W.scratch, W.scratch_bytes, st));
+  const size_t ww = (size_t)w * w;
+  if (gr.k_w == gr.q_w + ww && gr.v_w == gr.k_w + ww) {
+    RC(gemm_tn(W.d_qkv, 3 * w, L.ln1, w, M, 3 * w, w, gr.q_w, W.scratch, W.scratch_bytes, st));
+  } else {
+    RC(gemm_tn(W.d_qkv, 3 * w, L.ln1, w, M, w, w, gr.q_w, W.scratch, W.scratch_bytes, st));
+    RC(gemm_tn(W.d_qkv + w, 3 * w, L.ln1, w, M, w, w, gr.k_w, W.scratch, W.scratch_bytes, st));
+    RC(gemm_tn(W.d_qkv + 2 * w, 3 * w, L.ln1, w, M, w, w, gr.v_w, W.scratch, W.scratch_bytes, st));
+  }
+  {
+    GemmEpi e; e.out_bf16 = W.d_ln; e.ld_ob = w;
+    RC(gemm_nt(W.d_qkv, 3 * w, L.wqkv_t, 3 * w, M, w, 3 * w, e, st));
+  }
+  // LN1 (+ residual) over all rows: g = g2 + LNbwd(d_ln)
+  RC(layernorm_bwd(W.d_ln, x_in, L.mean1, L.rstd1, p.ln1_w, g2, g, gb, gr.ln1_w, gr.ln1_b, M, w, 0, 0, 0, W.scratch, W.scratch_bytes, st));
+  return SMBV_OK;
+}
+
 static int layer_bwd(const smbv_layer_ptrs& p, const smbv_layer_ptrs& gr, LayerWs& L, MimWs& W, const float* x_in, float* g, bf16_t* gb,
                      float* g2, bf16_t* gb2, size_t rows, int w, int ff, int B, int S, int H, hipStream_t st) {
   const int M = (int)rows;
@@ -207,7 +303,7 @@ static int layer_bwd(const smbv_layer_ptrs& p, const smbv_layer_ptrs& gr, LayerW
   }
   // attention
   RC(attention_bwd(L.qkv, L.qkv + w, L.qkv + 2 * w, 3 * w, L.attn_o, W.d_o, w, L.lse, W.delta, W.d_qkv, W.d_qkv + w, W.d_qkv + 2 * w, 3 * w, B, S,
-                   H, 64, 0.125f, 7, st));
+                   H, 64, 0.125f, 7, 0, 0, st));
   // QKV
   RC(colsum_bf16(W.d_qkv, 3 * w, M, w, gr.q_b, 0, 0, 0, W.scratch, W.scratch_bytes, st));
   RC(colsum_bf16(W.d_qkv + 2 * w, 3 * w, M, w, gr.v_b, 0, 0, 0, W.scratch, W.scratch_bytes, st));
@@ -253,7 +349,7 @@ static int mim_forward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const s
     RC(gemm_nt(W.a_patch, K, W.pe_w, K, (int)R, c.d, K, e, st));
   }
   for (int l = 0; l < c.layers; l++)
-    RC(layer_fwd(p.enc[l], W.enc[l], W.x[l], W.x[l + 1], l == c.layers - 1 ? W.enc_out : nullptr, R, c.d, c.ff, c.B, c.Nvis, c.heads, c.ln_eps, st));
+    RC(layer_fwd(p.enc[l], W.enc[l], W.x[l], W.x[l + 1], l == c.layers - 1 ? W.enc_out : nullptr, R, c.d, c.ff, c.B, c.Nvis, c.heads, c.ln_eps, W, 0, 0, st));
   // encoder_to_decoder + decoder input assembly: [visible + pos_vis, mask_token + pos_mask] (spec :801-815)
   {
     GemmEpi e; e.rowadd = io.pos_dec; e.rowidx = io.vis_idx; e.ldr = c.dd; e.out_f32 = W.xd[0]; e.ld_of = c.dd; e.grp_in = c.Nvis; e.grp_out = c.N;
@@ -261,7 +357,8 @@ static int mim_forward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const s
   }
   RC(fill_mask_rows(W.xd[0], p.mask_token, io.pos_dec, io.mask_idx, c.B, c.Nmask, c.Nvis, c.dd, st));
   for (int l = 0; l < c.dlayers; l++)
-    RC(layer_fwd(p.dec[l], W.dec[l], W.xd[l], W.xd[l + 1], nullptr, Rd, c.dd, c.dff, c.B, c.N, c.dheads, c.ln_eps, st));
+    RC(layer_fwd(p.dec[l], W.dec[l], W.xd[l], W.xd[l + 1], nullptr, Rd, c.dd, c.dff, c.B, c.N, c.dheads, c.ln_eps, W,
+                 l == c.dlayers - 1 ? c.Nmask : 0, l == c.dlayers - 1 ? c.Nvis : 0, st));
   // last N_mask tokens -> decoder.norm -> head (spec :717-722)
   RC(layernorm_fwd(W.xd[c.dlayers], p.dnorm_w, p.dnorm_b, W.lnf, W.meanf, W.rstdf, (int)Rm, c.dd, c.dec_norm_eps, c.Nmask, c.N, c.Nvis, st));
   {
@@ -306,7 +403,10 @@ static int mim_backward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const 
                    c.Nvis, W.scratch, W.scratch_bytes, st));
   RC(mark());
   for (int l = c.dlayers - 1; l >= 0; l--) {
-    RC(layer_bwd(p.dec[l], gr.dec[l], W.dec[l], W, W.xd[l], W.g0, W.gb0, W.g1, W.gb1, Rd, c.dd, c.dff, c.B, c.N, c.dheads, st));
+    if (l == c.dlayers - 1)
+      RC(layer_bwd_ranged(p.dec[l], gr.dec[l], W.dec[l], W, W.xd[l], W.g0, W.gb0, W.g1, W.gb1, Rd, c.dd, c.dff, c.B, c.N, c.dheads, c.Nmask, c.Nvis, st));
+    else
+      RC(layer_bwd(p.dec[l], gr.dec[l], W.dec[l], W, W.xd[l], W.g0, W.gb0, W.g1, W.gb1, Rd, c.dd, c.dff, c.B, c.N, c.dheads, st));
     RC(mark());
   }
   // decoder input: mask_token gradient = sum over masked rows; visible rows flow into encoder_to_decoder

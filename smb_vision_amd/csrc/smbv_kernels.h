@@ -14,6 +14,7 @@ struct GemmEpi {
   const float* rowadd = nullptr;    // + rowadd[(rowidx ? rowidx[m] : m) * ldr + n]   (residual stream / position table)
   const int* rowidx = nullptr;
   int ldr = 0;
+  int radd_grp_in = 0, radd_grp_out = 0, radd_off = 0;  // rowadd row remap when rowidx == null: (m / in) * out + m % in + off
   const bf16_t* dgelu_pre = nullptr;  // *= gelu'(dgelu_pre[m * ld_pre + n])          (dgrad through GELU)
   int ld_pre = 0;
   int act_gelu = 0;                 // exact-erf GELU; when aux_pre != null the bf16 pre-activation is stored there
@@ -38,9 +39,9 @@ int layernorm_bwd(const bf16_t* dy, const float* x, const float* mean, const flo
 size_t layernorm_bwd_workspace_bytes(int rows, int D);
 
 int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf16_t* O, int ldo, float* LSE, int B, int S, int H, int Dh,
-                  float scale, hipStream_t st);
+                  float scale, int Sq, int qoff, hipStream_t st);
 int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
-                  float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, hipStream_t st);
+                  float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st);
 
 int gather_bricks(const float* pix, const int* idx, int rows, int per_batch, bf16_t* out, int T, int H, int W, int ts, int ps, hipStream_t st);
 int brick_stats(const float* pix, const int* idx, int rows, int per_batch, float* mean, float* rinv, int T, int H, int W, int ts, int ps,

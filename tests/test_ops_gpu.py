@@ -241,3 +241,27 @@ def test_fused_adamw_matches_torch():
             assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), it
     sa, sb = oa.state[pa[3]], ob.state[pb[3]]
     assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-12) and float(sa["step"]) == 4
+
+
+@pytest.mark.parametrize("B,S,H,Sq,qoff", [(2, 200, 2, 120, 80), (1, 300, 1, 45, 255), (1, 512, 2, 384, 128)])
+def test_attention_query_subrange(ops, B, S, H, Sq, qoff):
+    """Only queries qoff..qoff+Sq-1 of each sequence are computed (keys/values: all S) - the last decoder block's case."""
+    w = H * 64
+    qkv = rnd(B * S, 3 * w, seed=11).bfloat16()
+    O, lse = ops.attention_fwd(qkv, B, S, H, Sq=Sq, q_off=qoff)
+    qf = qkv.float().requires_grad_(True)
+    q, k, v, s = _attn_ref(qf, B, S, H)
+    s = s[:, :, qoff:qoff + Sq]
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, Sq, w)
+    got = O.view(B, S, w)[:, qoff:qoff + Sq]
+    assert rel_err(got, ref) < 1.5e-2 and rms_err(got, ref) < 6e-3
+    assert float(O.view(B, S, w)[:, :qoff].abs().max()) == 0  # rows outside the range are not written
+    assert rel_err(lse, torch.logsumexp(s, -1)) < 2e-3
+    dO = torch.zeros(B, S, w, device="cuda")
+    dO[:, qoff:qoff + Sq] = rnd(B, Sq, w, seed=12)
+    dO = dO.bfloat16().view(B * S, w)
+    dqkv, delta = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff)
+    ref.backward(dO.float().view(B, S, w)[:, qoff:qoff + Sq])
+    for i, name in enumerate("qkv"):
+        a, b = dqkv[:, i * w:(i + 1) * w], qf.grad[:, i * w:(i + 1) * w]
+        assert rel_err(a, b) < 2.5e-2 and rms_err(a, b) < 1e-2, name
