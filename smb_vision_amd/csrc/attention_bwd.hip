@@ -13,11 +13,35 @@
 // float atomics would be bound by the ~1.3 TB/s atomic rate at S = 20,480: see DESIGN.md).
 #include "smbv_common.h"
 #include "smbv_kernels.h"
+#include <mutex>
 #include <type_traits>
 
 namespace smbv {
 extern int g_variant;
 bool attn_prefer_3waves(long blocks);
+
+#define HIPRC(x) do { hipError_t _e = (x); if (_e != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(_e)); return (int)_e; } } while (0)
+
+// Host-side fork/join resources: one private non-blocking stream + two events per device, created on first use and kept for
+// the life of the process (no device memory involved).  Stream order is preserved for the caller: everything forked is joined
+// back into the caller's stream before the launching function returns.
+struct ForkJoin {
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+static ForkJoin* fork_join_for_current_device() {
+  static ForkJoin table[64];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  ForkJoin& f = table[dev];
+  if (!f.side) {
+    if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) { f.side = nullptr; return nullptr; }
+    if (hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&f.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  return &f;
+}
 
 // 128-byte-row LDS image usable for ds_read_b128 row reads (16 rows x same chunk) AND ds_read_b64_tr_b16 blocks
 // (4 consecutive rows x 32 B): chunk16 ^= f((row>>1)&7), f(x) = ((x&1)<<2) | (x>>1).
@@ -347,6 +371,19 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     rc = check_launch("attn_delta");
     if (rc) return rc;
   }
+  // dK/dV and dQ are independent (disjoint outputs, shared read-only inputs).  Their grids rarely fill a whole number of
+  // block rounds (encoder: 672 blocks on 512 slots), so when both are requested they are forked onto two streams and run
+  // side by side, each filling the other's idle CUs, and joined again before this function's stream continues.
+  hipStream_t st_dq = st;
+  ForkJoin* fj = nullptr;
+  if ((parts & 6) == 6 && !(g_variant & 8192)) {
+    fj = fork_join_for_current_device();
+    if (fj) {
+      HIPRC(hipEventRecord(fj->fork, st));
+      HIPRC(hipStreamWaitEvent(fj->side, fj->fork, 0));
+      st_dq = fj->side;
+    }
+  }
   if (parts & 2) {
 #define DKV(W, QT) hipLaunchKernelGGL((attn_dkv_kernel<W, QT>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale)
     // measured (tools/attn_ab.py): 128-query iterations at 2 waves/SIMD beat 64/32-query ones and the 3-wave build on both shapes
@@ -358,11 +395,15 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     if (rc) return rc;
   }
   if (parts & 4) {
-#define DQ(W, KT) hipLaunchKernelGGL((attn_dq_kernel<W, KT>), dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale)
+#define DQ(W, KT) hipLaunchKernelGGL((attn_dq_kernel<W, KT>), dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale)
     if (g_variant & 512) DQ(2, 64);
     else DQ(2, 128);
 #undef DQ
     rc = check_launch("attn_dq");
+  }
+  if (fj) {
+    HIPRC(hipEventRecord(fj->join, fj->side));
+    HIPRC(hipStreamWaitEvent(st, fj->join, 0));
   }
   return rc;
 }

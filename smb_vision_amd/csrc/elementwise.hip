@@ -45,6 +45,51 @@ int transpose_cast_f32_bf16(const float* src, bf16_t* dst, int R, int C, int ldd
   return check_launch("transpose_cast");
 }
 
+// All per-step weight preparation in ONE launch: a device-resident job table (built by the host sequencer) lists, per fp32 master
+// tensor, a bf16 cast (optionally transposed, with a destination leading dimension), an fp32 copy or a zero fill; a block handles
+// one 32x32 tile of one job (binary search over the jobs' first-tile prefix).  Replaces ~200 tiny cast/transpose/copy launches.
+__global__ __launch_bounds__(256) void prep_weights_kernel(const PrepJob* __restrict__ jobs, int njobs) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = njobs - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const PrepJob j = jobs[lo];
+  const int tl = b - j.tile0;
+  const int tiles_c = (j.C + 31) >> 5;
+  const int r0 = (tl / tiles_c) * 32, c0 = (tl % tiles_c) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  if (j.kind == 0) {  // bf16 cast, same layout (dst leading dimension ldd)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int r = r0 + ty + 8 * i, c = c0 + tx;
+      if (r < j.R && c < j.C) ((bf16_t*)j.dst)[(size_t)r * j.ldd + c] = f2bf(j.src[(size_t)r * j.C + c]);
+    }
+  } else if (j.kind == 1) {  // bf16 cast, transposed: dst[c][r]
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int r = r0 + ty + 8 * i, c = c0 + tx;
+      tile[ty + 8 * i][tx] = (r < j.R && c < j.C) ? j.src[(size_t)r * j.C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int c = c0 + ty + 8 * i, r = r0 + tx;
+      if (c < j.C && r < j.R) ((bf16_t*)j.dst)[(size_t)c * j.ldd + r] = f2bf(tile[tx][ty + 8 * i]);
+    }
+  } else {  // fp32 copy (kind 2) or zero fill (kind 3) of a [1, C] row
+    for (int c = c0 + threadIdx.x; c < min(j.C, c0 + 32); c += 256) ((float*)j.dst)[c] = j.kind == 2 ? j.src[c] : 0.f;
+  }
+}
+
+int prep_weights(const PrepJob* jobs_dev, int njobs, int total_tiles, hipStream_t st) {
+  if (njobs <= 0 || total_tiles <= 0) return SMBV_OK;
+  hipLaunchKernelGGL(prep_weights_kernel, dim3(total_tiles), dim3(256), 0, st, jobs_dev, njobs);
+  return check_launch("prep_weights");
+}
+
 // decoder input, masked part (src/models/videomae/modeling_videomae.py:811-815): x_full[b, Nvis + i, :] = mask_token + pos[mask_idx[b,i], :]
 __global__ void fill_mask_rows_kernel(float* __restrict__ xfull, const float* __restrict__ mask_token, const float* __restrict__ pos,
                                       const int* __restrict__ mask_idx, int nmask, int nvis, int D) {

@@ -7,6 +7,7 @@
 #include "smbv_common.h"
 #include "smbv_kernels.h"
 #include "../../include/smbv.h"
+#include <vector>
 
 namespace smbv {
 
@@ -31,6 +32,7 @@ struct MimWs {
   // backward scratch
   float *g0, *g1, *delta;
   bf16_t *gb0, *gb1, *dlogits, *d_act, *d_ln, *d_o, *d_qkv, *d_vis, *gath0, *gath1;
+  PrepJob* prep_table;  // device copy of the weight-preparation job list (uploaded by every forward)
   void* scratch;  // gemm_tn slabs / ln-bwd partials / colsum partials (max of all uses)
   size_t scratch_bytes;
   size_t total;
@@ -86,6 +88,7 @@ static void carve(const smbv_mim_cfg& c, void* base, MimWs& w) {
   Carver cv{(char*)base};
   const int K = c.ts * c.ps * c.ps;
   const size_t R = (size_t)c.B * c.Nvis, Rd = (size_t)c.B * c.N, Rm = (size_t)c.B * c.Nmask;
+  w.prep_table = cv.take<PrepJob>(16 + 16 * (size_t)(c.layers + c.dlayers));
   w.pe_w = cv.take<bf16_t>((size_t)c.d * K);
   w.e2d = cv.take<bf16_t>((size_t)c.dd * c.d);
   w.e2d_t = cv.take<bf16_t>((size_t)c.dd * c.d);
@@ -134,24 +137,36 @@ static void carve(const smbv_mim_cfg& c, void* base, MimWs& w) {
 #define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
 #define HIPRC(x) do { hipError_t _e = (x); if (_e != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(_e)); return (int)_e; } } while (0)
 
-static int prep_layer(const smbv_layer_ptrs& p, LayerWs& L, int w, int ff, hipStream_t st) {
+struct PrepList {
+  std::vector<PrepJob> jobs;
+  int tiles = 0;
+  void add(const float* src, void* dst, int R, int C, int ldd, int kind) {
+    PrepJob j;
+    j.src = src; j.dst = dst; j.R = R; j.C = C; j.ldd = ldd; j.kind = kind; j.tile0 = tiles; j.pad = 0;
+    jobs.push_back(j);
+    tiles += cdiv(R, 32) * cdiv(C, 32);
+  }
+  void cast(const float* src, bf16_t* dst, int R, int C) { add(src, dst, R, C, C, 0); }
+  void tcast(const float* src, bf16_t* dst, int R, int C, int ldd) { add(src, dst, R, C, ldd, 1); }
+};
+
+static void prep_layer(PrepList& pl, const smbv_layer_ptrs& p, LayerWs& L, int w, int ff) {
   const size_t ww = (size_t)w * w;
-  RC(cast_f32_bf16(p.q_w, L.wqkv, ww, st));
-  RC(cast_f32_bf16(p.k_w, L.wqkv + ww, ww, st));
-  RC(cast_f32_bf16(p.v_w, L.wqkv + 2 * ww, ww, st));
-  RC(transpose_cast_f32_bf16(p.q_w, L.wqkv_t, w, w, 3 * w, st));
-  RC(transpose_cast_f32_bf16(p.k_w, L.wqkv_t + w, w, w, 3 * w, st));
-  RC(transpose_cast_f32_bf16(p.v_w, L.wqkv_t + 2 * w, w, w, 3 * w, st));
-  RC(cast_f32_bf16(p.proj_w, L.proj, ww, st));
-  RC(transpose_cast_f32_bf16(p.proj_w, L.proj_t, w, w, w, st));
-  RC(cast_f32_bf16(p.fc1_w, L.fc1, (size_t)ff * w, st));
-  RC(transpose_cast_f32_bf16(p.fc1_w, L.fc1_t, ff, w, ff, st));
-  RC(cast_f32_bf16(p.fc2_w, L.fc2, (size_t)ff * w, st));
-  RC(transpose_cast_f32_bf16(p.fc2_w, L.fc2_t, w, ff, w, st));
-  HIPRC(hipMemcpyAsync(L.bqkv, p.q_b, w * sizeof(float), hipMemcpyDeviceToDevice, st));
-  HIPRC(hipMemsetAsync(L.bqkv + w, 0, w * sizeof(float), st));  // key has no bias (spec :261)
-  HIPRC(hipMemcpyAsync(L.bqkv + 2 * w, p.v_b, w * sizeof(float), hipMemcpyDeviceToDevice, st));
-  return SMBV_OK;
+  pl.cast(p.q_w, L.wqkv, w, w);
+  pl.cast(p.k_w, L.wqkv + ww, w, w);
+  pl.cast(p.v_w, L.wqkv + 2 * ww, w, w);
+  pl.tcast(p.q_w, L.wqkv_t, w, w, 3 * w);
+  pl.tcast(p.k_w, L.wqkv_t + w, w, w, 3 * w);
+  pl.tcast(p.v_w, L.wqkv_t + 2 * w, w, w, 3 * w);
+  pl.cast(p.proj_w, L.proj, w, w);
+  pl.tcast(p.proj_w, L.proj_t, w, w, w);
+  pl.cast(p.fc1_w, L.fc1, ff, w);
+  pl.tcast(p.fc1_w, L.fc1_t, ff, w, ff);
+  pl.cast(p.fc2_w, L.fc2, w, ff);
+  pl.tcast(p.fc2_w, L.fc2_t, w, ff, w);
+  pl.add(p.q_b, L.bqkv, 1, w, w, 2);
+  pl.add(nullptr, L.bqkv + w, 1, w, w, 3);  // key has no bias (spec :261)
+  pl.add(p.v_b, L.bqkv + 2 * w, 1, w, w, 2);
 }
 
 // one pre-LN block forward (spec :405-431) over `rows` = B*S tokens of width w
@@ -333,14 +348,21 @@ static int mim_forward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const s
   const int K = c.ts * c.ps * c.ps;
   const size_t R = (size_t)c.B * c.Nvis, Rd = (size_t)c.B * c.N, Rm = (size_t)c.B * c.Nmask;
 
-  // bf16 operand copies of the fp32 master weights (they change every optimizer step)
-  RC(cast_f32_bf16(p.pe_w, W.pe_w, (size_t)c.d * K, st));
-  RC(cast_f32_bf16(p.e2d_w, W.e2d, (size_t)c.dd * c.d, st));
-  RC(transpose_cast_f32_bf16(p.e2d_w, W.e2d_t, c.dd, c.d, c.dd, st));
-  RC(cast_f32_bf16(p.head_w, W.head, (size_t)K * c.dd, st));
-  RC(transpose_cast_f32_bf16(p.head_w, W.head_t, K, c.dd, K, st));
-  for (int l = 0; l < c.layers; l++) RC(prep_layer(p.enc[l], W.enc[l], c.d, c.ff, st));
-  for (int l = 0; l < c.dlayers; l++) RC(prep_layer(p.dec[l], W.dec[l], c.dd, c.dff, st));
+  // bf16 operand copies (plain and transposed) of the fp32 master weights, which change every optimizer step: one launch
+  {
+    PrepList pl;
+    pl.cast(p.pe_w, W.pe_w, c.d, K);
+    pl.cast(p.e2d_w, W.e2d, c.dd, c.d);
+    pl.tcast(p.e2d_w, W.e2d_t, c.dd, c.d, c.dd);
+    pl.cast(p.head_w, W.head, K, c.dd);
+    pl.tcast(p.head_w, W.head_t, K, c.dd, K);
+    for (int l = 0; l < c.layers; l++) prep_layer(pl, p.enc[l], W.enc[l], c.d, c.ff);
+    for (int l = 0; l < c.dlayers; l++) prep_layer(pl, p.dec[l], W.dec[l], c.dd, c.dff);
+    if (pl.jobs.size() > 16 + 16 * (size_t)(c.layers + c.dlayers)) { set_error("mim_forward: prep table overflow"); return SMBV_ERR_WORKSPACE; }
+    // pageable-source H2D: HIP stages the bytes before returning, so the vector may die at the end of this scope
+    HIPRC(hipMemcpyAsync(W.prep_table, pl.jobs.data(), pl.jobs.size() * sizeof(PrepJob), hipMemcpyHostToDevice, st));
+    RC(prep_weights(W.prep_table, (int)pl.jobs.size(), pl.tiles, st));
+  }
 
   // patch embedding of the visible bricks + bias + sin-cos rows (spec :124-139, :179-192)
   RC(gather_bricks(io.pixel_values, io.vis_idx, (int)R, c.Nvis, W.a_patch, c.T, c.H, c.W, c.ts, c.ps, st));

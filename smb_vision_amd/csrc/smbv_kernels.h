@@ -51,6 +51,15 @@ int mse_fwd(const float* pix, const int* idx, int rows, int per_batch, const flo
 int mse_bwd(const float* pix, const int* idx, int rows, int per_batch, const float* mean, const float* rinv, const bf16_t* logits,
             bf16_t* dlogits, const float* gscale, int T, int H, int W, int ts, int ps, hipStream_t st);
 
+struct PrepJob {
+  const float* src;
+  void* dst;
+  int R, C, ldd;
+  int kind;   // 0 cast, 1 cast + transpose, 2 fp32 copy of C elements, 3 zero-fill of C floats
+  int tile0;  // first block of this job
+  int pad;
+};
+int prep_weights(const PrepJob* jobs_dev, int njobs, int total_tiles, hipStream_t st);
 int cast_f32_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st);
 int transpose_cast_f32_bf16(const float* src, bf16_t* dst, int R, int C, int ldd, hipStream_t st);
 int fill_mask_rows(float* xfull, const float* mask_token, const float* pos, const int* mask_idx, int B, int nmask, int nvis, int D, hipStream_t st);

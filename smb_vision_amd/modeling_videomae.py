@@ -118,11 +118,14 @@ class _MIMStepFn(torch.autograd.Function):
         ctx.model_ref = model_ref
         ctx.st = st
         ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)  # no 109 MB zero tensor for the unused logits gradient
         return loss, logits
 
     @staticmethod
     def backward(ctx, grad_loss, _grad_logits):
         model = ctx.model_ref()
+        if grad_loss is None:  # loss not used by the caller's graph
+            return (None,) * (4 + len(model._table))
         grads = model._run_backward(ctx.st, grad_loss)
         ctx.st = None
         return (None, None, None, None, *grads)
