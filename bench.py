@@ -241,8 +241,11 @@ def main():
                        "tokens": model.num_patches, "masked": n_masked, "parallelism": f"dp{world}", "final_loss": final_loss,
                        "replicas_in_sync": in_sync},
         }
-        step_tf = STEP_TFLOP / (ms * 1e-3) if not args.tiny else None
-        if not args.no_kernel_roofline and not args.tiny:
+        step_tf = world * STEP_TFLOP / (ms * 1e-3) if not args.tiny else None  # whole job, TFLOP/s
+        if world > 1 and not args.tiny:  # multi-GPU lines carry the whole-step roofline only (the kernel figure is a 1-GPU property)
+            line["roofline"] = {"bound": "mfma", "kernel": "whole step (per GPU)", "achieved": step_tf / world, "peak": MFMA_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": step_tf / world / MFMA_PEAK_TFLOPS, "traffic": None}
+        elif not args.no_kernel_roofline and not args.tiny:
             kr = kernel_roofline(device)
             dom = kr["attn_dkv_kernel"]
             traffic = None
@@ -254,8 +257,7 @@ def main():
                                 "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic,
                                 "launch_ms": dom["ms"], "flop_per_launch": dom["flop"],
                                 "other": {"attn_dq_kernel": {"launch_ms": kr["attn_dq_kernel"]["ms"], "achieved": kr["attn_dq_kernel"]["tflops"]}},
-                                "step": {"achieved": step_tf / world * 1.0 if step_tf else None, "flop_per_volume_T": STEP_TFLOP,
-                                         "frac": (step_tf / MFMA_PEAK_TFLOPS) if step_tf else None}}
+                                "step": {"achieved": step_tf, "flop_per_volume_T": STEP_TFLOP, "frac": step_tf / MFMA_PEAK_TFLOPS}}
         if world == 1 and not args.no_cpu_baseline and not args.tiny:
             try:
                 line["cpu_baseline"] = cpu_baseline(cpu_threads())
@@ -263,6 +265,7 @@ def main():
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
