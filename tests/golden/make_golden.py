@@ -151,7 +151,104 @@ def make_mim(name, spec):
     print(name, "loss", float(out.loss), "logits", tuple(out.logits.shape), "n tensors", len(blob))
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# V-JEPA (src/run_vjepa.py): the in-repo model class src/models/vjepa/modeling_vjepa.py imports as shipped.
+# ----------------------------------------------------------------------------------------------------------------------
+
+VJEPA_TINY = dict(patch_size=8, crop_size=32, frames_per_clip=8, tubelet_size=2, in_chans=1, hidden_size=128, num_hidden_layers=2,
+                  num_attention_heads=2, mlp_ratio=4.0, pred_hidden_size=64, pred_num_hidden_layers=2, pred_num_attention_heads=2,
+                  pred_num_mask_tokens=10, pred_mlp_ratio=4.0)
+
+
+def load_reference_vjepa_mask_generator():
+    """VJEPAMaskGenerator from the text of src/dataloader/transforms.py (module import needs monai); its MONAI ``Transform`` base only
+    contributes ``__init__``/call plumbing, so the class is compiled with ``object`` as base."""
+    import math
+    path = os.path.join(REF, "src/dataloader/transforms.py")
+    tree = ast.parse(open(path).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "VJEPAMaskGenerator"]
+    assert len(cls) == 1
+    cls[0].bases = []
+    mod = ast.Module(body=cls, type_ignores=[])
+    ns = {"np": np, "torch": torch, "math": math}
+    exec(compile(mod, path, "exec"), ns)
+    return ns["VJEPAMaskGenerator"]
+
+
+def make_vjepa_masks():
+    G = load_reference_vjepa_mask_generator()
+    out = {}
+    cases = [((8, 32, 32), (2, 8, 8), 1), ((8, 32, 32), (2, 8, 8), 3), ((160, 224, 224), (16, 16, 16), 3), ((320, 512, 512), (16, 16, 16), 3)]
+    for ci, (inp, ps, nb) in enumerate(cases):
+        gen = G(input_size=inp, patch_size=ps, pred_mask_scale=(0.2, 0.8), aspect_ratio=(0.3, 3.0), num_blocks=nb)
+        for seed in range(4):
+            torch.manual_seed(seed)
+            for draw in range(2):
+                d = gen({})
+                key = f"vmask_{ci}_seed{seed}_{draw}"
+                out[key + "_ctx"] = d["context_mask"].reshape(-1).numpy().astype(np.int64)
+                out[key + "_tgt"] = d["target_mask"].reshape(-1).numpy().astype(np.int64)
+        out[f"vmask_{ci}_cfg"] = np.array(list(inp) + list(ps) + [nb], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "vjepa_masks.npz"), **out)
+    print("vjepa_masks.npz:", len(out), "arrays")
+
+
+def make_vjepa(name="vjepa_tiny"):
+    from safetensors.torch import save_file
+    sys.path.insert(0, os.path.join(REF, "src"))
+    from models.vjepa.configuration_vjepa import VJEPA2Config
+    from models.vjepa.modeling_vjepa import VJEPA2Model
+    from oracle.vjepa_oracle import VJEPAConfig, init_params
+
+    ocfg = VJEPAConfig(**VJEPA_TINY)
+    rcfg = VJEPA2Config(**VJEPA_TINY)
+    rcfg._attn_implementation = "eager"
+    online, target = VJEPA2Model(rcfg).float().train(), VJEPA2Model(rcfg).float().eval()
+    p_on, p_tg = init_params(ocfg, seed=3), init_params(ocfg, seed=4)
+
+    def load(model, p):
+        sd = model.state_dict()
+        for k in sd:
+            if k in p:
+                sd[k] = p[k].clone()
+        model.load_state_dict(sd)
+    load(online, p_on)
+    load(target, p_tg)
+    B = 2
+    pix = torch.rand(B, ocfg.frames_per_clip, 1, ocfg.crop_size, ocfg.crop_size, generator=torch.Generator().manual_seed(7))
+    G = load_reference_vjepa_mask_generator()
+    gen = G(input_size=(ocfg.frames_per_clip, ocfg.crop_size, ocfg.crop_size), patch_size=(ocfg.tubelet_size, ocfg.patch_size, ocfg.patch_size),
+            pred_mask_scale=(0.2, 0.5), aspect_ratio=(0.3, 3.0), num_blocks=2)
+    torch.manual_seed(11)
+    d = gen({})
+    cm = torch.stack([d["context_mask"].reshape(-1)] * B)  # run_vjepa.py:144-160: one example's masks for the whole batch
+    tm = torch.stack([d["target_mask"].reshape(-1)] * B)
+    out = online(pixel_values_videos=pix, context_mask=[cm], target_mask=[tm], skip_predictor=False)
+    pred = out.predictor_output.last_hidden_state
+    with torch.no_grad():
+        tgt = target(pixel_values_videos=pix, context_mask=[cm], target_mask=[tm], skip_predictor=True).target_hidden_state
+    loss = torch.nn.L1Loss()(pred, tgt)
+    loss.backward()
+    blob = {"in.pixel_values_videos": pix, "in.context_mask": cm, "in.target_mask": tm, "out.loss": loss.detach().reshape(1),
+            "out.last_hidden_state": out.last_hidden_state.detach(), "out.predictor": pred.detach(), "out.target_hidden_state": tgt}
+    names = set(p_on)
+    for k, v in p_on.items():
+        blob["param." + k] = v.contiguous()
+    for k, v in p_tg.items():
+        blob["tparam." + k] = v.contiguous()
+    for k, v in online.named_parameters():
+        if k in names:
+            blob["grad." + k] = (v.grad if v.grad is not None else torch.zeros_like(v)).detach().contiguous()
+    save_file(blob, os.path.join(HERE, name + ".safetensors"), metadata={"config": repr(VJEPA_TINY), "generator": "reference VJEPA2Model fp32 eager CPU"})
+    print(name, "loss", float(loss), "pred", tuple(pred.shape), "ctx/tgt", cm.shape[1], tm.shape[1], "tensors", len(blob))
+
+
 if __name__ == "__main__":
-    make_masks()
-    for n, s in GOLDEN_CONFIGS.items():
-        make_mim(n, s)
+    which = sys.argv[1:] or ["mim", "vjepa"]
+    if "mim" in which:
+        make_masks()
+        for n, s in GOLDEN_CONFIGS.items():
+            make_mim(n, s)
+    if "vjepa" in which:
+        make_vjepa_masks()
+        make_vjepa()
