@@ -177,6 +177,25 @@ int smbv_grad_sqnorm(const smbv_adam_chunk* chunks_dev, int nchunks, float* part
 int smbv_adamw_step(const smbv_adam_chunk* chunks_dev, int nchunks, const smbv_adam_hyper* hyper /* host */, const float* gnorm_sq,
                     smbv_stream stream);
 
+/* ---- V-JEPA building blocks (src/run_vjepa.py, src/models/vjepa/modeling_vjepa.py) ------------------------------------------- */
+
+/* 3-axis rotary embedding of the q (column 0) and k (column k_off) sections of the fused QKV matrix bf16 [rows, ld], in place
+ * (modeling_vjepa.py:204-228 rotate_queries_or_keys with its tiled cos/sin, :277-326 position ids -> frame/height/width, three
+ * segments of 2*((Dh/3)/2) dims per head).  head_stride: columns between heads (64 when heads are padded).  pos: int32 [rows] token
+ * position ids or NULL (= row % S).  table: fp32 [P][2][seg/2] = cos | sin of position * 10000^(-j/(seg/2)).  transpose != 0 applies
+ * the transposed map (gradient). */
+int smbv_rope3d(smbv_bf16* qkv, int ld, int k_off, long rows, int S, int H, int head_stride, int Dh, int grid, const int32_t* pos,
+                const float* table, int transpose, smbv_stream stream);
+/* apply_masks (:542-556): dst[r,:] = src[batch(r)*src_batch_rows + idx[r], :]; scatter is the inverse placement; fill writes `vec`. */
+int smbv_gather_rows_idx_f32(const float* src, float* dst, const int32_t* idx, long nidx, int per_batch, long src_batch_rows, int D, smbv_stream stream);
+int smbv_scatter_rows_idx_f32(const float* src, float* dst, const int32_t* idx, long nidx, int per_batch, long dst_batch_rows, int D, smbv_stream stream);
+int smbv_fill_rows_idx_f32(float* dst, const float* vec, const int32_t* idx, long nidx, int per_batch, long dst_batch_rows, int D, smbv_stream stream);
+/* nn.L1Loss() (run_vjepa.py:108,136): loss = mean|pred - target|; dpred = sign(pred - target) * (*gscale) / n.  partial: fp32 [1024]. */
+int smbv_l1_fwd(const float* pred, const float* target, size_t n, float* partial, float* loss, smbv_stream stream);
+int smbv_l1_bwd(const float* pred, const float* target, size_t n, float* dpred, const float* gscale, smbv_stream stream);
+/* MomentumEncoder.update (run_vjepa.py:94-98): chunk.p (target) = m * chunk.p + (1 - m) * chunk.g (online); one launch. */
+int smbv_ema_update(const smbv_adam_chunk* chunks_dev, int nchunks, float momentum, smbv_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,13 @@ _SIGS = {
     "smbv_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "smbv_grad_sqnorm": (C.c_int, [c_f, C.c_int, c_f, c_f, c_f]),
     "smbv_adamw_step": (C.c_int, [c_f, C.c_int, C.POINTER(AdamHyper), c_f, c_f]),
+    "smbv_rope3d": (C.c_int, [c_f, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f, C.c_int, c_f]),
+    "smbv_gather_rows_idx_f32": (C.c_int, [c_f, c_f, c_f, C.c_long, C.c_int, C.c_long, C.c_int, c_f]),
+    "smbv_scatter_rows_idx_f32": (C.c_int, [c_f, c_f, c_f, C.c_long, C.c_int, C.c_long, C.c_int, c_f]),
+    "smbv_fill_rows_idx_f32": (C.c_int, [c_f, c_f, c_f, C.c_long, C.c_int, C.c_long, C.c_int, c_f]),
+    "smbv_l1_fwd": (C.c_int, [c_f, c_f, C.c_size_t, c_f, c_f, c_f]),
+    "smbv_l1_bwd": (C.c_int, [c_f, c_f, C.c_size_t, c_f, c_f, c_f]),
+    "smbv_ema_update": (C.c_int, [c_f, C.c_int, C.c_float, c_f]),
     "smbv_mim_workspace_bytes": (C.c_size_t, [C.POINTER(MimCfg)]),
     "smbv_mim_forward": (C.c_int, [C.POINTER(MimCfg), C.POINTER(MimTensors), C.POINTER(MimIO), c_f, C.c_size_t, c_f]),
     "smbv_mim_backward": (C.c_int, [C.POINTER(MimCfg), C.POINTER(MimTensors), C.POINTER(MimTensors), C.POINTER(MimIO), c_f, C.c_size_t,

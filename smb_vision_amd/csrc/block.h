@@ -1,0 +1,87 @@
+// One pre-LN transformer block (LayerNorm -> QKV -> [RoPE] -> attention -> projection + residual -> LayerNorm -> MLP + residual),
+// forward and backward, sequenced over the kernels of this library.  Shared by the MIM step (VideoMAELayer, spec
+// src/models/videomae/modeling_videomae.py:405-431) and the V-JEPA step (VJEPA2Layer, src/models/vjepa/modeling_vjepa.py:426-478).
+#pragma once
+#include "smbv_common.h"
+#include "smbv_kernels.h"
+#include <cmath>
+#include <vector>
+
+namespace smbv {
+
+struct BlockPtrs {  // fp32 parameters (or their gradients) of one block
+  float *ln1_w, *ln1_b, *q_w, *k_w, *v_w, *q_b, *k_b /* may be null: VideoMAE has no key bias */, *v_b, *proj_w, *proj_b, *ln2_w, *ln2_b, *fc1_w,
+      *fc1_b, *fc2_w, *fc2_b;
+};
+
+struct BlockDims {
+  size_t rows = 0;  // B * S tokens
+  int w = 0, ff = 0, B = 0, S = 0, H = 0;
+  int Dh = 64;      // true head dim (8..64, multiple of 8).  The attention kernels work on 64-wide heads: smaller heads are zero-padded
+                    // in the QKV / projection weights (exact: padded q/k columns add 0 to every score, padded v columns give 0 outputs)
+  float eps = 1e-12f;
+  int rope_grid = 0;              // > 0: 3-axis RoPE on q and k with this grid size (tokens per row; tokens per frame = grid^2)
+  const int* pos = nullptr;       // token position ids for RoPE (null = index within the sequence)
+  const float* rope_table = nullptr;
+  int wa() const { return H * 64; }
+  bool padded() const { return Dh != 64; }
+  float scale() const { return 1.0f / std::sqrt((float)Dh); }
+};
+
+struct LayerWs {
+  bf16_t *wqkv, *wqkv_t, *proj, *proj_t, *fc1, *fc1_t, *fc2, *fc2_t;  // bf16 operand copies of the weights
+  float* bqkv;
+  bf16_t *ln1, *qkv, *attn_o, *ln2, *pre, *act;                       // saved activations
+  float *mean1, *rstd1, *mean2, *rstd2, *lse, *x_mid;
+};
+
+struct BwdScratch {  // sized for the widest block of the model
+  bf16_t *d_act, *d_ln, *d_o, *d_qkv, *gath0, *gath1;
+  float *delta, *gpad;  // gpad: head-padded weight/bias gradients before un-padding (null when no block is padded)
+  void* scratch;        // gemm_tn slabs / LN-bwd partials / colsum partials
+  size_t scratch_bytes;
+};
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct PrepList {
+  std::vector<PrepJob> jobs;
+  int tiles = 0;
+  void add(const float* src, void* dst, int R, int C, int lds, int ldd, int kind) {
+    PrepJob j;
+    j.src = src; j.dst = dst; j.R = R; j.C = C; j.ldd = ldd; j.kind = kind; j.tile0 = tiles; j.lds = lds;
+    jobs.push_back(j);
+    tiles += cdiv(R, 32) * cdiv(C, 32);
+  }
+  void cast(const float* src, bf16_t* dst, int R, int C) { add(src, dst, R, C, C, C, 0); }
+  void tcast(const float* src, bf16_t* dst, int R, int C, int ldd) { add(src, dst, R, C, C, ldd, 1); }
+};
+
+void carve_layer(Carver& c, LayerWs& L, const BlockDims& d);
+size_t layer_prep_job_count(const BlockDims& d);
+// appends this block's weight-preparation jobs; for padded heads also enqueues the zero fills of the padded buffers on `st`
+int prep_layer(PrepList& pl, const BlockPtrs& p, LayerWs& L, const BlockDims& d, hipStream_t st);
+void bwd_scratch_requirements(const BlockDims& d, size_t& act_elems, size_t& w_elems, size_t& qkv_elems, size_t& gpad_elems, size_t& scratch_bytes,
+                              size_t& delta_elems);
+
+// Sq > 0: only tokens qoff..qoff+Sq-1 of every sequence are needed downstream (see mim_step.hip); 0 = all tokens.
+int layer_fwd(const BlockPtrs& p, LayerWs& L, const BlockDims& d, BwdScratch& sc, const float* x_in, float* x_out, bf16_t* x_out_bf16, int Sq, int qoff,
+              hipStream_t st);
+// g/gb: gradient w.r.t. the block output (fp32 + bf16 copy) on entry, w.r.t. the block input on exit; g2/gb2: ping-pong partners.
+int layer_bwd(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDims& d, BwdScratch& sc, const float* x_in, float* g, bf16_t* gb, float* g2,
+              bf16_t* gb2, int Sq, int qoff, hipStream_t st);
+
+#define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+#define HIPRC(x) do { hipError_t _e = (x); if (_e != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(_e)); return (int)_e; } } while (0)
+
+}  // namespace smbv

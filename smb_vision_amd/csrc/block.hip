@@ -1,0 +1,239 @@
+// Transformer block forward / backward sequencing (see block.h).
+#include "block.h"
+
+namespace smbv {
+
+void carve_layer(Carver& c, LayerWs& L, const BlockDims& d) {
+  const size_t w = d.w, wa = d.wa(), ff = d.ff, rows = d.rows;
+  L.wqkv = c.take<bf16_t>(3 * wa * w);
+  L.wqkv_t = c.take<bf16_t>(3 * wa * w);
+  L.proj = c.take<bf16_t>(w * wa);
+  L.proj_t = c.take<bf16_t>(w * wa);
+  L.fc1 = c.take<bf16_t>(ff * w);
+  L.fc1_t = c.take<bf16_t>(ff * w);
+  L.fc2 = c.take<bf16_t>(ff * w);
+  L.fc2_t = c.take<bf16_t>(ff * w);
+  L.bqkv = c.take<float>(3 * wa);
+  L.ln1 = c.take<bf16_t>(rows * w);
+  L.qkv = c.take<bf16_t>(rows * 3 * wa);
+  L.attn_o = c.take<bf16_t>(rows * wa);
+  L.ln2 = c.take<bf16_t>(rows * w);
+  L.pre = c.take<bf16_t>(rows * ff);
+  L.act = c.take<bf16_t>(rows * ff);
+  L.mean1 = c.take<float>(rows);
+  L.rstd1 = c.take<float>(rows);
+  L.mean2 = c.take<float>(rows);
+  L.rstd2 = c.take<float>(rows);
+  L.lse = c.take<float>((size_t)d.B * d.H * d.S);
+  L.x_mid = c.take<float>(rows * w);
+}
+
+size_t layer_prep_job_count(const BlockDims& d) { return d.padded() ? (size_t)(16 + 11 * d.H) : 16; }
+
+int prep_layer(PrepList& pl, const BlockPtrs& p, LayerWs& L, const BlockDims& d, hipStream_t st) {
+  const int w = d.w, ff = d.ff, wa = d.wa(), Dh = d.Dh;
+  const size_t ww = (size_t)w * w;
+  if (!d.padded()) {
+    pl.cast(p.q_w, L.wqkv, w, w);
+    pl.cast(p.k_w, L.wqkv + ww, w, w);
+    pl.cast(p.v_w, L.wqkv + 2 * ww, w, w);
+    pl.tcast(p.q_w, L.wqkv_t, w, w, 3 * w);
+    pl.tcast(p.k_w, L.wqkv_t + w, w, w, 3 * w);
+    pl.tcast(p.v_w, L.wqkv_t + 2 * w, w, w, 3 * w);
+    pl.cast(p.proj_w, L.proj, w, w);
+    pl.tcast(p.proj_w, L.proj_t, w, w, w);
+    pl.add(p.q_b, L.bqkv, 1, w, w, w, 2);
+    if (p.k_b) pl.add(p.k_b, L.bqkv + w, 1, w, w, w, 2);
+    else pl.add(nullptr, L.bqkv + w, 1, w, w, w, 3);  // VideoMAE: key has no bias (spec :261)
+    pl.add(p.v_b, L.bqkv + 2 * w, 1, w, w, w, 2);
+  } else {
+    // heads of Dh < 64 columns live in 64-column slots; everything outside the real columns is zero
+    HIPRC(hipMemsetAsync(L.wqkv, 0, (size_t)3 * wa * w * sizeof(bf16_t), st));
+    HIPRC(hipMemsetAsync(L.wqkv_t, 0, (size_t)3 * wa * w * sizeof(bf16_t), st));
+    HIPRC(hipMemsetAsync(L.proj, 0, (size_t)w * wa * sizeof(bf16_t), st));
+    HIPRC(hipMemsetAsync(L.proj_t, 0, (size_t)w * wa * sizeof(bf16_t), st));
+    HIPRC(hipMemsetAsync(L.bqkv, 0, (size_t)3 * wa * sizeof(float), st));
+    const float* wsrc[3] = {p.q_w, p.k_w, p.v_w};
+    const float* bsrc[3] = {p.q_b, p.k_b, p.v_b};
+    for (int sec = 0; sec < 3; sec++)
+      for (int h = 0; h < d.H; h++) {
+        const float* src = wsrc[sec] + (size_t)h * Dh * w;                       // rows h*Dh .. of [w_out, w_in]
+        pl.cast(src, L.wqkv + ((size_t)sec * wa + h * 64) * w, Dh, w);
+        pl.tcast(src, L.wqkv_t + (size_t)sec * wa + h * 64, Dh, w, 3 * wa);
+        if (bsrc[sec]) pl.add(bsrc[sec] + h * Dh, L.bqkv + sec * wa + h * 64, 1, Dh, Dh, Dh, 2);
+      }
+    for (int h = 0; h < d.H; h++) {
+      // proj weight [w, w_in = H*Dh]: column block h*Dh.. -> padded column block h*64..
+      pl.add(p.proj_w + h * Dh, L.proj + h * 64, w, Dh, w, wa, 0);
+      pl.add(p.proj_w + h * Dh, L.proj_t + (size_t)h * 64 * w, w, Dh, w, w, 1);
+    }
+  }
+  pl.cast(p.fc1_w, L.fc1, ff, w);
+  pl.tcast(p.fc1_w, L.fc1_t, ff, w, ff);
+  pl.cast(p.fc2_w, L.fc2, w, ff);
+  pl.tcast(p.fc2_w, L.fc2_t, w, ff, w);
+  return SMBV_OK;
+}
+
+void bwd_scratch_requirements(const BlockDims& d, size_t& act_elems, size_t& w_elems, size_t& qkv_elems, size_t& gpad_elems, size_t& scratch_bytes,
+                              size_t& delta_elems) {
+  const size_t rows = d.rows, w = d.w, wa = d.wa(), ff = d.ff;
+  act_elems = std::max(act_elems, rows * ff);
+  w_elems = std::max(w_elems, rows * std::max(w, wa));
+  qkv_elems = std::max(qkv_elems, rows * 3 * wa);
+  if (d.padded()) gpad_elems = std::max(gpad_elems, 3 * wa * w);
+  delta_elems = std::max(delta_elems, (size_t)d.B * d.H * d.S);
+  auto tn = [&](size_t M, size_t n1, size_t n2) { scratch_bytes = std::max(scratch_bytes, gemm_tn_workspace_bytes((int)M, (int)n1, (int)n2)); };
+  tn(rows, w, ff); tn(rows, ff, w); tn(rows, w, wa); tn(rows, 3 * wa, w);
+  scratch_bytes = std::max(scratch_bytes, layernorm_bwd_workspace_bytes((int)rows, (int)w));
+  scratch_bytes = std::max(scratch_bytes, colsum_workspace_bytes((int)rows, (int)std::max(ff, 3 * wa)));
+}
+
+int layer_fwd(const BlockPtrs& p, LayerWs& L, const BlockDims& d, BwdScratch& sc, const float* x_in, float* x_out, bf16_t* x_out_bf16, int Sq, int qoff,
+              hipStream_t st) {
+  const int w = d.w, ff = d.ff, wa = d.wa(), B = d.B, S = d.S, H = d.H;
+  const int M = (int)d.rows;
+  RC(layernorm_fwd(x_in, p.ln1_w, p.ln1_b, L.ln1, L.mean1, L.rstd1, M, w, d.eps, 0, 0, 0, st));
+  {
+    GemmEpi e; e.bias = L.bqkv; e.out_bf16 = L.qkv; e.ld_ob = 3 * wa;
+    RC(gemm_nt(L.ln1, w, L.wqkv, w, M, 3 * wa, w, e, st));
+  }
+  if (d.rope_grid > 0) RC(rope3d(L.qkv, 3 * wa, wa, M, S, H, 64, d.Dh, d.rope_grid, d.pos, d.rope_table, 0, st));
+  RC(attention_fwd(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, wa, L.lse, B, S, H, 64, d.scale(), Sq, qoff, st));
+  if (Sq > 0) {
+    // ranged tail: projection + MLP on the Sq tokens only; x_mid / x_out keep the full [B*S, w] layout, ln2 / pre / act are compact
+    const int Mq = B * Sq;
+    const bf16_t* a_rows = L.attn_o + (size_t)qoff * wa;  // contiguous for B == 1
+    if (B > 1) { RC(gather_rows_bf16(L.attn_o, sc.gath0, Mq, wa, Sq, S, qoff, st)); a_rows = sc.gath0; }
+    {
+      GemmEpi e; e.bias = p.proj_b; e.rowadd = x_in; e.ldr = w; e.radd_grp_in = Sq; e.radd_grp_out = S; e.radd_off = qoff;
+      e.out_f32 = L.x_mid + (size_t)qoff * w; e.ld_of = w; e.grp_in = Sq; e.grp_out = S;
+      RC(gemm_nt(a_rows, wa, L.proj, wa, Mq, w, wa, e, st));
+    }
+    RC(layernorm_fwd(L.x_mid, p.ln2_w, p.ln2_b, L.ln2, L.mean2, L.rstd2, Mq, w, d.eps, Sq, S, qoff, st));
+    {
+      GemmEpi e; e.bias = p.fc1_b; e.act_gelu = 1; e.aux_pre = L.pre; e.ld_aux = ff; e.out_bf16 = L.act; e.ld_ob = ff;
+      RC(gemm_nt(L.ln2, w, L.fc1, w, Mq, ff, w, e, st));
+    }
+    {
+      GemmEpi e; e.bias = p.fc2_b; e.rowadd = L.x_mid; e.ldr = w; e.radd_grp_in = Sq; e.radd_grp_out = S; e.radd_off = qoff;
+      e.out_f32 = x_out + (size_t)qoff * w; e.ld_of = w; e.grp_in = Sq; e.grp_out = S;
+      RC(gemm_nt(L.act, ff, L.fc2, ff, Mq, w, ff, e, st));
+    }
+    return SMBV_OK;
+  }
+  {
+    GemmEpi e; e.bias = p.proj_b; e.rowadd = x_in; e.ldr = w; e.out_f32 = L.x_mid; e.ld_of = w;
+    RC(gemm_nt(L.attn_o, wa, L.proj, wa, M, w, wa, e, st));
+  }
+  RC(layernorm_fwd(L.x_mid, p.ln2_w, p.ln2_b, L.ln2, L.mean2, L.rstd2, M, w, d.eps, 0, 0, 0, st));
+  {
+    GemmEpi e; e.bias = p.fc1_b; e.act_gelu = 1; e.aux_pre = L.pre; e.ld_aux = ff; e.out_bf16 = L.act; e.ld_ob = ff;
+    RC(gemm_nt(L.ln2, w, L.fc1, w, M, ff, w, e, st));
+  }
+  {
+    GemmEpi e; e.bias = p.fc2_b; e.rowadd = L.x_mid; e.ldr = w; e.out_f32 = x_out; e.ld_of = w; e.out_bf16 = x_out_bf16; e.ld_ob = w;
+    RC(gemm_nt(L.act, ff, L.fc2, ff, M, w, ff, e, st));
+  }
+  return SMBV_OK;
+}
+
+// colsum of a (possibly head-padded) [M, H*64] column block into a compact [H*Dh] gradient
+static int bias_grad(const bf16_t* X, int ld, int M, const BlockDims& d, float* out, BwdScratch& sc, hipStream_t st) {
+  if (!out) return SMBV_OK;
+  if (!d.padded()) return colsum_bf16(X, ld, M, d.w, out, 0, 0, 0, sc.scratch, sc.scratch_bytes, st);
+  RC(colsum_bf16(X, ld, M, d.wa(), sc.gpad, 0, 0, 0, sc.scratch, sc.scratch_bytes, st));
+  return map_copy_f32(out, sc.gpad, (size_t)d.w, d.Dh, 64, st);
+}
+
+int layer_bwd(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDims& d, BwdScratch& sc, const float* x_in, float* g, bf16_t* gb, float* g2,
+              bf16_t* gb2, int Sq, int qoff, hipStream_t st) {
+  const int w = d.w, ff = d.ff, wa = d.wa(), B = d.B, S = d.S, H = d.H;
+  const int M = (int)d.rows;
+  const bool ranged = Sq > 0;
+  const int Mq = ranged ? B * Sq : M;
+  // ---- MLP (on the ranged rows only when Sq > 0: ln2 / pre / act are compact then) ----
+  const bf16_t* gbc = gb;
+  if (ranged) {
+    gbc = gb + (size_t)qoff * w;  // contiguous for B == 1
+    if (B > 1) { RC(gather_rows_bf16(gb, sc.gath0, Mq, w, Sq, S, qoff, st)); gbc = sc.gath0; }
+  }
+  RC(colsum_bf16(gbc, w, Mq, w, gr.fc2_b, 0, 0, 0, sc.scratch, sc.scratch_bytes, st));
+  RC(gemm_tn(gbc, w, L.act, ff, Mq, w, ff, gr.fc2_w, sc.scratch, sc.scratch_bytes, st));
+  {
+    GemmEpi e; e.dgelu_pre = L.pre; e.ld_pre = ff; e.out_bf16 = sc.d_act; e.ld_ob = ff;
+    RC(gemm_nt(gbc, w, L.fc2_t, w, Mq, ff, w, e, st));
+  }
+  RC(colsum_bf16(sc.d_act, ff, Mq, ff, gr.fc1_b, 0, 0, 0, sc.scratch, sc.scratch_bytes, st));
+  RC(gemm_tn(sc.d_act, ff, L.ln2, w, Mq, ff, w, gr.fc1_w, sc.scratch, sc.scratch_bytes, st));
+  {
+    GemmEpi e; e.out_bf16 = sc.d_ln; e.ld_ob = w;
+    RC(gemm_nt(sc.d_act, ff, L.fc1_t, ff, Mq, w, ff, e, st));
+  }
+  // ---- LN2 (+ residual): g2 = g + LNbwd(d_ln); every non-ranged row of g2 is zero ----
+  if (ranged) {
+    HIPRC(hipMemsetAsync(g2, 0, (size_t)M * w * sizeof(float), st));
+    HIPRC(hipMemsetAsync(gb2, 0, (size_t)M * w * sizeof(bf16_t), st));
+    RC(layernorm_bwd(sc.d_ln, L.x_mid, L.mean2, L.rstd2, p.ln2_w, g, g2, gb2, gr.ln2_w, gr.ln2_b, Mq, w, Sq, S, qoff, sc.scratch, sc.scratch_bytes, st));
+  } else {
+    RC(layernorm_bwd(sc.d_ln, L.x_mid, L.mean2, L.rstd2, p.ln2_w, g, g2, gb2, gr.ln2_w, gr.ln2_b, M, w, 0, 0, 0, sc.scratch, sc.scratch_bytes, st));
+  }
+  // ---- attention output projection ----
+  const bf16_t* g2c = gb2;
+  const bf16_t* aoc = L.attn_o;
+  if (ranged) {
+    g2c = gb2 + (size_t)qoff * w;
+    aoc = L.attn_o + (size_t)qoff * wa;
+    if (B > 1) {
+      RC(gather_rows_bf16(gb2, sc.gath0, Mq, w, Sq, S, qoff, st));
+      RC(gather_rows_bf16(L.attn_o, sc.gath1, Mq, wa, Sq, S, qoff, st));
+      g2c = sc.gath0; aoc = sc.gath1;
+    }
+  }
+  RC(colsum_bf16(g2c, w, Mq, w, gr.proj_b, 0, 0, 0, sc.scratch, sc.scratch_bytes, st));
+  if (!d.padded()) {
+    RC(gemm_tn(g2c, w, aoc, wa, Mq, w, wa, gr.proj_w, sc.scratch, sc.scratch_bytes, st));
+  } else {
+    RC(gemm_tn(g2c, w, aoc, wa, Mq, w, wa, sc.gpad, sc.scratch, sc.scratch_bytes, st));   // [w, H*64] -> [w, H*Dh]
+    RC(map_copy_f32(gr.proj_w, sc.gpad, (size_t)w * w, d.Dh, 64, st));
+  }
+  {
+    GemmEpi e; e.out_bf16 = sc.d_o; e.ld_ob = wa;
+    if (ranged) { e.out_bf16 = sc.d_o + (size_t)qoff * wa; e.grp_in = Sq; e.grp_out = S; }
+    RC(gemm_nt(g2c, w, L.proj_t, w, Mq, wa, w, e, st));
+  }
+  // ---- attention (dQ exists only for the ranged queries; dK/dV for every token) ----
+  if (ranged) HIPRC(hipMemsetAsync(sc.d_qkv, 0, (size_t)M * 3 * wa * sizeof(bf16_t), st));
+  RC(attention_bwd(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, sc.d_o, wa, L.lse, sc.delta, sc.d_qkv, sc.d_qkv + wa, sc.d_qkv + 2 * wa, 3 * wa, B,
+                   S, H, 64, d.scale(), 7, Sq, qoff, st));
+  if (d.rope_grid > 0) RC(rope3d(sc.d_qkv, 3 * wa, wa, M, S, H, 64, d.Dh, d.rope_grid, d.pos, d.rope_table, 1, st));
+  // ---- QKV ----
+  RC(bias_grad(sc.d_qkv, 3 * wa, M, d, gr.q_b, sc, st));
+  RC(bias_grad(sc.d_qkv + wa, 3 * wa, M, d, gr.k_b, sc, st));
+  RC(bias_grad(sc.d_qkv + 2 * wa, 3 * wa, M, d, gr.v_b, sc, st));
+  const size_t ww = (size_t)w * w;
+  const bool contiguous = gr.k_w == gr.q_w + ww && gr.v_w == gr.k_w + ww;
+  if (!d.padded()) {
+    if (contiguous) {
+      RC(gemm_tn(sc.d_qkv, 3 * w, L.ln1, w, M, 3 * w, w, gr.q_w, sc.scratch, sc.scratch_bytes, st));
+    } else {
+      RC(gemm_tn(sc.d_qkv, 3 * w, L.ln1, w, M, w, w, gr.q_w, sc.scratch, sc.scratch_bytes, st));
+      RC(gemm_tn(sc.d_qkv + w, 3 * w, L.ln1, w, M, w, w, gr.k_w, sc.scratch, sc.scratch_bytes, st));
+      RC(gemm_tn(sc.d_qkv + 2 * w, 3 * w, L.ln1, w, M, w, w, gr.v_w, sc.scratch, sc.scratch_bytes, st));
+    }
+  } else {
+    RC(gemm_tn(sc.d_qkv, 3 * wa, L.ln1, w, M, 3 * wa, w, sc.gpad, sc.scratch, sc.scratch_bytes, st));   // [3*H*64, w]
+    float* dst[3] = {gr.q_w, gr.k_w, gr.v_w};
+    for (int sec = 0; sec < 3; sec++)
+      RC(map_copy_f32(dst[sec], sc.gpad + (size_t)sec * wa * w, ww, (long)d.Dh * w, (long)64 * w, st));
+  }
+  {
+    GemmEpi e; e.out_bf16 = sc.d_ln; e.ld_ob = w;
+    RC(gemm_nt(sc.d_qkv, 3 * wa, L.wqkv_t, 3 * wa, M, w, 3 * wa, e, st));
+  }
+  // ---- LN1 (+ residual) over all rows: g = g2 + LNbwd(d_ln) ----
+  RC(layernorm_bwd(sc.d_ln, x_in, L.mean1, L.rstd1, p.ln1_w, g2, g, gb, gr.ln1_w, gr.ln1_b, M, w, 0, 0, 0, sc.scratch, sc.scratch_bytes, st));
+  return SMBV_OK;
+}
+
+}  // namespace smbv

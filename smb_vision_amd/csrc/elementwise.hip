@@ -65,13 +65,13 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const PrepJob* __rest
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int r = r0 + ty + 8 * i, c = c0 + tx;
-      if (r < j.R && c < j.C) ((bf16_t*)j.dst)[(size_t)r * j.ldd + c] = f2bf(j.src[(size_t)r * j.C + c]);
+      if (r < j.R && c < j.C) ((bf16_t*)j.dst)[(size_t)r * j.ldd + c] = f2bf(j.src[(size_t)r * j.lds + c]);
     }
   } else if (j.kind == 1) {  // bf16 cast, transposed: dst[c][r]
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int r = r0 + ty + 8 * i, c = c0 + tx;
-      tile[ty + 8 * i][tx] = (r < j.R && c < j.C) ? j.src[(size_t)r * j.C + c] : 0.f;
+      tile[ty + 8 * i][tx] = (r < j.R && c < j.C) ? j.src[(size_t)r * j.lds + c] : 0.f;
     }
     __syncthreads();
 #pragma unroll

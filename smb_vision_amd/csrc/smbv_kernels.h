@@ -57,7 +57,7 @@ struct PrepJob {
   int R, C, ldd;
   int kind;   // 0 cast, 1 cast + transpose, 2 fp32 copy of C elements, 3 zero-fill of C floats
   int tile0;  // first block of this job
-  int pad;
+  int lds;    // source leading dimension (elements)
 };
 int prep_weights(const PrepJob* jobs_dev, int njobs, int total_tiles, hipStream_t st);
 int cast_f32_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st);
@@ -68,5 +68,9 @@ int colsum_bf16(const bf16_t* X, int ld, int M, int N, float* out, long grp_in, 
 int colsum_f32(const float* X, int ld, int M, int N, float* out, long grp_in, long grp_out, long row_off, void* ws, size_t ws_bytes, hipStream_t st);
 size_t colsum_workspace_bytes(int M, int N);
 int reduce_cols(const float* part, int nrows, int ncols, float* out0, float* out1, int split, hipStream_t st);
+
+int rope3d(bf16_t* qkv, int ld, int k_off, long rows, int S, int H, int hs, int Dh, int grid, const int* pos, const float* table, int transpose,
+           hipStream_t st);
+int map_copy_f32(float* dst, const float* src, size_t n, long grp_in, long grp_out, hipStream_t st);
 
 }  // namespace smbv

@@ -1,0 +1,186 @@
+// Small kernels of the V-JEPA step (src/run_vjepa.py / src/models/vjepa/modeling_vjepa.py) besides the transformer blocks:
+//   rope3d          3-axis rotary embedding of the q and k sections of the fused QKV matrix, in place (modeling_vjepa.py:204-228,
+//                   :277-326), and its transpose for the backward.  NOTE the reference's quirk, reproduced exactly: pairs are
+//                   interleaved (2i, 2i+1) but cos/sin are TILED ([f0..f_{n-1}, f0..f_{n-1}]), so the two elements of a pair use
+//                   different angles and the map is not a rotation: the backward is the transposed map, not rotate(-theta).
+//   gather/scatter  apply_masks (:542-556), predictor token assembly in position order (:602-619, :718-719) and its inverse (:737-738)
+//   l1              nn.L1Loss (run_vjepa.py:108,136) forward + backward
+//   ema             MomentumEncoder.update (run_vjepa.py:94-98) as one multi-tensor launch
+#include "smbv_common.h"
+#include "smbv_kernels.h"
+#include "../../include/smbv.h"
+
+namespace smbv {
+
+// One thread per (token, head, pair).  qkv: bf16 [rows, ld]; q at column 0, k at column k_off; head stride hs (64 when padded).
+// pos: int32 token position ids [rows] (null -> row % S).  table: fp32 [P][2][seg/2] cos|sin for positions 0..P-1.
+__global__ void rope3d_kernel(bf16_t* __restrict__ qkv, int ld, int k_off, long rows, int S, int H, int hs, int seg, int grid,
+                              const int* __restrict__ pos, const float* __restrict__ table, int transpose) {
+  const int npair = 3 * seg / 2;  // pairs per head
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = rows * H * npair;
+  if (gid >= total) return;
+  const int pr = gid % npair;
+  const int h = (gid / npair) % H;
+  const long row = gid / ((long)npair * H);
+  const int p = pos ? pos[row] : (int)(row % S);
+  const int tpf = grid * grid;
+  const int frame = p / tpf, height = (p - tpf * frame) / grid, width = (p - tpf * frame) - grid * height;
+  const int half = seg >> 1;
+  const int axis = (2 * pr) / seg;                 // 0 frame, 1 height, 2 width
+  const int t0 = 2 * pr - axis * seg;              // element index of the pair's first element inside its segment
+  const int pid = axis == 0 ? frame : (axis == 1 ? height : width);
+  const float* tb = table + (size_t)pid * seg;     // [cos half | sin half]
+  const float c0 = tb[t0 % half], s0 = tb[half + t0 % half];
+  const float c1 = tb[(t0 + 1) % half], s1 = tb[half + (t0 + 1) % half];
+  const int col = h * hs + axis * seg + t0;
+#pragma unroll
+  for (int sec = 0; sec < 2; sec++) {
+    unsigned* ptr = (unsigned*)(qkv + row * ld + (sec ? k_off : 0) + col);
+    const unsigned u = *ptr;
+    const float x0 = bf_lo(u), x1 = bf_hi(u);
+    float y0, y1;
+    if (!transpose) { y0 = x0 * c0 - x1 * s0; y1 = x1 * c1 + x0 * s1; }   // out = x*cos + rot(x)*sin, rot = (-x1, x0)
+    else { y0 = x0 * c0 + x1 * s1; y1 = x1 * c1 - x0 * s0; }              // transposed map for the gradient
+    *ptr = pack_bf16(y0, y1);
+  }
+}
+
+int rope3d(bf16_t* qkv, int ld, int k_off, long rows, int S, int H, int hs, int Dh, int grid, const int* pos, const float* table, int transpose,
+           hipStream_t st) {
+  const int seg = 2 * ((Dh / 3) / 2);
+  if (seg <= 0) return SMBV_OK;
+  if (rows <= 0 || H <= 0 || grid <= 0 || (ld & 1) || (k_off & 1) || (hs & 1) || !table) { set_error("rope3d: bad argument"); return SMBV_ERR_ARG; }
+  const long total = rows * H * (3 * seg / 2);
+  hipLaunchKernelGGL(rope3d_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, qkv, ld, k_off, rows, S, H, hs, seg, grid, pos, table, transpose);
+  return check_launch("rope3d");
+}
+
+// dst row r <- src row idx[r]  (gather);  scatter: dst row idx[r] <- src row r.  T = float or bf16_t; D multiple of 4 (f32) / 8 (bf16)
+template <typename T, bool SCATTER>
+__global__ void rows_idx_kernel(const T* __restrict__ src, T* __restrict__ dst, const int* __restrict__ idx, int per_batch_idx, long src_batch_rows,
+                                long dst_batch_rows, int D16) {
+  const long r = blockIdx.x;
+  const long b = r / per_batch_idx;
+  const long i = idx[r];
+  const u32x4* s = (const u32x4*)(src + (SCATTER ? r : b * src_batch_rows + i) * (size_t)D16 * (16 / sizeof(T)));
+  u32x4* d = (u32x4*)(dst + (SCATTER ? b * dst_batch_rows + i : r) * (size_t)D16 * (16 / sizeof(T)));
+  for (int c = threadIdx.x; c < D16; c += blockDim.x) d[c] = s[c];
+}
+
+template <typename T>
+static int rows_idx(const T* src, T* dst, const int* idx, long nidx, int per_batch, long src_batch_rows, long dst_batch_rows, int D, int scatter,
+                    hipStream_t st) {
+  const int per16 = 16 / (int)sizeof(T);
+  if (nidx <= 0 || per_batch <= 0 || D % per16 || (((uintptr_t)src | (uintptr_t)dst) & 15)) { set_error("rows_idx: bad shape/alignment"); return SMBV_ERR_SHAPE; }
+  if (scatter) hipLaunchKernelGGL((rows_idx_kernel<T, true>), dim3(nidx), dim3(64), 0, st, src, dst, idx, per_batch, src_batch_rows, dst_batch_rows, D / per16);
+  else hipLaunchKernelGGL((rows_idx_kernel<T, false>), dim3(nidx), dim3(64), 0, st, src, dst, idx, per_batch, src_batch_rows, dst_batch_rows, D / per16);
+  return check_launch("rows_idx");
+}
+
+// dst row idx[r] (per batch) <- vec  (mask-token rows of the predictor input)
+__global__ void fill_rows_idx_kernel(float* __restrict__ dst, const float* __restrict__ vec, const int* __restrict__ idx, int per_batch,
+                                     long dst_batch_rows, int D4) {
+  const long r = blockIdx.x;
+  f32x4* d = (f32x4*)(dst + ((r / per_batch) * dst_batch_rows + idx[r]) * (size_t)D4 * 4);
+  for (int c = threadIdx.x; c < D4; c += blockDim.x) d[c] = ((const f32x4*)vec)[c];
+}
+
+// dst[i] = src[(i / grp_in) * grp_out + i % grp_in]   (un-padding of head-padded gradients)
+__global__ void map_copy_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n, long grp_in, long grp_out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[(i / grp_in) * grp_out + i % grp_in];
+}
+int map_copy_f32(float* dst, const float* src, size_t n, long grp_in, long grp_out, hipStream_t st) {
+  if (!n) return SMBV_OK;
+  hipLaunchKernelGGL(map_copy_kernel, dim3((unsigned)std::min<size_t>(2048, (n + 255) / 256)), dim3(256), 0, st, dst, src, n, grp_in, grp_out);
+  return check_launch("map_copy");
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, size_t n4, float* __restrict__ part,
+                                                 float* __restrict__ dpred, const float* __restrict__ gscale, float coef) {
+  __shared__ float red[4];
+  float s = 0.f;
+  float gs = coef;
+  if (BWD && gscale) gs *= *gscale;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 d = ((const f32x4*)pred)[i] - ((const f32x4*)tgt)[i];
+    if (BWD) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; e++) o[e] = d[e] > 0.f ? gs : (d[e] < 0.f ? -gs : 0.f);   // sign(d) * g / n, sign(0) = 0 as torch
+      ((f32x4*)dpred)[i] = o;
+    } else {
+      s += (fabsf(d[0]) + fabsf(d[1])) + (fabsf(d[2]) + fabsf(d[3]));
+    }
+  }
+  if (!BWD) {
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+__global__ __launch_bounds__(256) void sum_scale2_kernel(const float* __restrict__ part, int n, float coef, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = (red[0] + red[1] + red[2] + red[3]) * coef;
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(const smbv_adam_chunk* __restrict__ chunks, float momentum) {
+  const smbv_adam_chunk c = chunks[blockIdx.x];   // p = target (k), g = online (q)
+  const float om = 1.0f - momentum;
+  const int n4 = c.n >> 2;
+  for (int i = threadIdx.x; i < n4; i += 256) ((f32x4*)c.p)[i] = ((f32x4*)c.p)[i] * momentum + ((const f32x4*)c.g)[i] * om;
+  for (int i = (n4 << 2) + threadIdx.x; i < c.n; i += 256) c.p[i] = c.p[i] * momentum + c.g[i] * om;
+}
+
+}  // namespace smbv
+
+using namespace smbv;
+
+extern "C" {
+
+int smbv_rope3d(smbv_bf16* qkv, int ld, int k_off, long rows, int S, int H, int head_stride, int Dh, int grid, const int32_t* pos, const float* table,
+                int transpose, smbv_stream stream) {
+  if (!qkv) { set_error("smbv_rope3d: null operand"); return SMBV_ERR_ARG; }
+  return rope3d(qkv, ld, k_off, rows, S, H, head_stride, Dh, grid, pos, table, transpose, (hipStream_t)stream);
+}
+int smbv_gather_rows_idx_f32(const float* src, float* dst, const int32_t* idx, long nidx, int per_batch, long src_batch_rows, int D, smbv_stream stream) {
+  return rows_idx<float>(src, dst, idx, nidx, per_batch, src_batch_rows, 0, D, 0, (hipStream_t)stream);
+}
+int smbv_scatter_rows_idx_f32(const float* src, float* dst, const int32_t* idx, long nidx, int per_batch, long dst_batch_rows, int D, smbv_stream stream) {
+  return rows_idx<float>(src, dst, idx, nidx, per_batch, 0, dst_batch_rows, D, 1, (hipStream_t)stream);
+}
+int smbv_fill_rows_idx_f32(float* dst, const float* vec, const int32_t* idx, long nidx, int per_batch, long dst_batch_rows, int D, smbv_stream stream) {
+  if (!dst || !vec || !idx || nidx <= 0 || (D & 3)) { set_error("smbv_fill_rows_idx_f32: bad argument"); return SMBV_ERR_ARG; }
+  hipLaunchKernelGGL(fill_rows_idx_kernel, dim3(nidx), dim3(64), 0, (hipStream_t)stream, dst, vec, idx, per_batch, dst_batch_rows, D / 4);
+  return check_launch("fill_rows_idx");
+}
+int smbv_l1_fwd(const float* pred, const float* target, size_t n, float* partial /*[1024]*/, float* loss, smbv_stream stream) {
+  if (!pred || !target || !partial || !loss || n == 0 || (n & 3)) { set_error("smbv_l1_fwd: bad argument (n %% 4)"); return SMBV_ERR_ARG; }
+  const int nb = (int)std::min<size_t>(1024, (n / 4 + 255) / 256);
+  hipLaunchKernelGGL(l1_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, pred, target, n / 4, partial, (float*)nullptr, (const float*)nullptr, 0.f);
+  int rc = check_launch("l1_fwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(sum_scale2_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, nb, 1.0f / (float)n, loss);
+  return check_launch("l1_reduce");
+}
+int smbv_l1_bwd(const float* pred, const float* target, size_t n, float* dpred, const float* gscale, smbv_stream stream) {
+  if (!pred || !target || !dpred || n == 0 || (n & 3)) { set_error("smbv_l1_bwd: bad argument"); return SMBV_ERR_ARG; }
+  const int nb = (int)std::min<size_t>(2048, (n / 4 + 255) / 256);
+  hipLaunchKernelGGL(l1_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, pred, target, n / 4, (float*)nullptr, dpred, gscale, 1.0f / (float)n);
+  return check_launch("l1_bwd");
+}
+int smbv_ema_update(const smbv_adam_chunk* chunks_dev, int nchunks, float momentum, smbv_stream stream) {
+  if (!chunks_dev || nchunks <= 0) { set_error("smbv_ema_update: bad argument"); return SMBV_ERR_ARG; }
+  hipLaunchKernelGGL(ema_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, chunks_dev, momentum);
+  return check_launch("ema");
+}
+
+}  // extern "C"
