@@ -196,6 +196,54 @@ int smbv_l1_bwd(const float* pred, const float* target, size_t n, float* dpred, 
 /* MomentumEncoder.update (run_vjepa.py:94-98): chunk.p (target) = m * chunk.p + (1 - m) * chunk.g (online); one launch. */
 int smbv_ema_update(const smbv_adam_chunk* chunks_dev, int nchunks, float momentum, smbv_stream stream);
 
+/* ---- the V-JEPA online-model step: VJEPA2Model.forward with context/target masks (modeling_vjepa.py:1081-1163) and its autograd ---- */
+
+typedef struct smbv_vjepa_cfg {
+  int B, T, H, W;                  /* pixel_values_videos fp32 [B,T,1,H,W], H == W == crop_size */
+  int ps, ts;                      /* patch_size, tubelet_size */
+  int N, Nctx, Ntgt;               /* tokens per volume; context / target tokens per volume */
+  int d, heads, ff, layers;        /* encoder: hidden_size, num_attention_heads, hidden_size*mlp_ratio, num_hidden_layers */
+  int pd, pheads, pff, players;    /* predictor: pred_hidden_size, pred_num_attention_heads, ..., pred_num_hidden_layers */
+  float ln_eps;                    /* config.layer_norm_eps (1e-6) */
+} smbv_vjepa_cfg;
+
+/* fp32 tensors of one VJEPA2Layer: norm1, attention.{query,key,value,proj}.{weight,bias}, norm2, mlp.{fc1,fc2} */
+typedef struct smbv_block_ptrs {
+  float *ln1_w, *ln1_b, *q_w, *k_w, *v_w, *q_b, *k_b, *v_b, *proj_w, *proj_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} smbv_block_ptrs;
+
+typedef struct smbv_vjepa_tensors {
+  float *pe_w, *pe_b;                         /* encoder.embeddings.patch_embeddings.proj_3d */
+  smbv_block_ptrs enc[SMBV_MAX_LAYERS];       /* encoder.layer.{i} */
+  float *enc_ln_w, *enc_ln_b;                 /* encoder.layernorm */
+  float *pemb_w, *pemb_b;                     /* predictor.embeddings.predictor_embeddings [pd,d] */
+  float *mask_token;                          /* the selected row of predictor.embeddings.mask_tokens: [pd] */
+  smbv_block_ptrs pred[SMBV_MAX_LAYERS];      /* predictor.layer.{i} */
+  float *pred_ln_w, *pred_ln_b;               /* predictor.layernorm */
+  float *pproj_w, *pproj_b;                   /* predictor.proj [d,pd] */
+} smbv_vjepa_tensors;
+
+typedef struct smbv_vjepa_io {
+  const float* pixel_values;       /* fp32 [B,T,1,H,W] */
+  const int32_t* all_idx;          /* int32 [B,N] = 0..N-1 per volume (brick ids) */
+  const int32_t* ctx_idx;          /* int32 [B,Nctx] context token ids */
+  const int32_t* tgt_idx;          /* int32 [B,Ntgt] target token ids */
+  const int32_t* pred_pos;         /* int32 [B,Nctx+Ntgt] position ids of the predictor sequence, sorted (modeling_vjepa.py:718-719) */
+  const int32_t* ctx_slot;         /* int32 [B,Nctx] row of each context token in the sorted predictor sequence */
+  const int32_t* tgt_slot;         /* int32 [B,Ntgt] row of each target token in the sorted predictor sequence */
+  const float* rope_enc;           /* fp32 [P][2][seg/2] cos|sin table for the encoder head_dim (see smbv_rope3d) */
+  const float* rope_pred;          /* same for the predictor head_dim */
+  float* enc_out;                  /* out: fp32 [B*N, d] last_hidden_state (after encoder.layernorm) */
+  float* pred_out;                 /* out: fp32 [B*Ntgt, d] predictor_output.last_hidden_state (NULL: encoder only = skip_predictor) */
+  const float* d_pred;             /* backward: fp32 [B*Ntgt, d] gradient w.r.t. pred_out */
+} smbv_vjepa_io;
+
+size_t smbv_vjepa_workspace_bytes(const smbv_vjepa_cfg* cfg);
+int smbv_vjepa_forward(const smbv_vjepa_cfg* cfg, const smbv_vjepa_tensors* params, const smbv_vjepa_io* io, void* ws, size_t ws_bytes,
+                       smbv_stream stream);
+int smbv_vjepa_backward(const smbv_vjepa_cfg* cfg, const smbv_vjepa_tensors* params, const smbv_vjepa_tensors* grads, const smbv_vjepa_io* io,
+                        void* ws, size_t ws_bytes, smbv_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,28 @@ class AdamHyper(C.Structure):
                 ("bias_corr1", C.c_float), ("bias_corr2", C.c_float), ("max_grad_norm", C.c_float)]
 
 
+class VjepaCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "T", "H", "W", "ps", "ts", "N", "Nctx", "Ntgt", "d", "heads", "ff", "layers", "pd", "pheads", "pff", "players")] + \
+               [("ln_eps", C.c_float)]
+
+
+BLOCK_FIELDS = ("ln1_w", "ln1_b", "q_w", "k_w", "v_w", "q_b", "k_b", "v_b", "proj_w", "proj_b", "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
+
+
+class BlockPtrs(C.Structure):
+    _fields_ = [(n, c_f) for n in BLOCK_FIELDS]
+
+
+class VjepaTensors(C.Structure):
+    _fields_ = [("pe_w", c_f), ("pe_b", c_f), ("enc", BlockPtrs * MAX_LAYERS), ("enc_ln_w", c_f), ("enc_ln_b", c_f), ("pemb_w", c_f), ("pemb_b", c_f),
+                ("mask_token", c_f), ("pred", BlockPtrs * MAX_LAYERS), ("pred_ln_w", c_f), ("pred_ln_b", c_f), ("pproj_w", c_f), ("pproj_b", c_f)]
+
+
+class VjepaIO(C.Structure):
+    _fields_ = [(n, c_f) for n in ("pixel_values", "all_idx", "ctx_idx", "tgt_idx", "pred_pos", "ctx_slot", "tgt_slot", "rope_enc", "rope_pred", "enc_out",
+                                   "pred_out", "d_pred")]
+
+
 _SIGS = {
     "smbv_version": (C.c_int, []),
     "smbv_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
@@ -84,6 +106,9 @@ _SIGS = {
     "smbv_l1_fwd": (C.c_int, [c_f, c_f, C.c_size_t, c_f, c_f, c_f]),
     "smbv_l1_bwd": (C.c_int, [c_f, c_f, C.c_size_t, c_f, c_f, c_f]),
     "smbv_ema_update": (C.c_int, [c_f, C.c_int, C.c_float, c_f]),
+    "smbv_vjepa_workspace_bytes": (C.c_size_t, [C.POINTER(VjepaCfg)]),
+    "smbv_vjepa_forward": (C.c_int, [C.POINTER(VjepaCfg), C.POINTER(VjepaTensors), C.POINTER(VjepaIO), c_f, C.c_size_t, c_f]),
+    "smbv_vjepa_backward": (C.c_int, [C.POINTER(VjepaCfg), C.POINTER(VjepaTensors), C.POINTER(VjepaTensors), C.POINTER(VjepaIO), c_f, C.c_size_t, c_f]),
     "smbv_mim_workspace_bytes": (C.c_size_t, [C.POINTER(MimCfg)]),
     "smbv_mim_forward": (C.c_int, [C.POINTER(MimCfg), C.POINTER(MimTensors), C.POINTER(MimIO), c_f, C.c_size_t, c_f]),
     "smbv_mim_backward": (C.c_int, [C.POINTER(MimCfg), C.POINTER(MimTensors), C.POINTER(MimTensors), C.POINTER(MimIO), c_f, C.c_size_t,

@@ -17,7 +17,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows, int D,
-                                                     float eps, long x_grp_in, long x_grp_out, long x_row_off) {
+                                                     float eps, long x_grp_in, long x_grp_out, long x_row_off, float* __restrict__ y32) {
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + w;
   if (row >= rows) return;
@@ -58,17 +58,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
       const f32x4 o = (v[i] - mu) * rs * g + b;
       u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
       ((u32x2*)yp)[c] = pk;
+      if (y32) ((f32x4*)(y32 + (size_t)row * D))[c] = o;
     }
   }
 }
 
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd, int rows, int D,
-                  float eps, long grp_in, long grp_out, long row_off, hipStream_t st) {
+                  float eps, long grp_in, long grp_out, long row_off, hipStream_t st, float* y32) {
   if (rows <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * LN_MAXV) { set_error("layernorm_fwd: need 0 < D <= %d, D %% 4 == 0 (D=%d rows=%d)", 64 * 4 * LN_MAXV, D, rows); return SMBV_ERR_SHAPE; }
   if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15 || ((uintptr_t)y & 7)) { set_error("layernorm_fwd: alignment"); return SMBV_ERR_ALIGN; }
   const int nv = cdiv(D, 256);
   dim3 grid(cdiv(rows, 4)), blk(256);
-#define LN_F(NV) hipLaunchKernelGGL(ln_fwd_kernel<NV>, grid, blk, 0, st, x, gamma, beta, y, mean, rstd, rows, D, eps, grp_in, grp_out, row_off)
+#define LN_F(NV) hipLaunchKernelGGL(ln_fwd_kernel<NV>, grid, blk, 0, st, x, gamma, beta, y, mean, rstd, rows, D, eps, grp_in, grp_out, row_off, y32)
   if (nv <= 1) LN_F(1); else if (nv <= 2) LN_F(2); else if (nv <= 3) LN_F(3); else if (nv <= 4) LN_F(4); else LN_F(8);
 #undef LN_F
   return check_launch("layernorm_fwd");

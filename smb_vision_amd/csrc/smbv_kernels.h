@@ -32,7 +32,7 @@ int gemm_tn(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int M, int N1, i
 size_t gemm_tn_workspace_bytes(int M, int N1, int N2);
 
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd, int rows, int D, float eps,
-                  long grp_in, long grp_out, long row_off, hipStream_t st);
+                  long grp_in, long grp_out, long row_off, hipStream_t st, float* y32 = nullptr);
 int layernorm_bwd(const bf16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
                   bf16_t* dx_bf16, float* dgamma, float* dbeta, int rows, int D, long grp_in, long grp_out, long row_off, void* ws,
                   size_t ws_bytes, hipStream_t st);
@@ -71,6 +71,11 @@ int reduce_cols(const float* part, int nrows, int ncols, float* out0, float* out
 
 int rope3d(bf16_t* qkv, int ld, int k_off, long rows, int S, int H, int hs, int Dh, int grid, const int* pos, const float* table, int transpose,
            hipStream_t st);
+int gather_rows_idx_bf16(const bf16_t* src, bf16_t* dst, const int* idx, long nidx, int per_batch, long src_batch_rows, int D, hipStream_t st);
+int scatter_rows_idx_bf16(const bf16_t* src, bf16_t* dst, const int* idx, long nidx, int per_batch, long dst_batch_rows, int D, hipStream_t st);
+int gather_rows_idx_f32(const float* src, float* dst, const int* idx, long nidx, int per_batch, long src_batch_rows, int D, hipStream_t st);
+int scatter_rows_idx_f32(const float* src, float* dst, const int* idx, long nidx, int per_batch, long dst_batch_rows, int D, hipStream_t st);
+int fill_rows_idx_f32(float* dst, const float* vec, const int* idx, long nidx, int per_batch, long dst_batch_rows, int D, hipStream_t st);
 int map_copy_f32(float* dst, const float* src, size_t n, long grp_in, long grp_out, hipStream_t st);
 
 }  // namespace smbv

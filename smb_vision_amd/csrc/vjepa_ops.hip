@@ -78,12 +78,31 @@ static int rows_idx(const T* src, T* dst, const int* idx, long nidx, int per_bat
   return check_launch("rows_idx");
 }
 
+int gather_rows_idx_bf16(const bf16_t* src, bf16_t* dst, const int* idx, long nidx, int per_batch, long src_batch_rows, int D, hipStream_t st) {
+  return rows_idx<bf16_t>(src, dst, idx, nidx, per_batch, src_batch_rows, 0, D, 0, st);
+}
+int scatter_rows_idx_bf16(const bf16_t* src, bf16_t* dst, const int* idx, long nidx, int per_batch, long dst_batch_rows, int D, hipStream_t st) {
+  return rows_idx<bf16_t>(src, dst, idx, nidx, per_batch, 0, dst_batch_rows, D, 1, st);
+}
+int scatter_rows_idx_f32(const float* src, float* dst, const int* idx, long nidx, int per_batch, long dst_batch_rows, int D, hipStream_t st) {
+  return rows_idx<float>(src, dst, idx, nidx, per_batch, 0, dst_batch_rows, D, 1, st);
+}
+int gather_rows_idx_f32(const float* src, float* dst, const int* idx, long nidx, int per_batch, long src_batch_rows, int D, hipStream_t st) {
+  return rows_idx<float>(src, dst, idx, nidx, per_batch, src_batch_rows, 0, D, 0, st);
+}
+
 // dst row idx[r] (per batch) <- vec  (mask-token rows of the predictor input)
 __global__ void fill_rows_idx_kernel(float* __restrict__ dst, const float* __restrict__ vec, const int* __restrict__ idx, int per_batch,
                                      long dst_batch_rows, int D4) {
   const long r = blockIdx.x;
   f32x4* d = (f32x4*)(dst + ((r / per_batch) * dst_batch_rows + idx[r]) * (size_t)D4 * 4);
   for (int c = threadIdx.x; c < D4; c += blockDim.x) d[c] = ((const f32x4*)vec)[c];
+}
+
+int fill_rows_idx_f32(float* dst, const float* vec, const int* idx, long nidx, int per_batch, long dst_batch_rows, int D, hipStream_t st) {
+  if (!dst || !vec || !idx || nidx <= 0 || (D & 3)) { set_error("fill_rows_idx_f32: bad argument"); return SMBV_ERR_ARG; }
+  hipLaunchKernelGGL(fill_rows_idx_kernel, dim3(nidx), dim3(64), 0, st, dst, vec, idx, per_batch, dst_batch_rows, D / 4);
+  return check_launch("fill_rows_idx");
 }
 
 // dst[i] = src[(i / grp_in) * grp_out + i % grp_in]   (un-padding of head-padded gradients)
@@ -158,9 +177,7 @@ int smbv_scatter_rows_idx_f32(const float* src, float* dst, const int32_t* idx, 
   return rows_idx<float>(src, dst, idx, nidx, per_batch, 0, dst_batch_rows, D, 1, (hipStream_t)stream);
 }
 int smbv_fill_rows_idx_f32(float* dst, const float* vec, const int32_t* idx, long nidx, int per_batch, long dst_batch_rows, int D, smbv_stream stream) {
-  if (!dst || !vec || !idx || nidx <= 0 || (D & 3)) { set_error("smbv_fill_rows_idx_f32: bad argument"); return SMBV_ERR_ARG; }
-  hipLaunchKernelGGL(fill_rows_idx_kernel, dim3(nidx), dim3(64), 0, (hipStream_t)stream, dst, vec, idx, per_batch, dst_batch_rows, D / 4);
-  return check_launch("fill_rows_idx");
+  return fill_rows_idx_f32(dst, vec, idx, nidx, per_batch, dst_batch_rows, D, (hipStream_t)stream);
 }
 int smbv_l1_fwd(const float* pred, const float* target, size_t n, float* partial /*[1024]*/, float* loss, smbv_stream stream) {
   if (!pred || !target || !partial || !loss || n == 0 || (n & 3)) { set_error("smbv_l1_fwd: bad argument (n %% 4)"); return SMBV_ERR_ARG; }

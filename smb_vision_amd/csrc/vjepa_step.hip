@@ -1,0 +1,242 @@
+// Host-side sequencing of the V-JEPA online-model step: VJEPA2Model.forward with context / target masks
+// (src/models/vjepa/modeling_vjepa.py:1081-1163 -> encoder :507-539, predictor :699-746) and its autograd, over the kernels of
+// this library.  The L1 loss against the EMA target encoder and the EMA update (src/run_vjepa.py:110-141) are separate entry
+// points (smbv_l1_*, smbv_ema_update) driven by the trainer mirror, exactly where the reference computes them.
+//
+// The encoder runs over ALL N tokens (no masking before it, :507-539).  The predictor sequence is held in position-sorted order
+// from the start (the reference concatenates [context, target] and then gathers by argsort, :718-719): context embeddings are
+// scattered to their slots, target slots are filled with the mask token, and RoPE takes the sorted position ids.
+// Predictor heads (head_dim 32 at the default 384/12) run zero-padded in 64-wide slots (block.h).
+#include "block.h"
+#include "../../include/smbv.h"
+
+namespace smbv {
+
+struct VjepaWs {
+  PrepJob* prep_table;
+  size_t prep_cap;
+  bf16_t *pe_w, *pemb, *pemb_t, *pproj, *pproj_t;
+  LayerWs enc[SMBV_MAX_LAYERS], pred[SMBV_MAX_LAYERS];
+  bf16_t* a_patch;
+  float* x[SMBV_MAX_LAYERS + 1];    // encoder residual stream [B*N, d]
+  float* xp[SMBV_MAX_LAYERS + 1];   // predictor residual stream [B*Sp, pd]
+  bf16_t *enc_ln, *ctx_bf, *pred_ln, *tgt_bf;
+  float *enc_mean, *enc_rstd, *pred_mean, *pred_rstd, *ctx_emb;
+  // backward
+  float *g0, *g1, *gtmp;
+  bf16_t *gb0, *gb1, *dpred_bf, *d_tgt, *d_lnfull, *d_ctx, *d_encctx;
+  BwdScratch sc;
+  size_t total;
+};
+
+static BlockDims venc_dims(const smbv_vjepa_cfg& c, const smbv_vjepa_io* io) {
+  BlockDims d; d.rows = (size_t)c.B * c.N; d.w = c.d; d.ff = c.ff; d.B = c.B; d.S = c.N; d.H = c.heads; d.Dh = c.d / c.heads; d.eps = c.ln_eps;
+  d.rope_grid = c.W / c.ps; d.pos = nullptr; d.rope_table = io ? io->rope_enc : nullptr;
+  return d;
+}
+static BlockDims vpred_dims(const smbv_vjepa_cfg& c, const smbv_vjepa_io* io) {
+  const int Sp = c.Nctx + c.Ntgt;
+  BlockDims d; d.rows = (size_t)c.B * Sp; d.w = c.pd; d.ff = c.pff; d.B = c.B; d.S = Sp; d.H = c.pheads; d.Dh = c.pd / c.pheads; d.eps = c.ln_eps;
+  d.rope_grid = c.W / c.ps; d.pos = io ? io->pred_pos : nullptr; d.rope_table = io ? io->rope_pred : nullptr;
+  return d;
+}
+static BlockPtrs vblock(const smbv_block_ptrs& p) {
+  BlockPtrs b;
+  b.ln1_w = p.ln1_w; b.ln1_b = p.ln1_b; b.q_w = p.q_w; b.k_w = p.k_w; b.v_w = p.v_w; b.q_b = p.q_b; b.k_b = p.k_b; b.v_b = p.v_b;
+  b.proj_w = p.proj_w; b.proj_b = p.proj_b; b.ln2_w = p.ln2_w; b.ln2_b = p.ln2_b; b.fc1_w = p.fc1_w; b.fc1_b = p.fc1_b; b.fc2_w = p.fc2_w; b.fc2_b = p.fc2_b;
+  return b;
+}
+
+static int vcheck(const smbv_vjepa_cfg& c) {
+  if (c.B <= 0 || c.layers <= 0 || c.players < 0 || c.layers > SMBV_MAX_LAYERS || c.players > SMBV_MAX_LAYERS) { set_error("vjepa: bad batch/layer counts"); return SMBV_ERR_SHAPE; }
+  if (c.ps <= 0 || c.ts <= 0 || c.T % c.ts || c.H % c.ps || c.W % c.ps || (c.ps & 3) || c.H != c.W) { set_error("vjepa: volume %dx%dx%d vs tubelet %d / patch %d (square crops only)", c.T, c.H, c.W, c.ts, c.ps); return SMBV_ERR_SHAPE; }
+  const int N = (c.T / c.ts) * (c.H / c.ps) * (c.W / c.ps);
+  if (c.N != N || c.Nctx <= 0 || c.Ntgt <= 0 || c.Nctx > N || c.Ntgt > N) { set_error("vjepa: token counts N=%d Nctx=%d Ntgt=%d inconsistent (%d)", c.N, c.Nctx, c.Ntgt, N); return SMBV_ERR_SHAPE; }
+  if (c.d % c.heads || c.pd % c.pheads) { set_error("vjepa: width not divisible by heads"); return SMBV_ERR_SHAPE; }
+  const int dh = c.d / c.heads, pdh = c.pd / c.pheads;
+  if (dh > 64 || pdh > 64 || (dh & 7) || (pdh & 7)) { set_error("vjepa: head_dim must be a multiple of 8 and <= 64 (got %d / %d)", dh, pdh); return SMBV_ERR_SHAPE; }
+  if ((c.d & 7) || (c.pd & 7) || (c.ff & 7) || (c.pff & 7) || ((c.ts * c.ps * c.ps) & 7)) { set_error("vjepa: widths must be multiples of 8"); return SMBV_ERR_SHAPE; }
+  return SMBV_OK;
+}
+
+static void vcarve(const smbv_vjepa_cfg& c, void* base, VjepaWs& w) {
+  Carver cv{(char*)base};
+  const int K = c.ts * c.ps * c.ps;
+  const BlockDims de = venc_dims(c, nullptr), dp = vpred_dims(c, nullptr);
+  const size_t Re = de.rows, Rp = dp.rows, Rc = (size_t)c.B * c.Nctx, Rt = (size_t)c.B * c.Ntgt;
+  w.prep_cap = 16 + (size_t)c.layers * layer_prep_job_count(de) + (size_t)c.players * layer_prep_job_count(dp);
+  w.prep_table = cv.take<PrepJob>(w.prep_cap);
+  w.pe_w = cv.take<bf16_t>((size_t)c.d * K);
+  w.pemb = cv.take<bf16_t>((size_t)c.pd * c.d);
+  w.pemb_t = cv.take<bf16_t>((size_t)c.pd * c.d);
+  w.pproj = cv.take<bf16_t>((size_t)c.pd * c.d);
+  w.pproj_t = cv.take<bf16_t>((size_t)c.pd * c.d);
+  for (int l = 0; l < c.layers; l++) carve_layer(cv, w.enc[l], de);
+  for (int l = 0; l < c.players; l++) carve_layer(cv, w.pred[l], dp);
+  w.a_patch = cv.take<bf16_t>(Re * K);
+  for (int l = 0; l <= c.layers; l++) w.x[l] = cv.take<float>(Re * c.d);
+  for (int l = 0; l <= c.players; l++) w.xp[l] = cv.take<float>(Rp * c.pd);
+  w.enc_ln = cv.take<bf16_t>(Re * c.d);
+  w.enc_mean = cv.take<float>(Re);
+  w.enc_rstd = cv.take<float>(Re);
+  w.ctx_bf = cv.take<bf16_t>(Rc * c.d);
+  w.ctx_emb = cv.take<float>(Rc * c.pd);
+  w.pred_ln = cv.take<bf16_t>(Rp * c.pd);
+  w.pred_mean = cv.take<float>(Rp);
+  w.pred_rstd = cv.take<float>(Rp);
+  w.tgt_bf = cv.take<bf16_t>(Rt * c.pd);
+  const size_t gw = std::max(Re * c.d, Rp * c.pd);
+  w.g0 = cv.take<float>(gw);
+  w.g1 = cv.take<float>(gw);
+  w.gb0 = cv.take<bf16_t>(gw);
+  w.gb1 = cv.take<bf16_t>(gw);
+  w.gtmp = cv.take<float>(Rt * c.pd);
+  w.dpred_bf = cv.take<bf16_t>(Rt * c.d);
+  w.d_tgt = cv.take<bf16_t>(Rt * c.pd);
+  w.d_lnfull = cv.take<bf16_t>(gw);
+  w.d_ctx = cv.take<bf16_t>(Rc * c.pd);
+  w.d_encctx = cv.take<bf16_t>(Rc * c.d);
+  size_t act = 0, we = 0, qkv = 0, gpad = 0, sb = 0, delta = 0;
+  bwd_scratch_requirements(de, act, we, qkv, gpad, sb, delta);
+  bwd_scratch_requirements(dp, act, we, qkv, gpad, sb, delta);
+  auto tn = [&](size_t M, int n1, int n2) { sb = std::max(sb, gemm_tn_workspace_bytes((int)M, n1, n2)); };
+  tn(Re, c.d, K); tn(Rc, c.pd, c.d); tn(Rt, c.d, c.pd);
+  sb = std::max(sb, colsum_workspace_bytes((int)std::max(Re, Rp), std::max(std::max(c.d, c.pd), K)));
+  w.sc.d_act = cv.take<bf16_t>(act);
+  w.sc.d_ln = cv.take<bf16_t>(we);
+  w.sc.d_o = cv.take<bf16_t>(we);
+  w.sc.d_qkv = cv.take<bf16_t>(qkv);
+  w.sc.gath0 = nullptr;
+  w.sc.gath1 = nullptr;
+  w.sc.delta = cv.take<float>(delta);
+  w.sc.gpad = gpad ? cv.take<float>(gpad) : nullptr;
+  w.sc.scratch = cv.take<char>(sb);
+  w.sc.scratch_bytes = sb;
+  w.total = (cv.off + 255) & ~(size_t)255;
+}
+
+static int vjepa_forward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, const smbv_vjepa_io& io, void* ws, size_t ws_bytes, hipStream_t st) {
+  RC(vcheck(c));
+  VjepaWs W;
+  vcarve(c, ws, W);
+  if (!ws || ws_bytes < W.total || ((uintptr_t)ws & 255)) { set_error("vjepa_forward: workspace too small or misaligned (%zu < %zu)", ws_bytes, W.total); return SMBV_ERR_WORKSPACE; }
+  const bool with_pred = io.pred_out != nullptr;
+  if (!io.pixel_values || !io.all_idx || !io.rope_enc || !io.enc_out) { set_error("vjepa_forward: null io pointer"); return SMBV_ERR_ARG; }
+  if (with_pred && (!io.ctx_idx || !io.tgt_idx || !io.pred_pos || !io.ctx_slot || !io.tgt_slot || !io.rope_pred || c.players <= 0)) { set_error("vjepa_forward: predictor inputs missing"); return SMBV_ERR_ARG; }
+  const int K = c.ts * c.ps * c.ps;
+  const BlockDims de = venc_dims(c, &io), dp = vpred_dims(c, &io);
+  const size_t Re = de.rows, Rp = dp.rows, Rc = (size_t)c.B * c.Nctx, Rt = (size_t)c.B * c.Ntgt;
+  const int Sp = c.Nctx + c.Ntgt;
+  {
+    PrepList pl;
+    pl.cast(p.pe_w, W.pe_w, c.d, K);
+    for (int l = 0; l < c.layers; l++) RC(prep_layer(pl, vblock(p.enc[l]), W.enc[l], de, st));
+    if (with_pred) {
+      pl.cast(p.pemb_w, W.pemb, c.pd, c.d);
+      pl.tcast(p.pemb_w, W.pemb_t, c.pd, c.d, c.pd);
+      pl.cast(p.pproj_w, W.pproj, c.d, c.pd);
+      pl.tcast(p.pproj_w, W.pproj_t, c.d, c.pd, c.d);
+      for (int l = 0; l < c.players; l++) RC(prep_layer(pl, vblock(p.pred[l]), W.pred[l], dp, st));
+    }
+    if (pl.jobs.size() > W.prep_cap) { set_error("vjepa_forward: prep table overflow"); return SMBV_ERR_WORKSPACE; }
+    HIPRC(hipMemcpyAsync(W.prep_table, pl.jobs.data(), pl.jobs.size() * sizeof(PrepJob), hipMemcpyHostToDevice, st));
+    RC(prep_weights(W.prep_table, (int)pl.jobs.size(), pl.tiles, st));
+  }
+  // encoder over all N tokens: Conv3d patch embedding (+bias, no position table: RoPE instead), L blocks, final LayerNorm
+  RC(gather_bricks(io.pixel_values, io.all_idx, (int)Re, c.N, W.a_patch, c.T, c.H, c.W, c.ts, c.ps, st));
+  {
+    GemmEpi e; e.bias = p.pe_b; e.out_f32 = W.x[0]; e.ld_of = c.d;
+    RC(gemm_nt(W.a_patch, K, W.pe_w, K, (int)Re, c.d, K, e, st));
+  }
+  for (int l = 0; l < c.layers; l++) RC(layer_fwd(vblock(p.enc[l]), W.enc[l], de, W.sc, W.x[l], W.x[l + 1], nullptr, 0, 0, st));
+  RC(layernorm_fwd(W.x[c.layers], p.enc_ln_w, p.enc_ln_b, W.enc_ln, W.enc_mean, W.enc_rstd, (int)Re, c.d, c.ln_eps, 0, 0, 0, st, io.enc_out));
+  if (!with_pred) return SMBV_OK;
+  // predictor: context rows -> Linear(d -> pd) -> their slots of the position-sorted sequence; target slots <- mask token
+  RC(gather_rows_idx_bf16(W.enc_ln, W.ctx_bf, io.ctx_idx, (long)Rc, c.Nctx, c.N, c.d, st));
+  {
+    GemmEpi e; e.bias = p.pemb_b; e.out_f32 = W.ctx_emb; e.ld_of = c.pd;
+    RC(gemm_nt(W.ctx_bf, c.d, W.pemb, c.d, (int)Rc, c.pd, c.d, e, st));
+  }
+  RC(scatter_rows_idx_f32(W.ctx_emb, W.xp[0], io.ctx_slot, (long)Rc, c.Nctx, Sp, c.pd, st));
+  RC(fill_rows_idx_f32(W.xp[0], p.mask_token, io.tgt_slot, (long)Rt, c.Ntgt, Sp, c.pd, st));
+  for (int l = 0; l < c.players; l++) RC(layer_fwd(vblock(p.pred[l]), W.pred[l], dp, W.sc, W.xp[l], W.xp[l + 1], nullptr, 0, 0, st));
+  RC(layernorm_fwd(W.xp[c.players], p.pred_ln_w, p.pred_ln_b, W.pred_ln, W.pred_mean, W.pred_rstd, (int)Rp, c.pd, c.ln_eps, 0, 0, 0, st));
+  // unsort + keep the target tokens (:737-738) == gather the target slots; then proj (pd -> d)
+  RC(gather_rows_idx_bf16(W.pred_ln, W.tgt_bf, io.tgt_slot, (long)Rt, c.Ntgt, Sp, c.pd, st));
+  {
+    GemmEpi e; e.bias = p.pproj_b; e.out_f32 = io.pred_out; e.ld_of = c.d;
+    RC(gemm_nt(W.tgt_bf, c.pd, W.pproj, c.pd, (int)Rt, c.d, c.pd, e, st));
+  }
+  return SMBV_OK;
+}
+
+static int vjepa_backward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, const smbv_vjepa_tensors& gr, const smbv_vjepa_io& io, void* ws,
+                          size_t ws_bytes, hipStream_t st) {
+  RC(vcheck(c));
+  VjepaWs W;
+  vcarve(c, ws, W);
+  if (!ws || ws_bytes < W.total || ((uintptr_t)ws & 255)) { set_error("vjepa_backward: workspace too small or misaligned"); return SMBV_ERR_WORKSPACE; }
+  if (!io.d_pred || !io.tgt_slot || !io.ctx_slot || !io.ctx_idx) { set_error("vjepa_backward: null io pointer"); return SMBV_ERR_ARG; }
+  const int K = c.ts * c.ps * c.ps;
+  const BlockDims de = venc_dims(c, &io), dp = vpred_dims(c, &io);
+  const size_t Re = de.rows, Rp = dp.rows, Rc = (size_t)c.B * c.Nctx, Rt = (size_t)c.B * c.Ntgt;
+  const int Sp = c.Nctx + c.Ntgt;
+  // predictor.proj
+  RC(cast_f32_bf16(io.d_pred, W.dpred_bf, Rt * c.d, st));
+  RC(colsum_bf16(W.dpred_bf, c.d, (int)Rt, c.d, gr.pproj_b, 0, 0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
+  RC(gemm_tn(W.dpred_bf, c.d, W.tgt_bf, c.pd, (int)Rt, c.d, c.pd, gr.pproj_w, W.sc.scratch, W.sc.scratch_bytes, st));
+  {
+    GemmEpi e; e.out_bf16 = W.d_tgt; e.ld_ob = c.pd;
+    RC(gemm_nt(W.dpred_bf, c.d, W.pproj_t, c.d, (int)Rt, c.pd, c.d, e, st));
+  }
+  // predictor.layernorm: only the target slots receive gradient
+  HIPRC(hipMemsetAsync(W.d_lnfull, 0, Rp * c.pd * sizeof(bf16_t), st));
+  RC(scatter_rows_idx_bf16(W.d_tgt, W.d_lnfull, io.tgt_slot, (long)Rt, c.Ntgt, Sp, c.pd, st));
+  RC(layernorm_bwd(W.d_lnfull, W.xp[c.players], W.pred_mean, W.pred_rstd, p.pred_ln_w, nullptr, W.g0, W.gb0, gr.pred_ln_w, gr.pred_ln_b, (int)Rp, c.pd, 0,
+                   0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
+  for (int l = c.players - 1; l >= 0; l--)
+    RC(layer_bwd(vblock(p.pred[l]), vblock(gr.pred[l]), W.pred[l], dp, W.sc, W.xp[l], W.g0, W.gb0, W.g1, W.gb1, 0, 0, st));
+  // predictor input: mask-token gradient = sum over the target slots; context slots flow into predictor_embeddings
+  RC(gather_rows_idx_f32(W.g0, W.gtmp, io.tgt_slot, (long)Rt, c.Ntgt, Sp, c.pd, st));
+  RC(colsum_f32(W.gtmp, c.pd, (int)Rt, c.pd, gr.mask_token, 0, 0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
+  RC(gather_rows_idx_bf16(W.gb0, W.d_ctx, io.ctx_slot, (long)Rc, c.Nctx, Sp, c.pd, st));
+  RC(colsum_bf16(W.d_ctx, c.pd, (int)Rc, c.pd, gr.pemb_b, 0, 0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
+  RC(gemm_tn(W.d_ctx, c.pd, W.ctx_bf, c.d, (int)Rc, c.pd, c.d, gr.pemb_w, W.sc.scratch, W.sc.scratch_bytes, st));
+  {
+    GemmEpi e; e.out_bf16 = W.d_encctx; e.ld_ob = c.d;
+    RC(gemm_nt(W.d_ctx, c.pd, W.pemb_t, c.pd, (int)Rc, c.d, c.pd, e, st));
+  }
+  // encoder.layernorm: only the context tokens receive gradient
+  HIPRC(hipMemsetAsync(W.d_lnfull, 0, Re * c.d * sizeof(bf16_t), st));
+  RC(scatter_rows_idx_bf16(W.d_encctx, W.d_lnfull, io.ctx_idx, (long)Rc, c.Nctx, c.N, c.d, st));
+  RC(layernorm_bwd(W.d_lnfull, W.x[c.layers], W.enc_mean, W.enc_rstd, p.enc_ln_w, nullptr, W.g0, W.gb0, gr.enc_ln_w, gr.enc_ln_b, (int)Re, c.d, 0, 0, 0,
+                   W.sc.scratch, W.sc.scratch_bytes, st));
+  for (int l = c.layers - 1; l >= 0; l--)
+    RC(layer_bwd(vblock(p.enc[l]), vblock(gr.enc[l]), W.enc[l], de, W.sc, W.x[l], W.g0, W.gb0, W.g1, W.gb1, 0, 0, st));
+  // patch embedding
+  RC(colsum_bf16(W.gb0, c.d, (int)Re, c.d, gr.pe_b, 0, 0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
+  RC(gemm_tn(W.gb0, c.d, W.a_patch, K, (int)Re, c.d, K, gr.pe_w, W.sc.scratch, W.sc.scratch_bytes, st));
+  return SMBV_OK;
+}
+
+}  // namespace smbv
+
+extern "C" {
+
+size_t smbv_vjepa_workspace_bytes(const smbv_vjepa_cfg* cfg) {
+  if (!cfg || smbv::vcheck(*cfg)) return 0;
+  smbv::VjepaWs W;
+  smbv::vcarve(*cfg, nullptr, W);
+  return W.total;
+}
+int smbv_vjepa_forward(const smbv_vjepa_cfg* cfg, const smbv_vjepa_tensors* params, const smbv_vjepa_io* io, void* ws, size_t ws_bytes, smbv_stream stream) {
+  if (!cfg || !params || !io) { smbv::set_error("smbv_vjepa_forward: null argument"); return SMBV_ERR_ARG; }
+  return smbv::vjepa_forward(*cfg, *params, *io, ws, ws_bytes, (hipStream_t)stream);
+}
+int smbv_vjepa_backward(const smbv_vjepa_cfg* cfg, const smbv_vjepa_tensors* params, const smbv_vjepa_tensors* grads, const smbv_vjepa_io* io, void* ws,
+                        size_t ws_bytes, smbv_stream stream) {
+  if (!cfg || !params || !grads || !io) { smbv::set_error("smbv_vjepa_backward: null argument"); return SMBV_ERR_ARG; }
+  return smbv::vjepa_backward(*cfg, *params, *grads, *io, ws, ws_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,432 @@
+"""``SmbVJEPA2Model`` — MI355X-native drop-in for the model class ``src/run_vjepa.py`` trains, plus the trainer-side pieces.
+
+Host-side mirror of the reference's ``VJEPA2Model`` (``src/models/vjepa/modeling_vjepa.py:1065-1167``; encoder + predictor; the
+attentive pooler / classifier of that file are off the pre-training path): ``Cls(config: VJEPA2Config)``, ``forward(
+pixel_values_videos, context_mask=[idx], target_mask=[idx], skip_predictor=...)`` -> object with ``last_hidden_state``,
+``masked_hidden_state``, ``target_hidden_state`` and ``predictor_output.last_hidden_state``; same state-dict names
+(``encoder.embeddings.patch_embeddings.proj_3d.*``, ``encoder.layer.{i}.{norm1,attention.{query,key,value,proj},norm2,mlp.{fc1,fc2}}.*``,
+``encoder.layernorm.*``, ``predictor.embeddings.{predictor_embeddings.*,mask_tokens}``, ``predictor.layer.{i}.*``,
+``predictor.layernorm.*``, ``predictor.proj.*``) and the same ``parameters()`` order, which ``MomentumEncoder.update`` zips
+(``run_vjepa.py:97``).  The arithmetic runs in libsmbv.so (``smbv_vjepa_forward`` / ``smbv_vjepa_backward``); no CPU fallback.
+
+``vjepa_loss`` / ``MomentumEncoder`` mirror ``VJEPATrainer.compute_loss`` and ``MomentumEncoder.update`` (``run_vjepa.py:87-141``)
+with the L1 loss and the EMA as HIP kernels (``smbv_l1_*``, ``smbv_ema_update``).
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+import weakref
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import torch
+from torch import nn
+from transformers import PreTrainedModel, VJEPA2Config
+from transformers.utils import ModelOutput
+
+from . import _lib
+from .optim import CHUNK
+
+
+@dataclass
+class SmbVJEPA2PredictorOutput(ModelOutput):
+    last_hidden_state: Optional[torch.Tensor] = None
+    target_hidden_state: Optional[torch.Tensor] = None
+
+
+@dataclass
+class SmbVJEPA2ModelOutput(ModelOutput):
+    last_hidden_state: Optional[torch.Tensor] = None
+    masked_hidden_state: Optional[torch.Tensor] = None
+    target_hidden_state: Optional[torch.Tensor] = None
+    predictor_output: Optional[SmbVJEPA2PredictorOutput] = None
+
+
+_BLOCK = (("norm1.weight", "ln1_w", "w"), ("norm1.bias", "ln1_b", "w"),
+          ("attention.query.weight", "q_w", "ww"), ("attention.query.bias", "q_b", "w"),
+          ("attention.key.weight", "k_w", "ww"), ("attention.key.bias", "k_b", "w"),
+          ("attention.value.weight", "v_w", "ww"), ("attention.value.bias", "v_b", "w"),
+          ("attention.proj.weight", "proj_w", "ww"), ("attention.proj.bias", "proj_b", "w"),
+          ("norm2.weight", "ln2_w", "w"), ("norm2.bias", "ln2_b", "w"),
+          ("mlp.fc1.weight", "fc1_w", "fw"), ("mlp.fc1.bias", "fc1_b", "f"), ("mlp.fc2.weight", "fc2_w", "wf"), ("mlp.fc2.bias", "fc2_b", "w"))
+
+
+def param_table(cfg) -> "list[tuple[str, tuple, tuple]]":
+    """[(state-dict name, shape, C-struct path)] in the reference's parameters() order."""
+    d, pd = cfg.hidden_size, cfg.pred_hidden_size
+    ff, pff = int(d * cfg.mlp_ratio), int(pd * cfg.pred_mlp_ratio)
+    out = [("encoder.embeddings.patch_embeddings.proj_3d.weight", (d, cfg.in_chans, cfg.tubelet_size, cfg.patch_size, cfg.patch_size), ("pe_w",)),
+           ("encoder.embeddings.patch_embeddings.proj_3d.bias", (d,), ("pe_b",))]
+
+    def block(prefix, grp, i, w, f):
+        shp = {"w": (w,), "ww": (w, w), "fw": (f, w), "f": (f,), "wf": (w, f)}
+        for suf, field, code in _BLOCK:
+            out.append((prefix + suf, shp[code], (grp, i, field)))
+
+    for i in range(cfg.num_hidden_layers):
+        block(f"encoder.layer.{i}.", "enc", i, d, ff)
+    out += [("encoder.layernorm.weight", (d,), ("enc_ln_w",)), ("encoder.layernorm.bias", (d,), ("enc_ln_b",)),
+            ("predictor.embeddings.mask_tokens", (cfg.pred_num_mask_tokens, 1, 1, pd), ("mask_tokens",)),
+            ("predictor.embeddings.predictor_embeddings.weight", (pd, d), ("pemb_w",)),
+            ("predictor.embeddings.predictor_embeddings.bias", (pd,), ("pemb_b",))]
+    for i in range(cfg.pred_num_hidden_layers):
+        block(f"predictor.layer.{i}.", "pred", i, pd, pff)
+    out += [("predictor.layernorm.weight", (pd,), ("pred_ln_w",)), ("predictor.layernorm.bias", (pd,), ("pred_ln_b",)),
+            ("predictor.proj.weight", (d, pd), ("pproj_w",)), ("predictor.proj.bias", (d,), ("pproj_b",))]
+    return out
+
+
+class _Slots(nn.Module):
+    """Pure parameter container (reproduces the reference's state-dict names)."""
+
+
+def _register(root, dotted, p):
+    mod = root
+    parts = dotted.split(".")
+    for part in parts[:-1]:
+        if part not in mod._modules:
+            mod.add_module(part, _Slots())
+        mod = mod._modules[part]
+    mod.register_parameter(parts[-1], p)
+
+
+def rope_table(head_dim: int, max_pos: int, device) -> torch.Tensor:
+    """fp32 [max_pos][2][seg/2]: cos | sin of pos * 10000^(-j/(seg/2)) (modeling_vjepa.py:204-217 with D = the segment size)."""
+    seg = 2 * ((head_dim // 3) // 2)
+    half = max(seg // 2, 1)
+    omega = 1.0 / 10000 ** (torch.arange(half, dtype=torch.float32) / float(half))
+    ang = torch.arange(max_pos, dtype=torch.float32)[:, None] * omega[None, :]
+    return torch.stack([ang.cos(), ang.sin()], dim=1).contiguous().to(device)
+
+
+class _VJEPAFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model_ref, pix, idx, with_pred, *params):
+        model = model_ref()
+        enc_out, pred_out, st = model._run_forward(pix, idx, with_pred)
+        ctx.model_ref, ctx.st = model_ref, st
+        ctx.set_materialize_grads(False)
+        if pred_out is None:
+            pred_out = enc_out.new_zeros(())
+            ctx.mark_non_differentiable(pred_out)
+        return enc_out, pred_out
+
+    @staticmethod
+    def backward(ctx, d_enc, d_pred):
+        model = ctx.model_ref()
+        n = len(model._table)
+        if d_enc is not None:
+            raise NotImplementedError("smb_vision_amd: gradients through last_hidden_state are not implemented (the V-JEPA loss only uses predictor_output)")
+        if d_pred is None:
+            return (None,) * (4 + n)
+        return (None, None, None, None, *model._run_backward(ctx.st, d_pred))
+
+
+class SmbVJEPA2Model(PreTrainedModel):
+    config_class = VJEPA2Config
+    base_model_prefix = "vjepa2"
+    main_input_name = "pixel_values_videos"
+    supports_gradient_checkpointing = True
+    _supports_sdpa = True
+    _supports_flash_attn = True
+    _supports_attention_backend = True
+
+    def __init__(self, config: VJEPA2Config):
+        super().__init__(config)
+        self.config = config
+        if config.in_chans != 1:
+            raise ValueError("smb_vision_amd: the MI355X V-JEPA path is built for single-channel volumes (in_chans=1, run_vjepa.py:225)")
+        if not config.qkv_bias or config.hidden_act != "gelu" or config.drop_path_rate != 0.0:
+            raise ValueError("smb_vision_amd: qkv_bias=True, hidden_act='gelu', drop_path_rate=0 only")
+        self._table = param_table(config)
+        for name, shape, _ in self._table:
+            _register(self, name, nn.Parameter(torch.empty(shape)))
+        self.gradient_checkpointing = False
+        self.mask_index = 1  # VJEPA2PredictorEmbeddings.forward default (modeling_vjepa.py:593)
+        self._gflat = self._structs = self._ws = self._ws_key = self._rope = None
+        self._fwd_count = 0
+        self.reset_parameters()
+        self.post_init()
+
+    # -- parameters ----------------------------------------------------------------------------------------------------
+    def reset_parameters(self):
+        """_init_weights of the reference (:1015-1046): trunc_normal(std) for Linear/Conv3d weights, zero biases, LayerNorm 1/0,
+        mask tokens zero (pred_zero_init_mask_tokens) or trunc_normal."""
+        std = self.config.initializer_range
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if name.endswith("mask_tokens"):
+                    p.zero_() if self.config.pred_zero_init_mask_tokens else nn.init.trunc_normal_(p, mean=0.0, std=std)
+                elif name.endswith("weight") and p.dim() >= 2:
+                    nn.init.trunc_normal_(p, mean=0.0, std=std)
+                elif "norm" in name and name.endswith("weight"):
+                    p.fill_(1.0)
+                else:
+                    p.zero_()
+
+    def _init_weights(self, module):
+        if not isinstance(module, _Slots) and module is not self:
+            return
+        names = {id(p): n for n, p in self.named_parameters()}
+        std = self.config.initializer_range
+        with torch.no_grad():
+            for _, p in module.named_parameters(recurse=False):
+                if getattr(p, "_is_hf_initialized", False):
+                    continue
+                n = names.get(id(p), "")
+                if n.endswith("mask_tokens"):
+                    p.zero_() if self.config.pred_zero_init_mask_tokens else nn.init.trunc_normal_(p, mean=0.0, std=std)
+                elif n.endswith("weight") and p.dim() >= 2:
+                    nn.init.trunc_normal_(p, mean=0.0, std=std)
+                elif "norm" in n and n.endswith("weight"):
+                    p.fill_(1.0)
+                else:
+                    p.zero_()
+
+    def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None):
+        self.gradient_checkpointing = True  # accepted; activations stay resident
+
+    def gradient_checkpointing_disable(self):
+        self.gradient_checkpointing = False
+
+    def _ordered_params(self):
+        sd = dict(self.named_parameters())
+        return [sd[n] for n, _, _ in self._table]
+
+    # -- geometry ------------------------------------------------------------------------------------------------------
+    @property
+    def num_patches(self):
+        c = self.config
+        return (c.frames_per_clip // c.tubelet_size) * (c.crop_size // c.patch_size) ** 2
+
+    def _cfg_struct(self, B, n_ctx, n_tgt):
+        c = self.config
+        s = _lib.VjepaCfg()
+        s.B, s.T, s.H, s.W, s.ps, s.ts = B, c.frames_per_clip, c.crop_size, c.crop_size, c.patch_size, c.tubelet_size
+        s.N, s.Nctx, s.Ntgt = self.num_patches, n_ctx, n_tgt
+        s.d, s.heads, s.ff, s.layers = c.hidden_size, c.num_attention_heads, int(c.hidden_size * c.mlp_ratio), c.num_hidden_layers
+        s.pd, s.pheads, s.pff, s.players = (c.pred_hidden_size, c.pred_num_attention_heads, int(c.pred_hidden_size * c.pred_mlp_ratio),
+                                            c.pred_num_hidden_layers)
+        s.ln_eps = c.layer_norm_eps
+        return s
+
+    def _ensure_device_state(self, device):
+        params = self._ordered_params()
+        for p in params:
+            if p.device != device or p.dtype != torch.float32 or not p.is_contiguous():
+                raise _lib.SmbvError("smb_vision_amd: parameters must be contiguous fp32 tensors on the input's HIP device")
+        c = self.config
+        if self._rope is None or self._rope[0].device != device:
+            maxpos = max(c.frames_per_clip // c.tubelet_size, c.crop_size // c.patch_size) + 1
+            self._rope = (rope_table(c.hidden_size // c.num_attention_heads, maxpos, device),
+                          rope_table(c.pred_hidden_size // c.pred_num_attention_heads, maxpos, device))
+        if self._gflat is None or self._gflat.device != device:
+            offs, off = [], 0
+            for p in params:
+                offs.append(off)
+                off += (p.numel() + 63) // 64 * 64
+            self._goffs = offs
+            self._gflat = torch.zeros(off, dtype=torch.float32, device=device)
+            self._structs = None
+        sig = tuple(p.data_ptr() for p in params)
+        if self._structs is None or self._structs[0] != sig:
+            ps, gs = _lib.VjepaTensors(), _lib.VjepaTensors()
+            gbase = self._gflat.data_ptr()
+            pd = c.pred_hidden_size
+            mi = self.mask_index % c.pred_num_mask_tokens
+            for p, off, (_, _, path) in zip(params, self._goffs, self._table):
+                pp, gp = p.data_ptr(), gbase + 4 * off
+                if path == ("mask_tokens",):   # only the selected token row takes part; the other rows get zero gradient
+                    ps.mask_token, gs.mask_token = pp + 4 * mi * pd, gp + 4 * mi * pd
+                elif len(path) == 1:
+                    setattr(ps, path[0], pp), setattr(gs, path[0], gp)
+                else:
+                    setattr(getattr(ps, path[0])[path[1]], path[2], pp), setattr(getattr(gs, path[0])[path[1]], path[2], gp)
+            self._structs = (sig, ps, gs)
+        return params
+
+    def grad_views(self):
+        return [self._gflat[o:o + p.numel()].view(p.shape) for p, o in zip(self._ordered_params(), self._goffs)]
+
+    # -- the step ------------------------------------------------------------------------------------------------------
+    def _index_plumbing(self, cm, tm, device):
+        """Sorted predictor sequence (modeling_vjepa.py:718-719): positions, and the slot of every context / target token."""
+        B, N = cm.shape[0], self.num_patches
+        all_idx = torch.arange(N, device=device, dtype=torch.int32).repeat(B, 1).contiguous()
+        pos = torch.cat([cm, tm], dim=1)
+        order = torch.argsort(pos, dim=1, stable=True)
+        rev = torch.argsort(order, dim=1, stable=True)
+        n_ctx = cm.shape[1]
+        return dict(all_idx=all_idx, ctx_idx=cm.to(torch.int32).contiguous(), tgt_idx=tm.to(torch.int32).contiguous(),
+                    pred_pos=torch.gather(pos, 1, order).to(torch.int32).contiguous(), ctx_slot=rev[:, :n_ctx].to(torch.int32).contiguous(),
+                    tgt_slot=rev[:, n_ctx:].to(torch.int32).contiguous())
+
+    def _run_forward(self, pix, idx, with_pred):
+        lib = _lib.load()
+        dev = pix.device
+        B = pix.shape[0]
+        n_ctx, n_tgt = idx["ctx_idx"].shape[1], idx["tgt_idx"].shape[1]
+        cfg = self._cfg_struct(B, n_ctx, n_tgt)
+        need = lib.smbv_vjepa_workspace_bytes(C.byref(cfg))
+        if need == 0:
+            raise ValueError("smbv_vjepa_workspace_bytes: " + _lib.last_error())
+        key = (B, n_ctx, n_tgt, dev)
+        if self._ws is None or self._ws_key != key or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._ws_key = key
+        d = self.config.hidden_size
+        enc_out = torch.empty(B, self.num_patches, d, dtype=torch.float32, device=dev)
+        pred_out = torch.empty(B, n_tgt, d, dtype=torch.float32, device=dev) if with_pred else None
+        io = _lib.VjepaIO()
+        io.pixel_values = pix.data_ptr()
+        for k in ("all_idx", "ctx_idx", "tgt_idx", "pred_pos", "ctx_slot", "tgt_slot"):
+            setattr(io, k, idx[k].data_ptr())
+        io.rope_enc, io.rope_pred = self._rope[0].data_ptr(), self._rope[1].data_ptr()
+        io.enc_out, io.pred_out, io.d_pred = enc_out.data_ptr(), (pred_out.data_ptr() if with_pred else None), None
+        _, ps, gs = self._structs
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.smbv_vjepa_forward(C.byref(cfg), C.byref(ps), C.byref(io), self._ws.data_ptr(), self._ws.numel(), stream), "smbv_vjepa_forward")
+        self._fwd_count += 1
+        return enc_out, pred_out, dict(cfg=cfg, io=io, step=self._fwd_count, keep=(pix, idx, enc_out, pred_out))
+
+    def _run_backward(self, st, d_pred):
+        lib = _lib.load()
+        if st["step"] != self._fwd_count:
+            raise _lib.SmbvError("smb_vision_amd: backward() after a later forward() reused the step workspace")
+        d_pred = d_pred.detach().to(torch.float32).contiguous()
+        io = st["io"]
+        io.d_pred = d_pred.data_ptr()
+        _, ps, gs = self._structs
+        self._gflat.zero_()  # rows of mask_tokens that were not selected keep a zero gradient
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.smbv_vjepa_backward(C.byref(st["cfg"]), C.byref(ps), C.byref(gs), C.byref(io), self._ws.data_ptr(), self._ws.numel(), stream),
+                   "smbv_vjepa_backward")
+        return self.grad_views()
+
+    def forward(self, pixel_values_videos: torch.Tensor, context_head_mask=None, context_mask: Optional[List[torch.Tensor]] = None,
+                target_head_mask=None, target_mask: Optional[List[torch.Tensor]] = None, skip_predictor: bool = False, output_attentions=None,
+                output_hidden_states=None, **kwargs):
+        if pixel_values_videos is None:
+            raise ValueError("You have to specify pixel_values_videos")
+        if output_attentions or output_hidden_states or context_head_mask is not None or target_head_mask is not None:
+            raise NotImplementedError("smb_vision_amd: head masks / attention maps / hidden states are not produced by the fused HIP path")
+        if not pixel_values_videos.is_cuda:
+            raise _lib.SmbvError("smb_vision_amd: pixel_values_videos must live on a HIP device; there is no CPU fallback")
+        c = self.config
+        B, T, Cc, H, W = pixel_values_videos.shape
+        if Cc != c.in_chans or H != c.crop_size or W != c.crop_size or T != c.frames_per_clip:
+            raise ValueError(f"pixel_values_videos {tuple(pixel_values_videos.shape)} does not match the config "
+                             f"([B,{c.frames_per_clip},{c.in_chans},{c.crop_size},{c.crop_size}])")
+        dev = pixel_values_videos.device
+        _lib.load()
+        with torch.cuda.device(dev):
+            pix = pixel_values_videos.to(torch.float32).contiguous()
+            N = self.num_patches
+            if context_mask is None and target_mask is None:
+                ar = torch.arange(N, device=dev).unsqueeze(0).repeat(B, 1)
+                context_mask, target_mask = [ar], [ar]
+            if len(context_mask) != 1 or len(target_mask) != 1:
+                raise NotImplementedError("smb_vision_amd: one context mask and one target mask per step (what run_vjepa.py's collate_fn emits)")
+            cm, tm = context_mask[0].to(dev).long(), target_mask[0].to(dev).long()
+            params = self._ensure_device_state(dev)
+            idx = self._index_plumbing(cm, tm, dev)
+            with_pred = not skip_predictor
+            if torch.is_grad_enabled() and with_pred and any(p.requires_grad for p in params):
+                enc_out, pred_out = _VJEPAFn.apply(weakref.ref(self), pix, idx, with_pred, *params)
+            else:
+                enc_out, pred_out, _ = self._run_forward(pix, idx, with_pred)
+            masked = gather_rows(enc_out.detach(), idx["ctx_idx"])
+            target = gather_rows(enc_out.detach(), idx["tgt_idx"])
+        pred = SmbVJEPA2PredictorOutput(last_hidden_state=pred_out, target_hidden_state=target) if with_pred else None
+        return SmbVJEPA2ModelOutput(last_hidden_state=enc_out, masked_hidden_state=masked, target_hidden_state=target, predictor_output=pred)
+
+
+def gather_rows(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """apply_masks (modeling_vjepa.py:542-556) for one mask: x fp32 [B,N,D], idx int32 [B,M] -> [B,M,D] (HIP row gather)."""
+    lib = _lib.load()
+    B, N, D = x.shape
+    out = torch.empty(B, idx.shape[1], D, dtype=torch.float32, device=x.device)
+    _lib.check(lib.smbv_gather_rows_idx_f32(x.data_ptr(), out.data_ptr(), idx.data_ptr(), idx.numel(), idx.shape[1], N, D,
+                                            torch.cuda.current_stream().cuda_stream), "smbv_gather_rows_idx_f32")
+    return out
+
+
+class _L1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        lib = _lib.load()
+        pred, target = pred.contiguous(), target.contiguous()
+        part = torch.empty(1024, dtype=torch.float32, device=pred.device)
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        _lib.check(lib.smbv_l1_fwd(pred.data_ptr(), target.data_ptr(), pred.numel(), part.data_ptr(), loss.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream), "smbv_l1_fwd")
+        ctx.save_for_backward(pred, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        pred, target = ctx.saved_tensors
+        d = torch.empty_like(pred)
+        gs = g.detach().to(torch.float32).reshape(1).contiguous()
+        _lib.check(lib.smbv_l1_bwd(pred.data_ptr(), target.data_ptr(), pred.numel(), d.data_ptr(), gs.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream), "smbv_l1_bwd")
+        return d, None
+
+
+def l1_loss(pred, target):
+    """nn.L1Loss() (run_vjepa.py:108,136) on the HIP path."""
+    if not pred.is_cuda:
+        raise _lib.SmbvError("smb_vision_amd: l1_loss needs HIP tensors")
+    return _L1Fn.apply(pred.float(), target.float())
+
+
+class MomentumEncoder:
+    """run_vjepa.py:87-98: frozen deep copy updated as k <- m*k + (1-m)*q, as ONE multi-tensor HIP launch."""
+
+    def __init__(self, model, momentum=0.99925):
+        self.model = model
+        self.momentum = momentum
+        self._table = None
+
+    def update(self, source_model):
+        lib = _lib.load()
+        pairs = list(zip(source_model.parameters(), self.model.parameters()))
+        sig = tuple((q.data_ptr(), k.data_ptr()) for q, k in pairs)
+        if self._table is None or self._table[0] != sig:
+            rows = []
+            for q, k in pairs:
+                for off in range(0, q.numel(), CHUNK):
+                    rows.append((k.data_ptr() + 4 * off, q.data_ptr() + 4 * off, 0, 0, min(CHUNK, q.numel() - off), 0))
+            arr = np.zeros(len(rows), dtype=np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i4"), ("group", "<i4")]))
+            for i, r in enumerate(rows):
+                arr[i] = r
+            self._table = (sig, torch.from_numpy(arr.view(np.uint8).copy()).to(pairs[0][0].device), len(rows))
+        _, table, n = self._table
+        _lib.check(lib.smbv_ema_update(table.data_ptr(), n, float(self.momentum), torch.cuda.current_stream().cuda_stream), "smbv_ema_update")
+
+
+def make_target_encoder(model: SmbVJEPA2Model) -> SmbVJEPA2Model:
+    """VJEPATrainer.__init__ (run_vjepa.py:104-106): frozen deep copy of the online model."""
+    t = copy.deepcopy(model)
+    t._gflat = t._structs = t._ws = t._ws_key = None
+    for p in t.parameters():
+        p.requires_grad = False
+    return t
+
+
+def vjepa_loss(model, target_encoder, momentum_encoder, inputs):
+    """VJEPATrainer.compute_loss (run_vjepa.py:110-141): online forward, frozen target forward, L1, EMA update — in that order."""
+    out = model(pixel_values_videos=inputs["pixel_values_videos"], context_mask=inputs["context_mask"], target_mask=inputs["target_mask"],
+                skip_predictor=False)
+    pred = out.predictor_output.last_hidden_state
+    with torch.no_grad():
+        tgt = target_encoder(pixel_values_videos=inputs["pixel_values_videos"], context_mask=inputs["context_mask"],
+                             target_mask=inputs["target_mask"], skip_predictor=True).target_hidden_state
+    loss = l1_loss(pred, tgt)
+    if momentum_encoder is not None:
+        momentum_encoder.update(model)
+    return loss, out
