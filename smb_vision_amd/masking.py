@@ -1,4 +1,4 @@
-"""Host-side block-mask generator for MIM pre-training (product code; stays on the host with numpy so that the random
+"""Host-side mask generators (MIM block masks, V-JEPA context/target index masks) (product code; stays on the host with numpy so that the random
 stream is bit-identical to the reference).
 
 Mirrors ``MaskGenerator`` of the reference (``src/dataloader/mim.py:25-69``, duplicate ``src/dataloader/transforms.py:20-63``):
@@ -73,3 +73,54 @@ def split_mask_indices(bool_masked_pos: torch.Tensor, num_masked: int):
     order = torch.argsort(bool_masked_pos.to(torch.uint8), dim=1, stable=True)
     n_vis = bool_masked_pos.shape[1] - num_masked
     return order[:, :n_vis].to(torch.int32).contiguous(), order[:, n_vis:].to(torch.int32).contiguous()
+
+
+class VJEPAMaskGenerator:
+    """Context / target index masks for V-JEPA (reference ``src/dataloader/transforms.py:96-217``, default flags): same constructor
+    arguments, same draws (the per-call seed and the block origins from the GLOBAL torch RNG, scale and aspect ratio from a local
+    ``torch.Generator``), same outputs ``data["context_mask"]`` (tokens outside every block) / ``data["target_mask"]`` (inside), both
+    ascending int64 over the (input[0]/p[0], input[1]/p[1], input[2]/p[2]) grid flattened row-major."""
+
+    def __init__(self, input_size=(224, 224, 160), patch_size=(16, 16, 16), pred_mask_scale=(0.2, 0.8), aspect_ratio=(0.3, 3.0), num_blocks=1,
+                 max_keep=None, inv_block=False, full_complement=False, pred_full_complement=False):
+        if not isinstance(input_size, tuple):
+            input_size = (input_size,) * 3
+        if not isinstance(patch_size, tuple):
+            patch_size = (patch_size,) * 3
+        if full_complement or pred_full_complement:
+            raise NotImplementedError("full_complement / pred_full_complement are not used by the shipped pipelines")
+        self.input_size, self.patch_size = input_size, patch_size
+        self.depth, self.height, self.width = (input_size[i] // patch_size[i] for i in range(3))
+        self.pred_mask_scale, self.aspect_ratio, self.num_blocks = pred_mask_scale, aspect_ratio, num_blocks
+        self.max_keep, self.inv_block = max_keep, inv_block
+
+    def _sample_block_size(self, generator):
+        import math
+        lo, hi = self.pred_mask_scale
+        mask_scale = lo + torch.rand(1, generator=generator).item() * (hi - lo)
+        num_keep = int(self.depth * self.height * self.width * mask_scale)
+        lo, hi = self.aspect_ratio
+        ar = lo + torch.rand(1, generator=generator).item() * (hi - lo)
+        ar1, ar2 = ar, 1.0 / ar
+        d = int(round(math.pow(num_keep * ar1 * ar2, 1 / 3)))
+        h, w = int(round(d * ar1)), int(round(d * ar2))
+        return min(d, self.depth), min(h, self.height), min(w, self.width)
+
+    def __call__(self, data):
+        seed = torch.randint(0, 2 ** 32, (1,)).item()
+        generator = torch.Generator()
+        generator.manual_seed(seed)
+        d, h, w = self._sample_block_size(generator)
+        keep = torch.ones((self.depth, self.height, self.width), dtype=torch.int32)
+        for _ in range(self.num_blocks):
+            sd = torch.randint(0, self.depth - d + 1, (1,))
+            sh = torch.randint(0, self.height - h + 1, (1,))
+            sw = torch.randint(0, self.width - w + 1, (1,))
+            keep[sd:sd + d, sh:sh + h, sw:sw + w] = 0
+        flat = keep.flatten()
+        mask_p = torch.argwhere(flat == 0).squeeze()
+        mask_e = torch.nonzero(flat).squeeze()
+        if self.max_keep is not None:
+            mask_e, mask_p = mask_e[: self.max_keep], mask_p[: self.max_keep]
+        data["context_mask"], data["target_mask"] = (mask_p, mask_e) if self.inv_block else (mask_e, mask_p)
+        return data

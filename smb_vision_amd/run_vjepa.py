@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""V-JEPA pre-training entry point on the MI355X path — the harness of reference ``src/run_vjepa.py`` with the model class swapped.
+
+Mirrors ``src/run_vjepa.py:101-160, 163-290``: ``VJEPATrainer`` (frozen EMA target encoder created from the online model, L1 loss
+between the predictor output and the target encoder's target tokens, EMA update inside ``compute_loss``), the collate function that
+broadcasts ONE example's masks to the whole batch, and the ``HfArgumentParser`` / ``Trainer`` skeleton.  The dataset is synthetic and
+in-memory (NIfTI/MONAI ingestion is out of scope); the model, loss and EMA run on the HIP path (``modeling_vjepa.py``)."""
+from __future__ import annotations
+
+import logging
+import os
+import random
+import sys
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+from torch.utils.data import Dataset
+from transformers import HfArgumentParser, Trainer, TrainingArguments, VJEPA2Config, set_seed
+
+from .masking import VJEPAMaskGenerator
+from .modeling_vjepa import MomentumEncoder, SmbVJEPA2Model, make_target_encoder, vjepa_loss
+
+logger = logging.getLogger(__name__)
+os.environ.setdefault("HF_HUB_OFFLINE", "1")
+os.environ.setdefault("TRANSFORMERS_OFFLINE", "1")
+os.environ.setdefault("WANDB_MODE", "disabled")
+random.seed(42)  # run_vjepa.py:30
+
+
+class SmbVJEPATrainer(Trainer):
+    """``VJEPATrainer`` (run_vjepa.py:101-141)."""
+
+    def __init__(self, *args, momentum=0.99925, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.target_encoder = None
+        self.momentum = momentum
+        self.momentum_encoder = None
+
+    def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None):
+        if self.target_encoder is None:  # created once the online model sits on its device
+            self.target_encoder = make_target_encoder(getattr(model, "module", model))
+            self.momentum_encoder = MomentumEncoder(self.target_encoder, momentum=self.momentum)
+        loss, outputs = vjepa_loss(model, self.target_encoder, self.momentum_encoder, inputs)
+        return (loss, outputs) if return_outputs else loss
+
+
+def collate_fn(examples):
+    """run_vjepa.py:144-160: stack the volumes; ONE random example's masks for every row; masks wrapped in 1-element lists."""
+    pixel_values = torch.stack([ex["image"] for ex in examples])
+    ex = random.choice(examples)
+    context_mask = torch.stack([ex["context_mask"] for _ in examples])
+    target_mask = torch.stack([ex["target_mask"] for _ in examples])
+    return {"pixel_values_videos": pixel_values, "context_mask": [context_mask], "target_mask": [target_mask]}
+
+
+class SyntheticVJEPADataset(Dataset):
+    def __init__(self, n, crop, depth, gen, seed):
+        self.n, self.crop, self.depth, self.gen, self.seed = n, crop, depth, gen, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed + i)
+        item = {"image": torch.rand(self.depth, 1, self.crop, self.crop, generator=g)}
+        return self.gen(item)
+
+
+@dataclass
+class DataTrainingArguments:
+    image_size: int = field(default=224, metadata={"help": "crop size (H == W)"})
+    depth: int = field(default=160, metadata={"help": "frames per clip"})
+    patch_size: int = field(default=16)
+    num_mask_blocks: int = field(default=3)
+    num_train_volumes: int = field(default=16)
+
+
+@dataclass
+class ModelArguments:
+    hidden_size: int = 768
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    pred_hidden_size: int = 384
+    pred_num_hidden_layers: int = 12
+    pred_num_attention_heads: int = 12
+
+
+def main(argv=None):
+    parser = HfArgumentParser((ModelArguments, DataTrainingArguments, TrainingArguments))
+    margs, dargs, targs = parser.parse_args_into_dataclasses(args=argv)
+    logging.basicConfig(level=logging.INFO, handlers=[logging.StreamHandler(sys.stdout)])
+    set_seed(targs.seed)
+    targs.remove_unused_columns = False
+    # run_vjepa.py:221-233: in_chans=1, frames_per_clip=depth, tubelet_size=patch_size, crop_size=image_size
+    config = VJEPA2Config(patch_size=dargs.patch_size, crop_size=dargs.image_size, frames_per_clip=dargs.depth, tubelet_size=dargs.patch_size, in_chans=1,
+                          hidden_size=margs.hidden_size, num_hidden_layers=margs.num_hidden_layers, num_attention_heads=margs.num_attention_heads,
+                          pred_hidden_size=margs.pred_hidden_size, pred_num_hidden_layers=margs.pred_num_hidden_layers,
+                          pred_num_attention_heads=margs.pred_num_attention_heads)
+    model = SmbVJEPA2Model(config)  # run_vjepa.py:245-246: always from scratch
+    # grid in the model's token order (D', H', W'): see SURVEY.md Appendix A.8 on the reference generator's axis naming
+    gen = VJEPAMaskGenerator(input_size=(dargs.depth, dargs.image_size, dargs.image_size), patch_size=(dargs.patch_size,) * 3,
+                             pred_mask_scale=(0.2, 0.8), aspect_ratio=(0.3, 3.0), num_blocks=dargs.num_mask_blocks)
+    train = SyntheticVJEPADataset(dargs.num_train_volumes, dargs.image_size, dargs.depth, gen, 1234)
+    trainer = SmbVJEPATrainer(model=model, args=targs, train_dataset=train, data_collator=collate_fn)
+    result = trainer.train()
+    trainer.save_model()
+    trainer.log_metrics("train", result.metrics)
+    return result.metrics
+
+
+if __name__ == "__main__":
+    main()

@@ -162,3 +162,47 @@ def test_errors_mirror_the_reference(model_and_cfg):
         SmbVideoMAEForPreTraining(VideoMAEConfig(num_channels=1, norm_pix_loss=False, **TINY))
     model.gradient_checkpointing_enable()
     assert model.gradient_checkpointing
+
+
+def vmask_cases():
+    z = np.load(os.path.join(G, "vjepa_masks.npz"))
+    for k in z.files:
+        if k.endswith("_cfg"):
+            yield z, int(k.split("_")[1]), z[k]
+
+
+@pytest.mark.parametrize("case", list(vmask_cases()), ids=lambda c: f"case{c[1]}")
+def test_product_vjepa_mask_generator_bit_exact(case):
+    from smb_vision_amd.masking import VJEPAMaskGenerator
+    z, ci, cfgv = case
+    inp, ps, nb = tuple(int(v) for v in cfgv[:3]), tuple(int(v) for v in cfgv[3:6]), int(cfgv[6])
+    gen = VJEPAMaskGenerator(inp, ps, (0.2, 0.8), (0.3, 3.0), nb)
+    for seed in range(4):
+        torch.manual_seed(seed)
+        for draw in range(2):
+            d = gen({})
+            key = f"vmask_{ci}_seed{seed}_{draw}"
+            assert np.array_equal(d["context_mask"].reshape(-1).numpy(), z[key + "_ctx"])
+            assert np.array_equal(d["target_mask"].reshape(-1).numpy(), z[key + "_tgt"])
+
+
+def test_vjepa_model_class_surface():
+    from transformers import VJEPA2Config
+    from oracle.vjepa_oracle import VJEPAConfig, param_shapes as vshapes
+    from smb_vision_amd.modeling_vjepa import SmbVJEPA2Model
+    c = dict(patch_size=8, crop_size=32, frames_per_clip=8, tubelet_size=2, in_chans=1, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+             mlp_ratio=4.0, pred_hidden_size=64, pred_num_hidden_layers=2, pred_num_attention_heads=2, pred_num_mask_tokens=10, pred_mlp_ratio=4.0)
+    m = SmbVJEPA2Model(VJEPA2Config(**c))
+    ref = vshapes(VJEPAConfig(**c))
+    # names, shapes AND parameters() order (MomentumEncoder.update zips the two models' parameters, run_vjepa.py:97)
+    assert [n for n, _ in m.named_parameters()] == list(ref)
+    assert all(tuple(p.shape) == ref[n] for n, p in m.named_parameters())
+    assert m.main_input_name == "pixel_values_videos" and m.base_model_prefix == "vjepa2"
+    sd = m.state_dict()
+    assert float(sd["predictor.embeddings.mask_tokens"].abs().sum()) == 0 and float(sd["encoder.layernorm.weight"].min()) == 1.0
+    with tempfile.TemporaryDirectory() as d:
+        m.save_pretrained(d)
+        m2 = SmbVJEPA2Model.from_pretrained(d)
+        assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    with pytest.raises(_lib.SmbvError, match="no CPU fallback"):
+        m(pixel_values_videos=torch.zeros(1, 8, 1, 32, 32))

@@ -142,3 +142,14 @@ def test_vjepa_default_masks_and_errors():
         model(pixel_values_videos=torch.zeros(1, 8, 1, 16, 16).cuda())
     with pytest.raises(Exception):
         model(pixel_values_videos=pix.cpu())
+
+
+def test_hf_trainer_runs_vjepa(tmp_path):
+    from smb_vision_amd.run_vjepa import main
+    metrics = main(["--output_dir", str(tmp_path), "--image_size", "32", "--depth", "16", "--patch_size", "8", "--num_mask_blocks", "2",
+                    "--hidden_size", "128", "--num_hidden_layers", "2", "--num_attention_heads", "2", "--pred_hidden_size", "64",
+                    "--pred_num_hidden_layers", "2", "--pred_num_attention_heads", "2", "--max_steps", "6", "--per_device_train_batch_size", "2",
+                    "--report_to", "none", "--bf16", "true", "--learning_rate", "1e-3", "--logging_steps", "1", "--save_strategy", "no",
+                    "--max_grad_norm", "1.0", "--dataloader_num_workers", "0"])
+    assert 0 < metrics["train_loss"] < 2.0
+    assert os.path.exists(os.path.join(tmp_path, "model.safetensors"))
