@@ -19,6 +19,9 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsmbv.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result", "-ffp-contract=fast"]
+# The attention bodies place single-issue VALU work between MFMAs; SLP-packing adjacent f32 multiplies into v_pk_* (plus the moves
+# that line the pairs up) costs more issue slots there than it saves.
+FILE_FLAGS = {"attention_bwd.hip": ["-fno-slp-vectorize"], "attention_fwd.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -40,9 +43,9 @@ def _deps_mtime() -> float:
 
 def _compile(src: str, force: bool) -> str:
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
-    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), _deps_mtime()):
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), _deps_mtime(), os.path.getmtime(__file__)):
         return obj
-    cmd = [_hipcc(), *FLAGS, "-c", src, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -225,6 +225,246 @@ __global__ __launch_bounds__(256, MINW) void attn_dkv_kernel(const bf16_t* __res
   }
 }
 
+// Scheduling-group masks of __builtin_amdgcn_sched_group_barrier
+#define SG_VALU 0x2
+#define SG_MFMA 0x8
+#define SG_DSR 0x100
+#define SG_TRANS 0x400
+
+// Hand-phased form of attn_dkv_kernel (same arithmetic, same accumulation order, bitwise identical results).  Per 32-query sub-tile
+// the 16 MFMAs run as four dependent chains of 4 and every LDS fragment is read one chain (>= 128 matrix-pipe cycles) before the
+// MFMA that consumes it, so no matrix instruction waits on an LDS round trip:
+//   chain 1  S'  = Q K^T - lse     | reads: dO^T fragments (for chain 3)
+//   chain 2  dP' = dO V^T - delta  | exp2(S') -> P, convert P         | reads: Q^T fragments (for chain 4)
+//   chain 3  dV^T += dO^T P        | dS = P * dP', convert dS         | reads: next sub-tile's Q rows + row constants
+//   chain 4  dK^T += Q^T dS        |                                  | reads: next sub-tile's dO rows + row constants
+// The next 128-query tile is copied into the other LDS buffer by LDS-DMA during sub-tiles 0..2 (two barriers per iteration: at the
+// top "everyone has left the previous tile", after sub-tile 2 "the new tile has landed"), so the last sub-tile prefetches across
+// the tile seam as well and the staging costs no registers.
+template <int QT>
+__global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                           const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO,
+                                                           int ldo, const float* __restrict__ LSE, const float* __restrict__ delta,
+                                                           bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int ldd, int S, int Sq, int qoff,
+                                                           int H, float scale) {
+  static_assert(QT == 128, "the mid-iteration hand-over is written for 4 sub-tiles");
+  constexpr int NS = QT / 32;
+  constexpr int BUF = 2 * QT * 128 + 2 * QT * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int r = l & 31, h2 = l >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const size_t row0 = (size_t)b * S;
+  const int key = blockIdx.x * 128 + w * 32 + r;
+  const int hoff = head * 64;
+  const float c = scale * 1.4426950408889634f;
+  const float* lse_p = LSE + ((size_t)b * H + head) * Sq;
+  const float* del_p = delta + ((size_t)b * H + head) * Sq;
+
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) {
+    u32x4 a = {0, 0, 0, 0}, bb = {0, 0, 0, 0};
+    if (key < S) {
+      a = *(const u32x4*)(K + (row0 + key) * ld + hoff + 16 * ks + 8 * h2);
+      bb = *(const u32x4*)(V + (row0 + key) * ld + hoff + 16 * ks + 8 * h2);
+    }
+    kf[ks] = scale_frag(a, c);
+    vf[ks] = __builtin_bit_cast(bf16x8, bb);
+  }
+  f32x16 dkt[2], dvt[2];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { dkt[0][i] = 0.f; dkt[1][i] = 0.f; dvt[0][i] = 0.f; dvt[1][i] = 0.f; }
+
+  // Q / dO tiles go global -> LDS by LDS-DMA: wave w stages rows 32w..32w+31 of both images as 4 + 4 pieces of 8 rows x 128 B.
+  // A piece lands lane-linear (lane -> row l>>3, chunk position l&7), so the swz128 permutation is applied to the SOURCE chunk.
+  // Rows >= Sq are outside the descriptors' range and arrive as zeros.
+  const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc((void*)(Q + (row0 + qoff) * ld + hoff), 0, (int)(((size_t)(Sq - 1) * ld + 64) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)(dO + (row0 + qoff) * ldo + hoff), 0, (int)(((size_t)(Sq - 1) * ldo + 64) * 2), 0x00020000);
+  int oq[4], od[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int row = 32 * w + 8 * i + (l >> 3);
+    const int x = (row >> 1) & 7;
+    const int cs = (l & 7) ^ (((x & 1) << 2) | (x >> 1));
+    oq[i] = (row * ld + cs * 8) * 2;
+    od[i] = (row * ldo + cs * 8) * 2;
+  }
+  const int oq0 = oq[0], oq1 = oq[1], oq2 = oq[2], oq3 = oq[3], od0 = od[0], od1 = od[1], od2 = od[2], od3 = od[3];
+  float rstat = 0.f;
+  auto stage = [&](int buf, int qt) __attribute__((always_inline)) {
+    unsigned char* sqw = smem + buf * BUF + w * 4096;
+    unsigned char* sdw = sqw + QT * 128;
+    const int kq = qt * QT * ld * 2, kd = qt * QT * ldo * 2;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (__attribute__((address_space(3))) void*)(sqw), 16, oq0 + kq, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (__attribute__((address_space(3))) void*)(sdw), 16, od0 + kd, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (__attribute__((address_space(3))) void*)(sqw + 1024), 16, oq1 + kq, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (__attribute__((address_space(3))) void*)(sdw + 1024), 16, od1 + kd, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (__attribute__((address_space(3))) void*)(sqw + 2048), 16, oq2 + kq, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (__attribute__((address_space(3))) void*)(sdw + 2048), 16, od2 + kd, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (__attribute__((address_space(3))) void*)(sqw + 3072), 16, oq3 + kq, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (__attribute__((address_space(3))) void*)(sdw + 3072), 16, od3 + kd, 0, 0, 0);
+    const int q0 = qt * QT;
+    if (t < QT) rstat = (q0 + t < Sq) ? -lse_p[q0 + t] * 1.4426950408889634f : -INFINITY;  // padded rows: p = exp2(-inf) = 0
+    else if (t < 2 * QT) rstat = (q0 + t - QT < Sq) ? -del_p[q0 + t - QT] : 0.f;
+  };
+  // row constants, arranged so that each lane half reads its 16 accumulator rows (8*rg + 4*h2 + e) of a 32-row sub-tile as ONE
+  // contiguous 64-byte vector: position = 32*sub + 16*h2 + 4*rg + e
+  auto put_stats = [&](int buf) __attribute__((always_inline)) {
+    if (t < 2 * QT) {
+      const int rr = t % QT;
+      const int pos = (rr & ~31) + 16 * ((rr >> 2) & 1) + 4 * ((rr & 31) >> 3) + (rr & 3);
+      ((float*)(smem + buf * BUF + 2 * QT * 128))[(t / QT) * QT + pos] = rstat;
+    }
+  };
+
+  const int nq = (Sq + QT - 1) / QT;
+  const int g1 = (l >> 4) & 1, qq = (l >> 2) & 3, pp = l & 3;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  // transposed fragment (s2, dt) of a row-major image: rows 16*s2 + 4*h2 + qq (+8), 16-byte chunk 4*dt + 2*g1 + (pp>>1)
+  auto tr_frag = [&](const unsigned char* img, int rb, int s2, int dt) __attribute__((always_inline)) -> bf16x8 {
+    const int qb = rb + 16 * s2 + 4 * h2 + qq;
+    const int c16 = 4 * dt + 2 * g1 + (pp >> 1);
+    const int sb8 = 8 * (pp & 1);
+    const s16x4 a0 = lds_read_tr16(img + swz128(qb, c16) + sb8);
+    const s16x4 a1 = lds_read_tr16(img + swz128(qb + 8, c16) + sb8);
+    const s16x8 aa = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    return __builtin_bit_cast(bf16x8, aa);
+  };
+
+  stage(0, 0);
+  put_stats(0);
+  __syncthreads();  // (hipcc drains the LDS-DMA with vmcnt(0) in front of the barrier)
+  bf16x8 qa[4], da[4];
+  f32x16 s, dp;
+  {
+    const unsigned char* sq = smem;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      qa[ks] = *(const bf16x8*)(sq + swz128(r, 2 * ks + h2));
+      da[ks] = *(const bf16x8*)(sq + QT * 128 + swz128(r, 2 * ks + h2));
+    }
+    s = *(const f32x16*)((const float*)(sq + 2 * QT * 128) + 16 * h2);
+    dp = *(const f32x16*)((const float*)(sq + 2 * QT * 128) + QT + 16 * h2);
+  }
+  for (int qt = 0; qt < nq; qt++) {
+    const int buf = qt & 1;
+    const bool more = qt + 1 < nq;
+    __syncthreads();  // every wave has left the previous tile: its buffer may be overwritten
+    if (more) stage(buf ^ 1, qt + 1);
+    const unsigned char* sq = smem + buf * BUF;
+    const unsigned char* sdo = sq + QT * 128;
+#pragma unroll
+    for (int sub = 0; sub < NS; sub++) {
+      const int rb = 32 * sub;
+      // where the NEXT sub-tile lives: same buffer, or rows 0..31 of the other buffer across the tile seam
+      const unsigned char* nq_img = (sub + 1 < NS) ? sq : smem + (buf ^ 1) * BUF;
+      const int nrb = (sub + 1 < NS) ? rb + 32 : 0;
+      const bool pre = (sub + 1 < NS) || more;
+      bf16x8 ta[2][2], tb[2][2], pf[2], dsf[2];
+      // ---- chain 1
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[ks], s, 0, 0, 0);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++) ta[s2][dt] = tr_frag(sdo, rb, s2, dt);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(SG_DSR, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- chain 2
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vf[ks], dp, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 16; i++) s[i] = fast_exp2(s[i]);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) pf[s2][j] = (__bf16)s[8 * s2 + j];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++) tb[s2][dt] = tr_frag(sq, rb, s2, dt);
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_DSR, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_TRANS, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_TRANS, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_DSR, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_VALU, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_TRANS, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_DSR, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_VALU, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_TRANS, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_VALU, 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- chain 3
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++) dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[s2][dt], pf[s2], dvt[dt], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 16; i++) dp[i] *= s[i];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) dsf[s2][j] = (__bf16)dp[8 * s2 + j];
+      if (pre) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) qa[ks] = *(const bf16x8*)(nq_img + swz128(nrb + r, 2 * ks + h2));
+        s = *(const f32x16*)((const float*)(nq_img + 2 * QT * 128) + nrb + 16 * h2);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(SG_VALU, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(SG_DSR, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- chain 4
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++) dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tb[s2][dt], dsf[s2], dkt[dt], 0, 0, 0);
+      if (pre) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) da[ks] = *(const bf16x8*)(nq_img + QT * 128 + swz128(nrb + r, 2 * ks + h2));
+        dp = *(const f32x16*)((const float*)(nq_img + 2 * QT * 128) + QT + nrb + 16 * h2);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(SG_DSR, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (sub == 2) {
+        if (more) put_stats(buf ^ 1);
+        __syncthreads();  // the new tile has landed (vmcnt(0) + barrier) before sub-tile 3 prefetches across the seam
+      }
+    }
+  }
+
+  if (key < S) {
+    bf16_t* kp = dK + (row0 + key) * ldd + hoff;
+    bf16_t* vp = dV + (row0 + key) * ldd + hoff;
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int d0 = 32 * dt + 8 * rg + 4 * h2;
+        u32x2 pk = {pack_bf16(dkt[dt][4 * rg] * scale, dkt[dt][4 * rg + 1] * scale), pack_bf16(dkt[dt][4 * rg + 2] * scale, dkt[dt][4 * rg + 3] * scale)};
+        *(u32x2*)(kp + d0) = pk;
+        u32x2 pv = {pack_bf16(dvt[dt][4 * rg], dvt[dt][4 * rg + 1]), pack_bf16(dvt[dt][4 * rg + 2], dvt[dt][4 * rg + 3])};
+        *(u32x2*)(vp + d0) = pv;
+      }
+  }
+}
+
 template <int MINW, int KT>
 __global__ __launch_bounds__(256, MINW) void attn_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                       const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO, int ldo,
@@ -389,7 +629,8 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     // measured (tools/attn_ab.py): 128-query iterations at 2 waves/SIMD beat 64/32-query ones and the 3-wave build on both shapes
     if (g_variant & 4) DKV(3, 32);
     else if (g_variant & 256) DKV(2, 64);
-    else DKV(2, 128);
+    else if (g_variant & 1024) DKV(2, 128);
+    else hipLaunchKernelGGL((attn_dkv2_kernel<128>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale);
 #undef DKV
     rc = check_launch("attn_dkv");
     if (rc) return rc;
