@@ -597,6 +597,193 @@ __global__ __launch_bounds__(256, MINW) void attn_dq_kernel(const bf16_t* __rest
   }
 }
 
+// Hand-phased, rotated form of attn_dq_kernel (same arithmetic and accumulation order: bitwise identical results).  Steady state,
+// per 32-key sub-tile j, three dependent chains of 4 MFMAs, each with the other sub-tile's VALU work and the LDS reads of a LATER
+// chain in its gaps:
+//   chain A  S'^T(j+1) = K Q^T - lse     | dS(j) = P(j) * dP'(j), convert          | reads: V rows of j+1
+//   chain B  dQ^T += K^T dS^T(j)         | exp2 of half of S'^T(j+1)               | reads: K rows of j+2
+//   chain C  dP'^T(j+1) = V dO^T - delta | exp2 of the other half                  | reads: K^T fragments of j+1
+// K/V tiles of 128 keys arrive by LDS-DMA two tiles ahead into a 2-buffer ring (barriers: before body 2 "tile T+1 has landed",
+// before body 3 "tile T is dead", after which tile T+2 is requested into its buffer).  The pipeline's last body runs its A and C
+// chains on a stale sub-tile; their results are never used.
+template <int KT>
+__global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                          const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO, int ldo,
+                                                          const float* __restrict__ LSE, const float* __restrict__ delta,
+                                                          bf16_t* __restrict__ dQ, int ldd, int S, int Sq, int qoff, int H, float scale) {
+  static_assert(KT == 128, "bodies are unrolled for 4 sub-tiles per tile");
+  constexpr int BUF = 2 * KT * 128;  // K image | V image
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int r = l & 31, h2 = l >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const size_t row0 = (size_t)b * S;
+  const int q = blockIdx.x * 128 + w * 32 + r;
+  const int hoff = head * 64;
+  const float c = scale * 1.4426950408889634f;
+
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) {
+    u32x4 a = {0, 0, 0, 0}, bb = {0, 0, 0, 0};
+    if (q < Sq) {
+      a = *(const u32x4*)(Q + (row0 + qoff + q) * ld + hoff + 16 * ks + 8 * h2);
+      bb = *(const u32x4*)(dO + (row0 + qoff + q) * ldo + hoff + 16 * ks + 8 * h2);
+    }
+    qf[ks] = scale_frag(a, c);
+    dof[ks] = __builtin_bit_cast(bf16x8, bb);
+  }
+  float nlse2 = -INFINITY, ndl = 0.f;
+  if (q < Sq) {
+    nlse2 = -LSE[((size_t)b * H + head) * Sq + q] * 1.4426950408889634f;
+    ndl = -delta[((size_t)b * H + head) * Sq + q];
+  }
+  f32x16 sinit, dinit;
+#pragma unroll
+  for (int i = 0; i < 16; i++) { sinit[i] = nlse2; dinit[i] = ndl; }
+  f32x16 dqt[2];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { dqt[0][i] = 0.f; dqt[1][i] = 0.f; }
+
+  // LDS-DMA staging: wave w copies rows 32w..32w+31 of the K and V tiles (4 + 4 pieces of 8 rows x 128 B, swz128 applied to the
+  // source chunk); rows >= S are outside the descriptors and arrive as zeros.
+  const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc((void*)(K + row0 * ld + hoff), 0, (int)(((size_t)(S - 1) * ld + 64) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc((void*)(V + row0 * ld + hoff), 0, (int)(((size_t)(S - 1) * ld + 64) * 2), 0x00020000);
+  int og[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int row = 32 * w + 8 * i + (l >> 3);
+    const int x = (row >> 1) & 7;
+    og[i] = (row * ld + ((l & 7) ^ (((x & 1) << 2) | (x >> 1))) * 8) * 2;
+  }
+  const int og0 = og[0], og1 = og[1], og2 = og[2], og3 = og[3];
+  auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
+    unsigned char* skw = smem + buf * BUF + w * 4096;
+    unsigned char* svw = skw + KT * 128;
+    const int ko = kt * KT * ld * 2;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (__attribute__((address_space(3))) void*)(skw), 16, og0 + ko, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (__attribute__((address_space(3))) void*)(svw), 16, og0 + ko, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (__attribute__((address_space(3))) void*)(skw + 1024), 16, og1 + ko, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (__attribute__((address_space(3))) void*)(svw + 1024), 16, og1 + ko, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (__attribute__((address_space(3))) void*)(skw + 2048), 16, og2 + ko, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (__attribute__((address_space(3))) void*)(svw + 2048), 16, og2 + ko, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (__attribute__((address_space(3))) void*)(skw + 3072), 16, og3 + ko, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (__attribute__((address_space(3))) void*)(svw + 3072), 16, og3 + ko, 0, 0, 0);
+  };
+
+  const int g1 = (l >> 4) & 1, qq = (l >> 2) & 3, pp = l & 3;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto rows = [&](const unsigned char* img, int sub, bf16x8* f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) f[ks] = *(const bf16x8*)(img + swz128(32 * sub + r, 2 * ks + h2));
+  };
+  auto trk = [&](const unsigned char* img, int sub, bf16x8 (*f)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+      for (int dt = 0; dt < 2; dt++) {
+        const int kb = 32 * sub + 16 * s2 + 4 * h2 + qq;
+        const int c16 = 4 * dt + 2 * g1 + (pp >> 1);
+        const int sb8 = 8 * (pp & 1);
+        const s16x4 a0 = lds_read_tr16(img + swz128(kb, c16) + sb8);
+        const s16x4 a1 = lds_read_tr16(img + swz128(kb + 8, c16) + sb8);
+        const s16x8 aa = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        f[s2][dt] = __builtin_bit_cast(bf16x8, aa);
+      }
+  };
+
+  const int nt = (S + KT - 1) / KT;
+  stage(0, 0);
+  if (nt > 1) stage(1, 1);
+  __syncthreads();  // (hipcc drains the LDS-DMA with vmcnt(0) in front of the barrier)
+  bf16x8 ka[4], va[4], tk[2][2];
+  f32x16 sA, sB, dp;
+  {
+    rows(smem, 0, ka);
+    rows(smem + KT * 128, 0, va);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], ks == 0 ? sinit : sA, 0, 0, 0);
+    rows(smem, 1, ka);
+    trk(smem, 0, tk);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[ks], dof[ks], ks == 0 ? dinit : dp, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 16; i++) sA[i] = fast_exp2(sA[i]);
+  }
+  // one pipeline body: finishes sub-tile j (P in sC, dP' in dp, K^T fragments in tk) and starts j+1 (K rows in ka)
+  auto body = [&](f32x16& sC, f32x16& sN, const unsigned char* img1, int sub1, const unsigned char* img2, int sub2) __attribute__((always_inline)) {
+    bf16x8 dsf[2];
+    // ---- chain A
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) sN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], ks == 0 ? sinit : sN, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 16; i++) dp[i] *= sC[i];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) dsf[s2][j] = (__bf16)dp[8 * s2 + j];
+    rows(img1 + KT * 128, sub1, va);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_VALU, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- chain B
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+      for (int dt = 0; dt < 2; dt++) dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tk[s2][dt], dsf[s2], dqt[dt], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { sN[i] = fast_exp2(sN[i]); asm volatile("" : "+v"(sN[i])); }  // (pinned: hipcc otherwise sinks the last body's exps into the next iteration's head)
+    rows(img2, sub2, ka);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_TRANS, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- chain C
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[ks], dof[ks], ks == 0 ? dinit : dp, 0, 0, 0);
+#pragma unroll
+    for (int i = 8; i < 16; i++) { sN[i] = fast_exp2(sN[i]); asm volatile("" : "+v"(sN[i])); }
+    trk(img1, sub1, tk);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_TRANS, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_DSR, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int kt = 0; kt < nt; kt++) {
+    const unsigned char* cur = smem + (kt & 1) * BUF;
+    const unsigned char* nxt = smem + ((kt & 1) ^ 1) * BUF;
+    body(sA, sB, cur, 1, cur, 2);
+    body(sB, sA, cur, 2, cur, 3);
+    __syncthreads();  // tile kt+1 has landed (vmcnt(0) + barrier)
+    body(sA, sB, cur, 3, nxt, 0);
+    __syncthreads();  // every wave is done with tile kt: its buffer takes tile kt+2
+    if (kt + 2 < nt) stage(kt & 1, kt + 2);
+    body(sB, sA, nxt, 0, nxt, 1);
+  }
+
+  if (q < Sq) {
+    bf16_t* qp = dQ + (row0 + qoff + q) * ldd + hoff;
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int d0 = 32 * dt + 8 * rg + 4 * h2;
+        u32x2 pk = {pack_bf16(dqt[dt][4 * rg] * scale, dqt[dt][4 * rg + 1] * scale), pack_bf16(dqt[dt][4 * rg + 2] * scale, dqt[dt][4 * rg + 3] * scale)};
+        *(u32x2*)(qp + d0) = pk;
+      }
+  }
+}
+
 int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
                   float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st) {
   if (Sq <= 0) { Sq = S; qoff = 0; }
@@ -638,7 +825,8 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
   if (parts & 4) {
 #define DQ(W, KT) hipLaunchKernelGGL((attn_dq_kernel<W, KT>), dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale)
     if (g_variant & 512) DQ(2, 64);
-    else DQ(2, 128);
+    else if (g_variant & 2048) DQ(2, 128);
+    else hipLaunchKernelGGL((attn_dq2_kernel<128>), dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale);
 #undef DQ
     rc = check_launch("attn_dq");
   }
