@@ -253,7 +253,7 @@ def main():
                 traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_attn_dkv_traffic.json")))["traffic_bytes_per_launch"]
             except Exception:
                 pass
-            line["roofline"] = {"bound": "mfma", "kernel": "attn_dkv_kernel (decoder, S=20480, H=6, Dh=64)", "achieved": dom["tflops"],
+            line["roofline"] = {"bound": "mfma", "kernel": "attn_dkv2_kernel (decoder, S=20480, H=6, Dh=64)", "achieved": dom["tflops"],
                                 "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic,
                                 "launch_ms": dom["ms"], "flop_per_launch": dom["flop"],
                                 "other": {"attn_dq_kernel": {"launch_ms": kr["attn_dq_kernel"]["ms"], "achieved": kr["attn_dq_kernel"]["tflops"]}},

@@ -187,7 +187,254 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __res
   }
 }
 
-int g_variant = 0;  // tuning / A-B hook (tools/attn_ab.py): bit1 force 3 waves/SIMD fwd, bit2 dkv, bit3 dq, bit4 force 2 everywhere
+#define SG_VALU 0x2
+#define SG_MFMA 0x8
+#define SG_DSR 0x100
+#define SG_TRANS 0x400
+
+// Hand-phased, rotated forward: while the matrix pipe runs the QK^T chains of tile j+1 and the PV products of tile j, the wave's
+// VALU slots carry the exp2 / row-sum / bf16-convert work of tile j and the row maximum of tile j+1, and every LDS fragment is read
+// at least four MFMAs before its consumer.  Per 64-key tile, four groups of 4 MFMAs:
+//   G1  S'^T(j+1)[keys 0..31]   | P(j) k-step 0 (8 exp2, 8 adds, 4 converts) | reads: V^T fragments of k-steps 0,1
+//   G2  S'^T(j+1)[keys 32..63]  | P(j) k-step 1                              | reads: V^T fragments of k-steps 2,3
+//   -- barrier: tile j is dead -> its ring slot takes tile j+4 (LDS-DMA); tile j+2 has landed (counted vmcnt) --
+//   G3  O^T += V^T P^T, k-steps 0,1 | P(j) k-step 2                          | reads: K rows 0..31 of tile j+2
+//   G4  O^T += V^T P^T, k-steps 2,3 | P(j) k-step 3, then max of S'(j+1)     | reads: K rows 32..63 of tile j+2
+// followed by the (rare, wave-uniform) rebase of the running reference.  K/V travel global -> LDS by LDS-DMA into a ring of four
+// 64-key slots, two tiles of flight time, no staging registers.  Arithmetic is that of attn_fwd_kernel except for the order in
+// which a tile's 64 probabilities enter the row sum.
+__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                           const bf16_t* __restrict__ V, int ld, bf16_t* __restrict__ O, int ldo,
+                                                           float* __restrict__ LSE, int S, int Sq, int qoff, int H, float scale) {
+  constexpr int SLOT = 2 * 64 * 128;  // K image | V image
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * SLOT];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int r = l & 31, h2 = l >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const size_t row0 = (size_t)b * S;
+  const int q = blockIdx.x * 128 + w * 32 + r;
+  const int hoff = head * 64;
+  const float c = scale * 1.4426950408889634f;
+
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) {
+    u32x4 v = {0, 0, 0, 0};
+    if (q < Sq) v = *(const u32x4*)(Q + (row0 + qoff + q) * ld + hoff + 16 * ks + 8 * h2);
+    qf[ks] = scale_bf16x8(v, c);
+  }
+  f32x16 ot[2], cneg;
+#pragma unroll
+  for (int i = 0; i < 16; i++) { ot[0][i] = 0.f; ot[1][i] = 0.f; cneg[i] = 0.f; }
+  float m2 = 0.f, l_a = 0.f, l_b = 0.f;
+
+  // LDS-DMA: wave w copies rows 16w..16w+15 of the K and the V tile (2 + 2 pieces of 8 rows x 128 B), image swizzles applied to the
+  // source chunk; rows >= S lie outside the descriptors and arrive as zeros, so tiles past the end may be requested freely.
+  const i32x4 rsk = dma_rsrc(K + row0 * ld + hoff, (unsigned)(((size_t)(S - 1) * ld + 64) * 2));
+  const i32x4 rsv = dma_rsrc(V + row0 * ld + hoff, (unsigned)(((size_t)(S - 1) * ld + 64) * 2));
+  const int rw0 = 16 * w + (l >> 3), rw1 = rw0 + 8;
+  const int ok0 = (rw0 * ld + ((l & 7) ^ ((rw0 >> 1) & 7)) * 8) * 2, ok1 = (rw1 * ld + ((l & 7) ^ ((rw1 >> 1) & 7)) * 8) * 2;
+  const int ov0 = (rw0 * ld + ((l & 7) ^ (((rw0 >> 1) & 1) << 2)) * 8) * 2, ov1 = (rw1 * ld + ((l & 7) ^ (((rw1 >> 1) & 1) << 2)) * 8) * 2;
+  const int tile_bytes = 64 * ld * 2;
+  const unsigned lds_w = __builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem) + w * 2048));
+  auto stage = [&](int j) __attribute__((always_inline)) {
+    const unsigned dk = lds_w + (unsigned)(j & 3) * SLOT, dv = dk + 64 * 128;
+    const int ko = j * tile_bytes;
+    dma16_hidden(rsk, dk, ok0 + ko);
+    dma16_hidden(rsk, dk + 1024, ok1 + ko);
+    dma16_hidden(rsv, dv, ov0 + ko);
+    dma16_hidden(rsv, dv + 1024, ov1 + ko);
+  };
+  const int g1 = (l >> 4) & 1, qq = (l >> 2) & 3, pp = l & 3;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto kread = [&](int j, int kt2, bf16x8* kf) __attribute__((always_inline)) {
+    const unsigned char* sk = smem + (j & 3) * SLOT;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) kf[ks] = *(const bf16x8*)(sk + swz_k64(32 * kt2 + r, 2 * ks + h2));
+  };
+  auto vread = [&](int j, int kstep, bf16x8* vt) __attribute__((always_inline)) {  // vt[dt]
+    const unsigned char* sv = smem + (j & 3) * SLOT + 64 * 128;
+    const int kb = 16 * kstep + 4 * h2 + qq;
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++) {
+      const int c32 = 2 * dt + g1;
+      const s16x4 v0 = lds_read_tr16(sv + swz_v64(kb, c32) + 8 * pp);
+      const s16x4 v1 = lds_read_tr16(sv + swz_v64(kb + 8, c32) + 8 * pp);
+      const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      vt[dt] = __builtin_bit_cast(bf16x8, vv);
+    }
+  };
+  auto pgroup = [&](f32x16& sb, int s2, bf16x8& pf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      const float p0 = fast_exp2(sb[8 * s2 + i]), p1 = fast_exp2(sb[8 * s2 + i + 1]);
+      l_a += p0;
+      l_b += p1;
+      pf[i] = (__bf16)p0;
+      pf[i + 1] = (__bf16)p1;
+    }
+  };
+  const int nt = (S + 63) / 64;
+  auto tile_max = [&](const f32x16* sn) __attribute__((always_inline)) -> float {
+    float mx = sn[0][0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) mx = fmaxf(mx, sn[0][i]);
+#pragma unroll
+    for (int i = 0; i < 16; i++) mx = fmaxf(mx, sn[1][i]);
+    return mx;
+  };
+  // tile j's scores (relative to the running reference) are complete and mx is their per-lane maximum: mask a ragged last tile,
+  // combine the two lane halves and, when the maximum exceeds the threshold, move the reference (rare, wave-uniform)
+  auto settle = [&](f32x16* sn, float mx, int j, bool first) __attribute__((always_inline)) {
+    if (j * 64 + 64 > S && j * 64 < S) {  // ragged last tile: keys >= S get -inf
+#pragma unroll
+      for (int kt2 = 0; kt2 < 2; kt2++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const int key = j * 64 + 32 * kt2 + (i & 3) + 8 * (i >> 2) + 4 * h2;
+          if (key >= S) sn[kt2][i] = -INFINITY;
+        }
+      mx = tile_max(sn);
+    }
+    {  // the other lane half holds the other 32 keys of the same query row
+      typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+      const unsigned ma = __builtin_bit_cast(unsigned, mx);
+      const u32x2v sw = __builtin_amdgcn_permlane32_swap(ma, ma, false, false);
+      unsigned lo = sw[0], hi = sw[1];
+      asm volatile("" : "+v"(lo), "+v"(hi));  // (hipcc -O3 otherwise folds max(sw[0], sw[1]) to sw[0]: checked in the .s)
+      mx = fmaxf(__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi));
+    }
+    const bool rebase = first || (j < nt && mx > ATTN_DEFER_THR);
+    if (__builtin_amdgcn_ballot_w64(rebase) != 0) {
+      const float d = rebase ? mx : 0.f;
+      const float alpha = fast_exp2(-d);
+      m2 += d;
+      l_a *= alpha;
+      l_b *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        ot[0][i] *= alpha;
+        ot[1][i] *= alpha;
+        sn[0][i] -= d;
+        sn[1][i] -= d;
+        cneg[i] = -m2;
+      }
+    }
+  };
+
+  stage(0); stage(1); stage(2); stage(3);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tiles 0 and 1
+  __builtin_amdgcn_s_barrier();
+  bf16x8 kfa[4], kfb[4];
+  f32x16 sA[2], sB[2];
+  kread(0, 0, kfa);
+  kread(0, 1, kfb);
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) sA[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[ks], qf[ks], ks == 0 ? cneg : sA[0], 0, 0, 0);
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) sA[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[ks], qf[ks], ks == 0 ? cneg : sA[1], 0, 0, 0);
+  kread(1, 0, kfa);
+  kread(1, 1, kfb);
+  settle(sA, tile_max(sA), 0, true);
+
+  // one pipeline body: finishes tile j (scores in sc) and starts tile j+1 (K fragments in kfa/kfb) into sn
+  auto body = [&](f32x16* sc, f32x16* sn, int j) __attribute__((always_inline)) {
+    bf16x8 pf[4], vt[4][2];
+    // ---- G1
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[ks], qf[ks], ks == 0 ? cneg : sn[0], 0, 0, 0);
+    pgroup(sc[0], 0, pf[0]);
+    vread(j, 0, vt[0]);
+    vread(j, 1, vt[1]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_TRANS, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_VALU, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_DSR, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- G2
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[ks], qf[ks], ks == 0 ? cneg : sn[1], 0, 0, 0);
+    pgroup(sc[0], 1, pf[1]);
+    vread(j, 2, vt[2]);
+    vread(j, 3, vt[3]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_TRANS, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_VALU, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_DSR, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- every wave is past its last read of tile j; this wave's pieces of tile j+2 have landed (tile j+3 may still fly)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    stage(j + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- G3
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int dt = 0; dt < 2; dt++) ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt[ks][dt], pf[ks], ot[dt], 0, 0, 0);
+    pgroup(sc[1], 0, pf[2]);
+    kread(j + 2, 0, kfa);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_TRANS, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_VALU, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- G4
+    pgroup(sc[1], 1, pf[3]);
+#pragma unroll
+    for (int ks = 2; ks < 4; ks++)
+#pragma unroll
+      for (int dt = 0; dt < 2; dt++) ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt[ks][dt], pf[ks], ot[dt], 0, 0, 0);
+    kread(j + 2, 1, kfb);
+    const float mx = tile_max(sn);
+    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(SG_TRANS, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(SG_VALU, 6, 0);
+    __builtin_amdgcn_sched_group_barrier(SG_DSR, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(SG_TRANS, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(SG_VALU, 6, 0);
+    __builtin_amdgcn_sched_group_barrier(SG_DSR, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(SG_VALU, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(SG_VALU, 9, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    settle(sn, mx, j + 1, false);
+  };
+  for (int j = 0; j < nt; j += 2) {
+    body(sA, sB, j);
+    if (j + 1 < nt) body(sB, sA, j + 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+
+  const float l_i = l_a + l_b;
+  const float l_tot = l_i + __shfl_xor(l_i, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (q < Sq) {
+    bf16_t* op = O + (row0 + qoff + q) * ldo + hoff;
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int d0 = 32 * dt + 8 * rg + 4 * h2;
+        u32x2 pk = {pack_bf16(ot[dt][4 * rg] * inv, ot[dt][4 * rg + 1] * inv), pack_bf16(ot[dt][4 * rg + 2] * inv, ot[dt][4 * rg + 3] * inv)};
+        *(u32x2*)(op + d0) = pk;
+      }
+    if (h2 == 0) LSE[((size_t)b * H + head) * Sq + q] = (m2 + __log2f(l_tot)) * 0.6931471805599453f;
+  }
+}
+
+int g_variant = 0;  // tuning / A-B hook (tools/attn_*ab.py): 32 previous fwd kernel (2: its 3-wave build, 16: its 2-wave build), 1024 / 2048 previous dkv / dq kernels
 
 // A block-per-CU round holds 2 (<=256 VGPR) or 3 (<=168 VGPR) 4-wave blocks per CU.  The 3-wave build is a little slower per
 // block but wins whenever it saves a whole round of blocks (e.g. encoder: 56 x 12 = 672 blocks fit 768 slots, not 512).
@@ -201,7 +448,8 @@ int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf1
   if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 3)) { set_error("attention_fwd: bad shape B=%d S=%d H=%d ld=%d ldo=%d", B, S, H, ld, ldo); return SMBV_ERR_SHAPE; }
   if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || ((uintptr_t)O & 7)) { set_error("attention_fwd: alignment"); return SMBV_ERR_ALIGN; }
   const bool w3 = (g_variant & 2) || (!(g_variant & 16) && attn_prefer_3waves((long)cdiv(Sq, 128) * H * B));
-  if (w3) hipLaunchKernelGGL(attn_fwd_kernel<3>, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale);
+  if (!(g_variant & 32)) hipLaunchKernelGGL(attn_fwd2_kernel, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale);
+  else if (w3) hipLaunchKernelGGL(attn_fwd_kernel<3>, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale);
   else hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale);
   return check_launch("attention_fwd");
 }

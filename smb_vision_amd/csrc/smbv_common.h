@@ -44,6 +44,33 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const void* lds_addr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)lds_addr);
 }
 
+// ---- LDS-DMA hidden from hipcc's wait-count bookkeeping -------------------------------------------------------------------------
+// hipcc waits vmcnt(0) before any LDS read that follows an LDS-DMA it knows about (it cannot prove the two do not alias), which drains a
+// multi-tile ring at every tile.  Issued from an asm statement the copy is invisible to that pass; the kernel then owns the protocol:
+// a counted `s_waitcnt vmcnt(N)` by every issuing wave, then a barrier, then the reads.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// raw buffer descriptor (stride 0, `bytes` addressable; accesses past it read zeros), forced into SGPRs
+__device__ __forceinline__ i32x4 dma_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a & 0xffffffffull));
+  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffull));
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
+}
+// one wave-instruction: lane i copies 16 B from (descriptor base + voff) to LDS byte address lds_uniform + 16*i
+__device__ __forceinline__ void dma16_hidden(i32x4 rsrc, unsigned lds_uniform, int voff) {
+  unsigned keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_uniform), "v"(voff), "s"(rsrc)
+               : "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
