@@ -121,20 +121,30 @@ int gather_rows_bf16(const bf16_t* in, bf16_t* out, int rows, int D, long grp_in
 }
 
 // Deterministic column reduction of a partial-sum matrix part[nrows][ncols] -> out0[0:split) | out1[split:ncols).
-// 256 threads = 32 column lanes (float4 each -> 128 columns per block) x 8 row lanes, combined through LDS.
+// 256 threads = 8 column lanes (float4 each -> 32 columns per block) x 32 row lanes; a thread's rows (r, r+32, ...) are loaded four at
+// a time (the partial matrices have <= 64..128 rows: with one load in flight this kernel was pure latency), combined through LDS in a
+// fixed order.
 __global__ __launch_bounds__(256) void reduce_cols_kernel(const float* __restrict__ part, int nrows, int ncols, float* __restrict__ out0,
                                                           float* __restrict__ out1, int split) {
-  __shared__ f32x4 red[8][32];
-  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c4 = blockIdx.x * 32 + cl;  // float4 column index
+  __shared__ f32x4 red[32][8];
+  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c4 = blockIdx.x * 8 + cl;  // float4 column index
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (c4 * 4 < ncols)
-    for (int r = rl; r < nrows; r += 8) acc += *(const f32x4*)(part + (size_t)r * ncols + 4 * c4);
+  if (c4 * 4 < ncols) {
+    const float* p = part + 4 * c4;
+    int r = rl;
+    for (; r + 96 < nrows; r += 128) {
+      const f32x4 a = *(const f32x4*)(p + (size_t)r * ncols), b = *(const f32x4*)(p + (size_t)(r + 32) * ncols);
+      const f32x4 c = *(const f32x4*)(p + (size_t)(r + 64) * ncols), d = *(const f32x4*)(p + (size_t)(r + 96) * ncols);
+      acc += a; acc += b; acc += c; acc += d;
+    }
+    for (; r < nrows; r += 32) acc += *(const f32x4*)(p + (size_t)r * ncols);
+  }
   red[rl][cl] = acc;
   __syncthreads();
   if (rl == 0 && c4 * 4 < ncols) {
 #pragma unroll
-    for (int i = 1; i < 8; i++) acc += red[i][cl];
+    for (int i = 1; i < 32; i++) acc += red[i][cl];
     const int c = 4 * c4;
     if (c < split) *(f32x4*)(out0 + c) = acc;
     else *(f32x4*)(out1 + (c - split)) = acc;
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(256) void reduce_cols_kernel(const float* __restric
 
 int reduce_cols(const float* part, int nrows, int ncols, float* out0, float* out1, int split, hipStream_t st) {
   if ((ncols & 3) || (split & 3)) { set_error("reduce_cols: ncols/split must be multiples of 4"); return SMBV_ERR_SHAPE; }
-  hipLaunchKernelGGL(reduce_cols_kernel, dim3(cdiv(ncols, 128)), dim3(256), 0, st, part, nrows, ncols, out0, out1, split);
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3(cdiv(ncols, 32)), dim3(256), 0, st, part, nrows, ncols, out0, out1, split);
   return check_launch("reduce_cols");
 }
 
@@ -159,18 +169,38 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, in
   const int m0 = z * mchunk, m1 = min(M, m0 + mchunk);
   float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (n0 < N) {
-    for (int m = m0 + rl; m < m1; m += 16) {
+    auto src = [&](int m) -> const T* {
       size_t r = m;
       if (grp_in > 0) r = (size_t)(m / grp_in) * grp_out + (m % grp_in) + row_off;
+      return X + r * ld + n0;
+    };
+    auto add = [&](const u32x4* v) {
       if constexpr (sizeof(T) == 2) {
-        const u32x4 v = *(const u32x4*)(X + r * ld + n0);
 #pragma unroll
-        for (int i = 0; i < 4; i++) { a[2 * i] += bf_lo(v[i]); a[2 * i + 1] += bf_hi(v[i]); }
+        for (int i = 0; i < 4; i++) { a[2 * i] += bf_lo(v[0][i]); a[2 * i + 1] += bf_hi(v[0][i]); }
       } else {
-        const f32x4 v0 = *(const f32x4*)(X + r * ld + n0), v1 = *(const f32x4*)(X + r * ld + n0 + 4);
+        const f32x4 v0 = __builtin_bit_cast(f32x4, v[0]), v1 = __builtin_bit_cast(f32x4, v[1]);
 #pragma unroll
         for (int i = 0; i < 4; i++) { a[i] += v0[i]; a[4 + i] += v1[i]; }
       }
+    };
+    constexpr int W = sizeof(T) == 2 ? 1 : 2;  // 16-byte words per 8 columns
+    constexpr int U = 8;                       // rows in flight per thread (the loop is latency-bound otherwise)
+    int m = m0 + rl;
+    for (; m + 16 * (U - 1) < m1; m += 16 * U) {
+      u32x4 v[U][W];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int k = 0; k < W; k++) v[u][k] = ((const u32x4*)src(m + 16 * u))[k];
+#pragma unroll
+      for (int u = 0; u < U; u++) add(v[u]);  // fixed order: the sum is reproducible
+    }
+    for (; m < m1; m += 16) {
+      u32x4 v[W];
+#pragma unroll
+      for (int k = 0; k < W; k++) v[k] = ((const u32x4*)src(m))[k];
+      add(v);
     }
   }
 #pragma unroll

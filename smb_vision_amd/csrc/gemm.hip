@@ -512,8 +512,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
 
 __global__ void reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ slabs, int nslab, size_t n4, size_t slab_stride4) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    f32x4 s = ((const f32x4*)slabs)[i];
-    for (int z = 1; z < nslab; z++) s += ((const f32x4*)slabs)[i + z * slab_stride4];
+    const f32x4* p = (const f32x4*)slabs + i;
+    f32x4 s = p[0];
+    int z = 1;
+    for (; z + 3 < nslab; z += 4) {  // four slabs in flight; summed in slab order (reproducible)
+      const f32x4 a = p[z * slab_stride4], b = p[(z + 1) * slab_stride4], c = p[(z + 2) * slab_stride4], d = p[(z + 3) * slab_stride4];
+      s += a; s += b; s += c; s += d;
+    }
+    for (; z < nslab; z++) s += p[z * slab_stride4];
     ((f32x4*)out)[i] = s;
   }
 }

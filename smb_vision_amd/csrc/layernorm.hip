@@ -100,8 +100,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     const float mu = mean[row], rs = rstd[row];
     const float* xp = x + xr * D;
     const bf16_t* dyp = dy + (size_t)row * D;
-    f32x4 xh[NV], gy[NV];
+    f32x4 xh[NV], gy[NV], dr[NV];
     float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {  // the residual gradient is fetched with the other operands, not after the two reductions
+      const int c = l + 64 * i;
+      dr[i] = (dres && c < nv) ? ((const f32x4*)(dres + xr * D))[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       const int c = l + 64 * i;
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       const int c = l + 64 * i;
       if (c < nv) {
         f32x4 o = (gy[i] - s1 - xh[i] * s2) * rs;
-        if (dres) o += ((const f32x4*)(dres + xr * D))[c];
+        o += dr[i];
         if (dx) ((f32x4*)(dx + xr * D))[c] = o;
         if (dx_bf16) {
           u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
