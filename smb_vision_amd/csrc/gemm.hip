@@ -147,17 +147,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
 // of the (now idle) staging buffers and re-reads it row-wise, so that every global access of the epilogue - residual / position
 // rows, saved pre-activations, fp32 and bf16 outputs - is a fully coalesced 16/32-byte-per-lane row segment instead of
 // 8-byte fragments scattered over 16 rows.  (With K = 384..768 the scattered form cost as much as the whole main loop.)
-__device__ __forceinline__ void epilogue_nt_lds(f32x4 (&acc)[4][4], unsigned char* smem, int w, int m0, int n0, int wm, int wn, int l, int M,
-                                                int N, const GemmEpi& e_in) {
+// One 32-row x 64-column piece of a wave's accumulator block (row tiles a0, a1; the accumulators hold D^T: register e of acc[i][j] is
+// column j*16 + 4*(lane>>4) + e, row i*16 + (lane&15)), staged through the wave's private LDS area ws and written out row-wise.
+__device__ __forceinline__ void epilogue_rows32(float* ws, const f32x4 (&a0)[4], const f32x4 (&a1)[4], const int mbase, const int n, const bool ncol,
+                                                const f32x4 b0, const f32x4 b1, const int l, const int M, const GemmEpi& e) {
   constexpr int LDW = 68;
-  const GemmEpi e = e_in;  // by-value copy: keeps the lambda below from pinning the kernel-argument struct in memory
-  float* ws = (float*)(smem + w * 16384);
   const int c8 = l & 7, r8 = l >> 3;
-  const int n = n0 + wn * 64 + c8 * 8;
-  const bool ncol = n < N;
-  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
-  if (e.bias && ncol) { b0 = *(const f32x4*)(e.bias + n); b1 = *(const f32x4*)(e.bias + n + 4); }
-  auto do_half = [&](const int half, const f32x4 (&a0)[4], const f32x4 (&a1)[4]) __attribute__((always_inline)) {
+  {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       *(f32x4*)(ws + (l & 15) * LDW + j * 16 + 4 * (l >> 4)) = a0[j];
@@ -169,7 +165,7 @@ __device__ __forceinline__ void epilogue_nt_lds(f32x4 (&acc)[4][4], unsigned cha
 #pragma unroll
     for (int it = 0; it < 4; it++) {
       const int r = it * 8 + r8;
-      const int m = m0 + wm * 64 + half * 32 + r;
+      const int m = mbase + r;
       f32x4 v0 = *(const f32x4*)(ws + r * LDW + c8 * 8), v1 = *(const f32x4*)(ws + r * LDW + c8 * 8 + 4);
       if (m < M && ncol) {
         size_t orow = (size_t)m;
@@ -212,9 +208,19 @@ __device__ __forceinline__ void epilogue_nt_lds(f32x4 (&acc)[4][4], unsigned cha
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
-  do_half(0, acc[0], acc[1]);
-  do_half(1, acc[2], acc[3]);
+  }
+}
+
+__device__ __forceinline__ void epilogue_nt_lds(f32x4 (&acc)[4][4], unsigned char* smem, int w, int m0, int n0, int wm, int wn, int l, int M,
+                                                int N, const GemmEpi& e_in) {
+  const GemmEpi e = e_in;  // by-value copy: keeps the kernel-argument struct from being pinned in memory
+  float* ws = (float*)(smem + w * 16384);
+  const int n = n0 + wn * 64 + (l & 7) * 8;
+  const bool ncol = n < N;
+  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+  if (e.bias && ncol) { b0 = *(const f32x4*)(e.bias + n); b1 = *(const f32x4*)(e.bias + n + 4); }
+  epilogue_rows32(ws, acc[0], acc[1], m0 + wm * 64, n, ncol, b0, b1, l, M, e);
+  epilogue_rows32(ws, acc[2], acc[3], m0 + wm * 64 + 32, n, ncol, b0, b1, l, M, e);
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,

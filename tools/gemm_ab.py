@@ -11,7 +11,7 @@ def timeit(fn, iters=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
 variants = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 32]
-shapes = [(7168, 2304, 768, {}), (7168, 768, 768, {}), (7168, 3072, 768, dict(gelu=True, save_pre=True)), (7168, 768, 3072, {}),
+shapes = [(7168, 2304, 768, {}), (7168, 2304, 3072, {}), (7168, 768, 768, {}), (7168, 3072, 768, dict(gelu=True, save_pre=True)), (7168, 768, 3072, {}),
           (20480, 1152, 384, {}), (20480, 384, 1536, {}), (20480, 1536, 384, dict(gelu=True, save_pre=True)), (13312, 4096, 384, {}), (7168, 768, 4096, {})]
 g = torch.Generator(device="cuda").manual_seed(0)
 for M, N, K, kw in shapes:
