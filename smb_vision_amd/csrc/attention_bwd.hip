@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
       a = *(const u32x4*)(K + (row0 + key) * ld + hoff + 16 * ks + 8 * h2);
       bb = *(const u32x4*)(V + (row0 + key) * ld + hoff + 16 * ks + 8 * h2);
     }
+    asm volatile("" : "+v"(bb));  // (consumed here so that hipcc waits for the load here, not with a vmcnt(0) inside the tile loop)
     kf[ks] = scale_frag(a, c);
     vf[ks] = __builtin_bit_cast(bf16x8, bb);
   }
@@ -279,8 +280,8 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
   // Q / dO tiles go global -> LDS by LDS-DMA: wave w stages rows 32w..32w+31 of both images as 4 + 4 pieces of 8 rows x 128 B.
   // A piece lands lane-linear (lane -> row l>>3, chunk position l&7), so the swz128 permutation is applied to the SOURCE chunk.
   // Rows >= Sq are outside the descriptors' range and arrive as zeros.
-  const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc((void*)(Q + (row0 + qoff) * ld + hoff), 0, (int)(((size_t)(Sq - 1) * ld + 64) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)(dO + (row0 + qoff) * ldo + hoff), 0, (int)(((size_t)(Sq - 1) * ldo + 64) * 2), 0x00020000);
+  const i32x4 rsq = dma_rsrc(Q + (row0 + qoff) * ld + hoff, (unsigned)(((size_t)(Sq - 1) * ld + 64) * 2));
+  const i32x4 rsd = dma_rsrc(dO + (row0 + qoff) * ldo + hoff, (unsigned)(((size_t)(Sq - 1) * ldo + 64) * 2));
   int oq[4], od[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -291,22 +292,30 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
     od[i] = (row * ldo + cs * 8) * 2;
   }
   const int oq0 = oq[0], oq1 = oq[1], oq2 = oq[2], oq3 = oq[3], od0 = od[0], od1 = od[1], od2 = od[2], od3 = od[3];
-  float rstat = 0.f;
+  const unsigned lds_w = __builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem) + (t >> 6) * 4096));
+  // The copies and the row-constant load are issued from asm statements (smbv_common.h): hipcc would otherwise drain them with a
+  // vmcnt(0) in front of the very next LDS read.  They are waited for once, explicitly, before the "landed" barrier.
+  float rraw = 0.f;
   auto stage = [&](int buf, int qt) __attribute__((always_inline)) {
-    unsigned char* sqw = smem + buf * BUF + w * 4096;
-    unsigned char* sdw = sqw + QT * 128;
+    const unsigned dq_ = lds_w + (unsigned)buf * BUF, dd_ = dq_ + QT * 128;
     const int kq = qt * QT * ld * 2, kd = qt * QT * ldo * 2;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (__attribute__((address_space(3))) void*)(sqw), 16, oq0 + kq, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (__attribute__((address_space(3))) void*)(sdw), 16, od0 + kd, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (__attribute__((address_space(3))) void*)(sqw + 1024), 16, oq1 + kq, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (__attribute__((address_space(3))) void*)(sdw + 1024), 16, od1 + kd, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (__attribute__((address_space(3))) void*)(sqw + 2048), 16, oq2 + kq, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (__attribute__((address_space(3))) void*)(sdw + 2048), 16, od2 + kd, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (__attribute__((address_space(3))) void*)(sqw + 3072), 16, oq3 + kq, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (__attribute__((address_space(3))) void*)(sdw + 3072), 16, od3 + kd, 0, 0, 0);
-    const int q0 = qt * QT;
-    if (t < QT) rstat = (q0 + t < Sq) ? -lse_p[q0 + t] * 1.4426950408889634f : -INFINITY;  // padded rows: p = exp2(-inf) = 0
-    else if (t < 2 * QT) rstat = (q0 + t - QT < Sq) ? -del_p[q0 + t - QT] : 0.f;
+    dma16_hidden(rsq, dq_, oq0 + kq);
+    dma16_hidden(rsd, dd_, od0 + kd);
+    dma16_hidden(rsq, dq_ + 1024, oq1 + kq);
+    dma16_hidden(rsd, dd_ + 1024, od1 + kd);
+    dma16_hidden(rsq, dq_ + 2048, oq2 + kq);
+    dma16_hidden(rsd, dd_ + 2048, od2 + kd);
+    dma16_hidden(rsq, dq_ + 3072, oq3 + kq);
+    dma16_hidden(rsd, dd_ + 3072, od3 + kd);
+    const int qi = min(qt * QT + (t & (QT - 1)), Sq - 1);  // threads 0..QT-1: lse, QT..2QT-1: delta (rows past Sq: clamped, fixed up below)
+    const float* src = (t < QT ? lse_p : del_p) + qi;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(rraw) : "v"(src) : "memory");
+  };
+  float rstat = 0.f;
+  auto landed = [&](int qt) __attribute__((always_inline)) {  // everything stage(.., qt) requested has arrived (this wave's share)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rraw) : : "memory");
+    const bool ok = qt * QT + (t & (QT - 1)) < Sq;
+    rstat = t < QT ? (ok ? -rraw * 1.4426950408889634f : -INFINITY) : (ok ? -rraw : 0.f);  // padded rows: p = exp2(-inf) = 0
   };
   // row constants, arranged so that each lane half reads its 16 accumulator rows (8*rg + 4*h2 + e) of a 32-row sub-tile as ONE
   // contiguous 64-byte vector: position = 32*sub + 16*h2 + 4*rg + e
@@ -333,8 +342,9 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
   };
 
   stage(0, 0);
+  landed(0);
   put_stats(0);
-  __syncthreads();  // (hipcc drains the LDS-DMA with vmcnt(0) in front of the barrier)
+  __syncthreads();
   bf16x8 qa[4], da[4];
   f32x16 s, dp;
   {
@@ -443,8 +453,8 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
       }
       __builtin_amdgcn_sched_barrier(0);
       if (sub == 2) {
-        if (more) put_stats(buf ^ 1);
-        __syncthreads();  // the new tile has landed (vmcnt(0) + barrier) before sub-tile 3 prefetches across the seam
+        if (more) { landed(qt + 1); put_stats(buf ^ 1); }
+        __syncthreads();  // the new tile is visible before sub-tile 3 prefetches across the seam
       }
     }
   }
@@ -630,6 +640,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
       a = *(const u32x4*)(Q + (row0 + qoff + q) * ld + hoff + 16 * ks + 8 * h2);
       bb = *(const u32x4*)(dO + (row0 + qoff + q) * ldo + hoff + 16 * ks + 8 * h2);
     }
+    asm volatile("" : "+v"(bb));  // (consumed here so that hipcc waits for the load here, not with a vmcnt(0) inside the tile loop)
     qf[ks] = scale_frag(a, c);
     dof[ks] = __builtin_bit_cast(bf16x8, bb);
   }
@@ -638,6 +649,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
     nlse2 = -LSE[((size_t)b * H + head) * Sq + q] * 1.4426950408889634f;
     ndl = -delta[((size_t)b * H + head) * Sq + q];
   }
+  asm volatile("" : "+v"(nlse2), "+v"(ndl));
   f32x16 sinit, dinit;
 #pragma unroll
   for (int i = 0; i < 16; i++) { sinit[i] = nlse2; dinit[i] = ndl; }
@@ -647,8 +659,8 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
 
   // LDS-DMA staging: wave w copies rows 32w..32w+31 of the K and V tiles (4 + 4 pieces of 8 rows x 128 B, swz128 applied to the
   // source chunk); rows >= S are outside the descriptors and arrive as zeros.
-  const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc((void*)(K + row0 * ld + hoff), 0, (int)(((size_t)(S - 1) * ld + 64) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc((void*)(V + row0 * ld + hoff), 0, (int)(((size_t)(S - 1) * ld + 64) * 2), 0x00020000);
+  const i32x4 rsk = dma_rsrc(K + row0 * ld + hoff, (unsigned)(((size_t)(S - 1) * ld + 64) * 2));
+  const i32x4 rsv = dma_rsrc(V + row0 * ld + hoff, (unsigned)(((size_t)(S - 1) * ld + 64) * 2));
   int og[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -657,18 +669,19 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
     og[i] = (row * ld + ((l & 7) ^ (((x & 1) << 2) | (x >> 1))) * 8) * 2;
   }
   const int og0 = og[0], og1 = og[1], og2 = og[2], og3 = og[3];
+  const unsigned lds_w = __builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem) + (t >> 6) * 4096));
+  // (issued from asm statements, see smbv_common.h: hipcc would drain a visible LDS-DMA in front of the next LDS read)
   auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
-    unsigned char* skw = smem + buf * BUF + w * 4096;
-    unsigned char* svw = skw + KT * 128;
+    const unsigned dk_ = lds_w + (unsigned)buf * BUF, dv_ = dk_ + KT * 128;
     const int ko = kt * KT * ld * 2;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (__attribute__((address_space(3))) void*)(skw), 16, og0 + ko, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (__attribute__((address_space(3))) void*)(svw), 16, og0 + ko, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (__attribute__((address_space(3))) void*)(skw + 1024), 16, og1 + ko, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (__attribute__((address_space(3))) void*)(svw + 1024), 16, og1 + ko, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (__attribute__((address_space(3))) void*)(skw + 2048), 16, og2 + ko, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (__attribute__((address_space(3))) void*)(svw + 2048), 16, og2 + ko, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (__attribute__((address_space(3))) void*)(skw + 3072), 16, og3 + ko, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (__attribute__((address_space(3))) void*)(svw + 3072), 16, og3 + ko, 0, 0, 0);
+    dma16_hidden(rsk, dk_, og0 + ko);
+    dma16_hidden(rsv, dv_, og0 + ko);
+    dma16_hidden(rsk, dk_ + 1024, og1 + ko);
+    dma16_hidden(rsv, dv_ + 1024, og1 + ko);
+    dma16_hidden(rsk, dk_ + 2048, og2 + ko);
+    dma16_hidden(rsv, dv_ + 2048, og2 + ko);
+    dma16_hidden(rsk, dk_ + 3072, og3 + ko);
+    dma16_hidden(rsv, dv_ + 3072, og3 + ko);
   };
 
   const int g1 = (l >> 4) & 1, qq = (l >> 2) & 3, pp = l & 3;
@@ -695,7 +708,8 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
   const int nt = (S + KT - 1) / KT;
   stage(0, 0);
   if (nt > 1) stage(1, 1);
-  __syncthreads();  // (hipcc drains the LDS-DMA with vmcnt(0) in front of the barrier)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   bf16x8 ka[4], va[4], tk[2][2];
   f32x16 sA, sB, dp;
   {
@@ -764,12 +778,14 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
     const unsigned char* nxt = smem + ((kt & 1) ^ 1) * BUF;
     body(sA, sB, cur, 1, cur, 2);
     body(sB, sA, cur, 2, cur, 3);
-    __syncthreads();  // tile kt+1 has landed (vmcnt(0) + barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt+1 (requested a whole tile ago) have landed
+    __syncthreads();                                  // ... everyone's have
     body(sA, sB, cur, 3, nxt, 0);
     __syncthreads();  // every wave is done with tile kt: its buffer takes tile kt+2
     if (kt + 2 < nt) stage(kt & 1, kt + 2);
     body(sB, sA, nxt, 0, nxt, 1);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
 
   if (q < Sq) {
     bf16_t* qp = dQ + (row0 + qoff + q) * ldd + hoff;

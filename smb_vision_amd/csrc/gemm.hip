@@ -435,8 +435,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
   const int mbeg = z * mchunk, mend = min(M, mbeg + mchunk);
   const int nk = (mend - mbeg + BK - 1) / BK;
 
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, mend > 0 ? (int)(((size_t)(mend - 1) * ldx + N1) * 2) : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)Y, 0, mend > 0 ? (int)(((size_t)(mend - 1) * ldy + N2) * 2) : 0, 0x00020000);
+  // (the copies are issued from asm statements - smbv_common.h - because hipcc puts a vmcnt(0) in front of the first ds_read_b64_tr_b16
+  // that follows an LDS-DMA it can see, which serialised every K-step's copy with its MFMAs)
+  const i32x4 rx = dma_rsrc(X, mend > 0 ? (unsigned)(((size_t)(mend - 1) * ldx + N1) * 2) : 0u);
+  const i32x4 ry = dma_rsrc(Y, mend > 0 ? (unsigned)(((size_t)(mend - 1) * ldy + N2) * 2) : 0u);
   // piece i (0..3) of wave w covers tile rows 16w + 4i .. +3; lane -> (row_in = l>>4, 16-B chunk position = l&15)
   const int rin = l >> 4, cp = l & 15;
   int ox[4], oy[4];
@@ -450,17 +452,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
   }
   const int ox0 = ox[0], ox1 = ox[1], ox2 = ox[2], ox3 = ox[3], oy0 = oy[0], oy1 = oy[1], oy2 = oy[2], oy3 = oy[3];
   const int kx = BK * ldx * 2, ky = BK * ldy * 2;
+  const unsigned lds_w = __builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem) + w * 4096));
   auto stage = [=](int buf, int kt) __attribute__((always_inline)) {
-    unsigned char* sx = smem + buf * (2 * BK * 256) + w * 4096;
-    unsigned char* sy = sx + BK * 256;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sx), 16, ox0 + kt * kx, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (__attribute__((address_space(3))) void*)(sy), 16, oy0 + kt * ky, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sx + 1024), 16, ox1 + kt * kx, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (__attribute__((address_space(3))) void*)(sy + 1024), 16, oy1 + kt * ky, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sx + 2048), 16, ox2 + kt * kx, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (__attribute__((address_space(3))) void*)(sy + 2048), 16, oy2 + kt * ky, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sx + 3072), 16, ox3 + kt * kx, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (__attribute__((address_space(3))) void*)(sy + 3072), 16, oy3 + kt * ky, 0, 0, 0);
+    const unsigned sx = lds_w + (unsigned)buf * (2 * BK * 256), sy = sx + BK * 256;
+    dma16_hidden(rx, sx, ox0 + kt * kx);
+    dma16_hidden(ry, sy, oy0 + kt * ky);
+    dma16_hidden(rx, sx + 1024, ox1 + kt * kx);
+    dma16_hidden(ry, sy + 1024, oy1 + kt * ky);
+    dma16_hidden(rx, sx + 2048, ox2 + kt * kx);
+    dma16_hidden(ry, sy + 2048, oy2 + kt * ky);
+    dma16_hidden(rx, sx + 3072, ox3 + kt * kx);
+    dma16_hidden(ry, sy + 3072, oy3 + kt * ky);
   };
 
   f32x4 acc[4][4];
@@ -470,6 +472,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
     for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if (nk > 0) stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int g = l >> 4, q = (l >> 2) & 3, p = l & 3;
   for (int kt = 0; kt < nk; kt++) {
@@ -501,6 +504,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
         for (int j = 0; j < 4; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[j], xf[i], acc[i][j], 0, 0, 0);  // D[n2][n1]
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next K-step's copy had this step's MFMAs to land
     __syncthreads();
   }
 
