@@ -80,6 +80,15 @@ int smbv_attention_bwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* 
                        int ldo, const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S,
                        int H, int Dh, float scale, int parts /* bit0 delta, bit1 dK/dV, bit2 dQ; 7 = all */, int Sq, int q_off, smbv_stream stream);
 
+/* Input feed, device side: the per-volume tail of the reference's MONAI pipeline - ScaleIntensityRanged ->
+ * SpatialPadd -> CenterSpatialCropd -> PermuteImage (src/dataloader/mim.py:154-169, 88-93) - in one pass from the uploaded raw volume
+ * to the model input.  src: [B, H0, W0, D0] (D0 fastest; what EnsureChannelFirstd leaves of a NIfTI array), src_dtype 0 int16,
+ * 1 uint16, 2 bf16, 3 fp32; dst: fp32 [B, D, 1, H, W].  v = (x - a_min) / (a_max - a_min) * (b_max - b_min) + b_min, clipped to
+ * [b_min, b_max] when clip != 0; symmetric zero pad, centre crop. */
+enum { SMBV_SRC_I16 = 0, SMBV_SRC_U16 = 1, SMBV_SRC_BF16 = 2, SMBV_SRC_F32 = 3 };
+int smbv_prepare_volume(const void* src, int src_dtype, float* dst, int B, int H0, int W0, int D0, int H, int W, int D, float a_min,
+                        float a_max, float b_min, float b_max, int clip, smbv_stream stream);
+
 /* Brick readers over pixel_values fp32 [B,T,1,H,W] (spec :172-177,190-191 Conv3d patchify; :835-867 labels; :896-897 MSE).
  * idx: int32 token ids (0..N-1) of the selected bricks, `per_batch` per volume, rows = B*per_batch. */
 int smbv_gather_bricks(const float* pix, const int32_t* idx, int rows, int per_batch, smbv_bf16* out, int T, int H, int W, int ts,

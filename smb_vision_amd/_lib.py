@@ -89,6 +89,7 @@ _SIGS = {
     "smbv_layernorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "smbv_attention_fwd": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, c_f]),
     "smbv_attention_bwd": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, c_f]),
+    "smbv_prepare_volume": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, c_f]),
     "smbv_gather_bricks": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "smbv_brick_stats": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "smbv_mse_fwd": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),

@@ -93,6 +93,11 @@ int smbv_attention_bwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* 
   return attention_bwd(Q, K, V, ld, O, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, H, Dh, scale, parts, Sq, q_off, (hipStream_t)stream);
 }
 
+int smbv_prepare_volume(const void* src, int src_dtype, float* dst, int B, int H0, int W0, int D0, int H, int W, int D, float a_min, float a_max,
+                        float b_min, float b_max, int clip, smbv_stream stream) {
+  if (!src || !dst) { set_error("smbv_prepare_volume: null operand"); return SMBV_ERR_ARG; }
+  return prepare_volume(src, src_dtype, dst, B, H0, W0, D0, H, W, D, a_min, a_max, b_min, b_max, clip, (hipStream_t)stream);
+}
 int smbv_gather_bricks(const float* pix, const int32_t* idx, int rows, int per_batch, smbv_bf16* out, int T, int H, int W, int ts, int ps, smbv_stream stream) {
   if (!pix || !idx || !out) { set_error("smbv_gather_bricks: null operand"); return SMBV_ERR_ARG; }
   return gather_bricks(pix, idx, rows, per_batch, out, T, H, W, ts, ps, (hipStream_t)stream);
