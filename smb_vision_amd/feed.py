@@ -3,7 +3,8 @@
 staging on a copy stream, and the tail of the reference's MONAI pipeline (``src/dataloader/mim.py:154-169, 88-93``: ScaleIntensityRanged
 -> SpatialPadd -> CenterSpatialCropd -> PermuteImage) runs as one HIP kernel (``smbv_prepare_volume``) on the device.
 
-    feeder = VolumeFeeder(source, device, image_size=512, depth=320)     # source yields (raw ndarray/tensor [H0,W0,D0], extras)
+    feeder = VolumeFeeder(source, device, image_size=512, depth=320)     # source yields (raw ndarray/tensor [H0,W0,D0] or a
+                                                                           # volcache.VolumeRecord, extras)
     for pixel_values, extras in feeder:                                    # pixel_values: fp32 [1, D, 1, H, W] on the device
         out = model(pixel_values=pixel_values, bool_masked_pos=extras["mask"][None].to(device))
 
@@ -77,10 +78,22 @@ class VolumeFeeder:
             for i, (raw, extras) in enumerate(self.source):
                 if stop.is_set():
                     return
+                k = i % self.nhost
+                if hasattr(raw, "read_into"):  # a record that fills a host buffer itself (volcache.VolumeRecord): no intermediate copy
+                    if raw.dtype not in _DTYPES:
+                        raise ValueError(f"unsupported raw dtype {raw.dtype} (int16, uint16, bfloat16, float32)")
+                    if self._pinned[k] is None or tuple(self._pinned[k].shape) != tuple(raw.shape) or self._pinned[k].dtype != raw.dtype or self._borrowed[k]:
+                        self._pinned[k] = torch.empty(tuple(raw.shape), dtype=raw.dtype).pin_memory()
+                    ev = self._h2d_done[k]
+                    if ev is not None:
+                        ev.synchronize()
+                    raw.read_into(self._pinned[k])
+                    self._borrowed[k] = False
+                    q.put((k, extras))
+                    continue
                 t = torch.from_numpy(np.ascontiguousarray(raw)) if isinstance(raw, np.ndarray) else raw.contiguous()
                 if t.dtype not in _DTYPES:
                     raise ValueError(f"unsupported raw dtype {t.dtype} (int16, uint16, bfloat16, float32)")
-                k = i % self.nhost
                 if t.is_pinned():  # a loader that already reads into page-locked memory: uploaded from where it is (the loader owns its reuse)
                     self._pinned[k] = t
                 else:

@@ -88,3 +88,21 @@ def test_volume_feeder_propagates_source_errors(feed):
     next(it)
     with pytest.raises(RuntimeError, match="source failed"):
         next(it)
+
+
+def test_cached_volumes_through_the_feeder(feed, tmp_path):
+    from smb_vision_amd import volcache as vc
+    rng = np.random.default_rng(5)
+    raws, paths = [], []
+    for i in range(4):
+        r = rng.integers(-1500, 1500, size=(40 + 3 * i, 48, 20 + i), dtype=np.int16)
+        p = str(tmp_path / f"v{i}.smbvol")
+        vc.write_volume(p, r)
+        raws.append(r)
+        paths.append(p)
+    got = []
+    for pix, extras in feed.VolumeFeeder(vc.CachedVolumeSource(paths, epochs=2), "cuda:0", 64, 32):
+        got.append((extras["path"], pix[0].cpu().numpy().copy()))
+    assert [p for p, _ in got] == paths + paths
+    for (p, a) in got:
+        assert np.array_equal(a, fo.prepare_volume(raws[paths.index(p)], 64, 32))
