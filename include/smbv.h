@@ -163,6 +163,36 @@ int smbv_mim_forward(const smbv_mim_cfg* cfg, const smbv_mim_tensors* params, co
 int smbv_mim_backward(const smbv_mim_cfg* cfg, const smbv_mim_tensors* params, const smbv_mim_tensors* grads, const smbv_mim_io* io,
                       void* ws, size_t ws_bytes, void** events, int n_events, smbv_stream stream);
 
+/* ---- encoder-only forward: VideoMAEModel.forward (spec :509-655) as src/run_inference.py:78-83 calls it for the
+ *      embedding export (all tokens, no mask) and as the classification head (spec :917-989) sits on it.  Forward only. ---- */
+
+typedef struct smbv_encoder_cfg {
+  int B, T, H, W;                 /* pixel_values fp32 [B,T,1,H,W] */
+  int ps, ts;
+  int N, Nsel;                    /* tokens per volume; tokens processed (N without a mask, the visible ones with bool_masked_pos) */
+  int d, heads, ff, layers;
+  float ln_eps;                   /* config.layer_norm_eps */
+  int final_ln;                   /* VideoMAEModel.layernorm: present iff !config.use_mean_pooling (spec :517-520) */
+  float final_ln_eps;
+} smbv_encoder_cfg;
+
+typedef struct smbv_encoder_tensors {
+  float *pe_w, *pe_b;             /* embeddings.patch_embeddings.projection */
+  smbv_layer_ptrs enc[SMBV_MAX_LAYERS];
+  float *lnf_w, *lnf_b;           /* layernorm.{weight,bias} or NULL */
+} smbv_encoder_tensors;
+
+typedef struct smbv_encoder_io {
+  const float* pixel_values;
+  const int32_t* sel_idx;         /* int32 [B,Nsel] ascending token ids to process (0..N-1 each when there is no mask) */
+  const float* pos_enc;           /* fp32 [N,d] sin-cos table */
+  float* last_hidden_state;       /* fp32 [B*Nsel, d] */
+} smbv_encoder_io;
+
+size_t smbv_encoder_workspace_bytes(const smbv_encoder_cfg* cfg);
+int smbv_encoder_forward(const smbv_encoder_cfg* cfg, const smbv_encoder_tensors* params, const smbv_encoder_io* io, void* ws, size_t ws_bytes,
+                         smbv_stream stream);
+
 /* ---- fused optimizer tail: clip_grad_norm_ + AdamW as HF Trainer runs them for the reference
  *      (site-packages/transformers/trainer.py:2539, :1785; --max_grad_norm / adamw_torch of scripts/training/run_mim.sh) ---- */
 

@@ -262,6 +262,34 @@ def mim_forward(p: "dict[str, torch.Tensor]", cfg: MIMConfig, pixel_values: torc
     return loss, logits
 
 
+def encoder_forward(p, cfg: MIMConfig, pixel_values, bool_masked_pos=None, prefix="videomae.", final_ln=False, emulate_bf16=False):
+    """VideoMAEModel.forward (spec :509-655; embeddings :124-139): all tokens when bool_masked_pos is None (the embedding export of
+    src/run_inference.py:78-83), the visible ones otherwise; final ``layernorm`` only when the config has use_mean_pooling=False (:517-520)."""
+    emu = emulate_bf16
+    B = pixel_values.shape[0]
+    N, d = cfg.num_patches, cfg.hidden_size
+    emb = patch_embed(pixel_values, p[prefix + "embeddings.patch_embeddings.projection.weight"],
+                      p[prefix + "embeddings.patch_embeddings.projection.bias"], cfg, emu)
+    x = emb + sinusoid_table(N, d)[None]
+    if bool_masked_pos is not None:
+        x = x[~bool_masked_pos].reshape(B, -1, d)
+    for i in range(cfg.num_hidden_layers):
+        x = layer(x, p, f"{prefix}encoder.layer.{i}.", cfg.num_attention_heads, cfg.layer_norm_eps, emu)
+    if final_ln:
+        x = F.layer_norm(x, (d,), p[prefix + "layernorm.weight"], p[prefix + "layernorm.bias"], cfg.layer_norm_eps)
+    return x
+
+
+def classification_forward(p, cfg: MIMConfig, pixel_values, additional_features=None, emulate_bf16=False):
+    """VideoMAEForVideoClassification.forward with use_mean_pooling=True (spec :917-989): mean over tokens -> fc_norm (torch default
+    eps 1e-5, :925) -> [concat additional_features] -> classifier."""
+    seq = encoder_forward(p, cfg, pixel_values, None, "videomae.", False, emulate_bf16)
+    pooled = F.layer_norm(seq.mean(1), (cfg.hidden_size,), p["fc_norm.weight"], p["fc_norm.bias"], 1e-5)
+    if additional_features is not None:
+        pooled = torch.cat([pooled, additional_features], dim=-1)
+    return F.linear(pooled, p["classifier.weight"], p["classifier.bias"])
+
+
 def mim_step(p, cfg, pixel_values, bool_masked_pos, emulate_bf16=False):
     """Forward + backward; returns (loss, logits, grads dict) — what one train step hands the optimizer."""
     leaf = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}

@@ -47,6 +47,19 @@ class MimIO(C.Structure):
                 ("loss", c_f), ("logits", c_f), ("grad_scale", c_f)]
 
 
+class EncoderCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "T", "H", "W", "ps", "ts", "N", "Nsel", "d", "heads", "ff", "layers")] + \
+               [("ln_eps", C.c_float), ("final_ln", C.c_int), ("final_ln_eps", C.c_float)]
+
+
+class EncoderTensors(C.Structure):
+    _fields_ = [("pe_w", c_f), ("pe_b", c_f), ("enc", LayerPtrs * MAX_LAYERS), ("lnf_w", c_f), ("lnf_b", c_f)]
+
+
+class EncoderIO(C.Structure):
+    _fields_ = [("pixel_values", c_f), ("sel_idx", c_f), ("pos_enc", c_f), ("last_hidden_state", c_f)]
+
+
 class AdamChunk(C.Structure):
     _fields_ = [("p", c_f), ("g", c_f), ("m", c_f), ("v", c_f), ("n", C.c_int32), ("group", C.c_int32)]
 
@@ -110,6 +123,8 @@ _SIGS = {
     "smbv_vjepa_workspace_bytes": (C.c_size_t, [C.POINTER(VjepaCfg)]),
     "smbv_vjepa_forward": (C.c_int, [C.POINTER(VjepaCfg), C.POINTER(VjepaTensors), C.POINTER(VjepaIO), c_f, C.c_size_t, c_f]),
     "smbv_vjepa_backward": (C.c_int, [C.POINTER(VjepaCfg), C.POINTER(VjepaTensors), C.POINTER(VjepaTensors), C.POINTER(VjepaIO), c_f, C.c_size_t, c_f]),
+    "smbv_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderCfg)]),
+    "smbv_encoder_forward": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(EncoderTensors), C.POINTER(EncoderIO), c_f, C.c_size_t, c_f]),
     "smbv_mim_workspace_bytes": (C.c_size_t, [C.POINTER(MimCfg)]),
     "smbv_mim_forward": (C.c_int, [C.POINTER(MimCfg), C.POINTER(MimTensors), C.POINTER(MimIO), c_f, C.c_size_t, c_f]),
     "smbv_mim_backward": (C.c_int, [C.POINTER(MimCfg), C.POINTER(MimTensors), C.POINTER(MimTensors), C.POINTER(MimIO), c_f, C.c_size_t,

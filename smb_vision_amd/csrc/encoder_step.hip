@@ -1,0 +1,129 @@
+// Encoder-only forward: VideoMAEModel.forward (src/models/videomae/modeling_videomae.py:509-655) - patch
+// embedding + sin-cos rows of the selected tokens, L pre-LN blocks, optional final LayerNorm (absent when config.use_mean_pooling,
+// :517-520) - as used by the embedding export (src/run_inference.py:78-83: model.videomae(image), all 20,480 tokens, no mask) and
+// under the classification head (spec :917-989).  Forward only: one shared set of activation buffers serves every layer.
+#include "block.h"
+#include "../../include/smbv.h"
+
+namespace smbv {
+
+struct EncWs {
+  bf16_t* pe_w;
+  LayerWs L[SMBV_MAX_LAYERS];
+  bf16_t *a_patch, *lnf_bf16;
+  float *x0, *x1, *meanf, *rstdf;
+  BwdScratch sc;
+  PrepJob* prep_table;
+  size_t prep_cap, total;
+};
+
+static BlockDims edims(const smbv_encoder_cfg& c) {
+  BlockDims d; d.rows = (size_t)c.B * c.Nsel; d.w = c.d; d.ff = c.ff; d.B = c.B; d.S = c.Nsel; d.H = c.heads; d.Dh = 64; d.eps = c.ln_eps;
+  return d;
+}
+
+static int check_cfg(const smbv_encoder_cfg& c) {
+  if (c.B <= 0 || c.layers <= 0 || c.layers > SMBV_MAX_LAYERS) { set_error("encoder: bad batch/layer counts"); return SMBV_ERR_SHAPE; }
+  if (c.ps <= 0 || c.ts <= 0 || c.T % c.ts || c.H % c.ps || c.W % c.ps || (c.ps & 3)) { set_error("encoder: volume %dx%dx%d not divisible by tubelet %d / patch %d", c.T, c.H, c.W, c.ts, c.ps); return SMBV_ERR_SHAPE; }
+  const int N = (c.T / c.ts) * (c.H / c.ps) * (c.W / c.ps);
+  if (c.N != N || c.Nsel <= 0 || c.Nsel > N) { set_error("encoder: token counts N=%d Nsel=%d inconsistent with the volume (%d)", c.N, c.Nsel, N); return SMBV_ERR_SHAPE; }
+  if (c.d % c.heads || c.d / c.heads != 64) { set_error("encoder: head_dim must be 64 (d=%d/%d)", c.d, c.heads); return SMBV_ERR_SHAPE; }
+  if ((c.d & 7) || (c.ff & 7) || ((c.ts * c.ps * c.ps) & 7)) { set_error("encoder: widths must be multiples of 8"); return SMBV_ERR_SHAPE; }
+  return SMBV_OK;
+}
+
+static void carve(const smbv_encoder_cfg& c, void* base, EncWs& w) {
+  Carver cv{(char*)base};
+  const int K = c.ts * c.ps * c.ps;
+  const size_t R = (size_t)c.B * c.Nsel;
+  const BlockDims de = edims(c);
+  w.prep_cap = 8 + (size_t)c.layers * layer_prep_job_count(de);
+  w.prep_table = cv.take<PrepJob>(w.prep_cap);
+  w.pe_w = cv.take<bf16_t>((size_t)c.d * K);
+  carve_layer(cv, w.L[0], de);  // weights of layer 0 + the ONE set of activation buffers
+  const size_t ww = (size_t)c.d * c.d, fw = (size_t)c.ff * c.d;
+  for (int l = 1; l < c.layers; l++) {
+    LayerWs& L = w.L[l];
+    L = w.L[0];                                    // share every activation buffer ...
+    L.wqkv = cv.take<bf16_t>(3 * ww);             // ... but not the bf16 operand copies of the weights
+    L.wqkv_t = w.L[0].wqkv_t;                     // transposed copies exist for dgrads only: all layers dump theirs into layer 0's
+    L.proj = cv.take<bf16_t>(ww);
+    L.proj_t = w.L[0].proj_t;
+    L.fc1 = cv.take<bf16_t>(fw);
+    L.fc1_t = w.L[0].fc1_t;
+    L.fc2 = cv.take<bf16_t>(fw);
+    L.fc2_t = w.L[0].fc2_t;
+    L.bqkv = cv.take<float>(3 * (size_t)c.d);
+  }
+  w.a_patch = cv.take<bf16_t>(R * K);
+  w.x0 = cv.take<float>(R * c.d);
+  w.x1 = cv.take<float>(R * c.d);
+  w.lnf_bf16 = cv.take<bf16_t>(R * c.d);
+  w.meanf = cv.take<float>(R);
+  w.rstdf = cv.take<float>(R);
+  w.sc = BwdScratch{};
+  w.sc.gath0 = cv.take<bf16_t>(16);
+  w.total = (cv.off + 255) & ~(size_t)255;
+}
+
+static int encoder_forward(const smbv_encoder_cfg& c, const smbv_encoder_tensors& p, const smbv_encoder_io& io, void* ws, size_t ws_bytes, hipStream_t st) {
+  RC(check_cfg(c));
+  EncWs W;
+  carve(c, ws, W);
+  if (!ws || ws_bytes < W.total || ((uintptr_t)ws & 255)) { set_error("encoder_forward: workspace too small or misaligned (%zu < %zu)", ws_bytes, W.total); return SMBV_ERR_WORKSPACE; }
+  if (!io.pixel_values || !io.sel_idx || !io.pos_enc || !io.last_hidden_state) { set_error("encoder_forward: null io pointer"); return SMBV_ERR_ARG; }
+  if (c.final_ln && (!p.lnf_w || !p.lnf_b)) { set_error("encoder_forward: final_ln set but no layernorm parameters"); return SMBV_ERR_ARG; }
+  const int K = c.ts * c.ps * c.ps;
+  const size_t R = (size_t)c.B * c.Nsel;
+  const BlockDims de = edims(c);
+  auto blk = [&](int l) {
+    const smbv_layer_ptrs& q = p.enc[l];
+    BlockPtrs b;
+    b.ln1_w = q.ln1_w; b.ln1_b = q.ln1_b; b.q_w = q.q_w; b.k_w = q.k_w; b.v_w = q.v_w; b.q_b = q.q_b; b.k_b = nullptr; b.v_b = q.v_b;
+    b.proj_w = q.proj_w; b.proj_b = q.proj_b; b.ln2_w = q.ln2_w; b.ln2_b = q.ln2_b; b.fc1_w = q.fc1_w; b.fc1_b = q.fc1_b; b.fc2_w = q.fc2_w; b.fc2_b = q.fc2_b;
+    return b;
+  };
+  {
+    PrepList pl;
+    pl.cast(p.pe_w, W.pe_w, c.d, K);
+    for (int l = 0; l < c.layers; l++) RC(prep_layer(pl, blk(l), W.L[l], de, st));
+    if (pl.jobs.size() > W.prep_cap) { set_error("encoder_forward: prep table overflow"); return SMBV_ERR_WORKSPACE; }
+    HIPRC(hipMemcpyAsync(W.prep_table, pl.jobs.data(), pl.jobs.size() * sizeof(PrepJob), hipMemcpyHostToDevice, st));
+    RC(prep_weights(W.prep_table, (int)pl.jobs.size(), pl.tiles, st));
+  }
+  RC(gather_bricks(io.pixel_values, io.sel_idx, (int)R, c.Nsel, W.a_patch, c.T, c.H, c.W, c.ts, c.ps, st));
+  float* xin = W.x0;
+  float* xout = W.x1;
+  {
+    GemmEpi e; e.bias = p.pe_b; e.rowadd = io.pos_enc; e.rowidx = io.sel_idx; e.ldr = c.d; e.out_f32 = xin; e.ld_of = c.d;
+    RC(gemm_nt(W.a_patch, K, W.pe_w, K, (int)R, c.d, K, e, st));
+  }
+  for (int l = 0; l < c.layers; l++) {
+    const bool last = l == c.layers - 1;
+    float* dst = (last && !c.final_ln) ? io.last_hidden_state : xout;
+    RC(layer_fwd(blk(l), W.L[l], de, W.sc, xin, dst, nullptr, 0, 0, st));
+    xout = xin;
+    xin = dst;
+  }
+  if (c.final_ln)
+    RC(layernorm_fwd(xin, p.lnf_w, p.lnf_b, W.lnf_bf16, W.meanf, W.rstdf, (int)R, c.d, c.final_ln_eps, 0, 0, 0, st, io.last_hidden_state));
+  return SMBV_OK;
+}
+
+}  // namespace smbv
+
+extern "C" {
+
+size_t smbv_encoder_workspace_bytes(const smbv_encoder_cfg* cfg) {
+  if (!cfg || smbv::check_cfg(*cfg)) return 0;
+  smbv::EncWs W;
+  smbv::carve(*cfg, nullptr, W);
+  return W.total;
+}
+
+int smbv_encoder_forward(const smbv_encoder_cfg* cfg, const smbv_encoder_tensors* params, const smbv_encoder_io* io, void* ws, size_t ws_bytes, smbv_stream stream) {
+  if (!cfg || !params || !io) { smbv::set_error("smbv_encoder_forward: null argument"); return SMBV_ERR_ARG; }
+  return smbv::encoder_forward(*cfg, *params, *io, ws, ws_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

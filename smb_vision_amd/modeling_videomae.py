@@ -88,7 +88,14 @@ def _pair(x):
 
 
 class _Slots(nn.Module):
-    """Pure parameter container; the hierarchy only exists to reproduce the reference's state-dict names."""
+    """Pure parameter container; the hierarchy only exists to reproduce the reference's state-dict names.  The ``videomae`` node of a
+    task model is also callable (``model.videomae(image)``, src/run_inference.py:78-83): its owner installs ``_encode``."""
+
+    def forward(self, pixel_values=None, bool_masked_pos=None, **kwargs):
+        enc = self.__dict__.get("_encode")
+        if enc is None:
+            raise TypeError("this container only holds parameters")
+        return enc(pixel_values, bool_masked_pos)
 
 
 def _register(root: nn.Module, dotted: str, p: nn.Parameter):
@@ -175,6 +182,11 @@ class SmbVideoMAEForPreTraining(PreTrainedModel):
         self.dp = None            # optional DataParallelEngine (smb_vision_amd.dp)
         self.reset_parameters()
         self.post_init()
+
+        def _encode(pixel_values, bool_masked_pos=None, _ref=weakref.ref(self)):
+            from .modeling_videomae_encoder import encode_with
+            return encode_with(_ref(), pixel_values, bool_masked_pos)
+        object.__setattr__(self._modules["videomae"], "_encode", _encode)
 
     # ------------------------------------------------------------------------------------------------------------
     # parameters

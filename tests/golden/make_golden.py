@@ -152,6 +152,78 @@ def make_mim(name, spec):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# Encoder-only forwards: embedding export (VideoMAEModel, all tokens / visible tokens / with the final LayerNorm)
+# and the classification head, from the installed transformers classes (the vendored file does not import under transformers 5.x).
+# ----------------------------------------------------------------------------------------------------------------------
+ENC_TINY = dict(image_size=64, num_frames=32, patch_size=16, tubelet_size=16, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                intermediate_size=256)
+
+
+def _pinned_from_hf(sd):
+    out = {}
+    for k, v in sd.items():
+        if k.endswith("attention.attention.query.bias"):
+            out[k.replace("query.bias", "q_bias")] = v
+        elif k.endswith("attention.attention.value.bias"):
+            out[k.replace("value.bias", "v_bias")] = v
+        elif k.endswith("attention.attention.key.bias"):
+            continue
+        else:
+            out[k] = v
+    return out
+
+
+def _randomise(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if k.endswith("attention.attention.key.bias"):
+                p.zero_()  # the pinned-era layout has no key bias (softmax-invariant anyway)
+            elif p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+            elif "norm" in k and k.endswith("weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+
+
+def make_encoder(name="encoder_tiny"):
+    from safetensors.torch import save_file
+    from transformers import VideoMAEConfig, VideoMAEForVideoClassification, VideoMAEModel
+
+    MG = load_reference_mask_generator()
+    blob = {}
+    cfg = VideoMAEConfig(num_channels=1, num_labels=3, use_mean_pooling=True, **ENC_TINY)
+    cfg._attn_implementation = "eager"
+    cls = VideoMAEForVideoClassification(cfg).float().eval()
+    _randomise(cls, 7)
+    g = torch.Generator().manual_seed(99)
+    pix = torch.rand(2, 32, 1, 64, 64, generator=g)
+    gen = MG(input_size=64, depth=32, mask_patch_size=16, model_patch_size=16, mask_ratio=0.6)
+    np.random.seed(3)
+    mask = torch.stack([gen() for _ in range(2)])
+    with torch.no_grad():
+        blob["cls.out.last_hidden_state"] = cls.videomae(pix).last_hidden_state
+        blob["cls.out.visible_hidden_state"] = cls.videomae(pix, bool_masked_pos=mask).last_hidden_state
+        blob["cls.out.logits"] = cls(pixel_values=pix).logits
+    blob["in.pixel_values"], blob["in.bool_masked_pos"] = pix, mask.to(torch.uint8)
+    for k, v in _pinned_from_hf(cls.state_dict()).items():
+        blob["cls.param." + k] = v.contiguous()
+    cfg2 = VideoMAEConfig(num_channels=1, use_mean_pooling=False, **ENC_TINY)
+    cfg2._attn_implementation = "eager"
+    enc = VideoMAEModel(cfg2).float().eval()
+    _randomise(enc, 8)
+    with torch.no_grad():
+        blob["enc.out.last_hidden_state"] = enc(pix).last_hidden_state
+    for k, v in _pinned_from_hf(enc.state_dict()).items():
+        blob["enc.param." + k] = v.contiguous()
+    meta = {"config": repr(ENC_TINY), "generator": "transformers.VideoMAEForVideoClassification / VideoMAEModel fp32 eager CPU",
+            "transformers": __import__("transformers").__version__, "torch": torch.__version__}
+    save_file({k: v.contiguous() for k, v in blob.items()}, os.path.join(HERE, name + ".safetensors"), metadata=meta)
+    print(name, "n tensors", len(blob), "logits", blob["cls.out.logits"])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # V-JEPA (src/run_vjepa.py): the in-repo model class src/models/vjepa/modeling_vjepa.py imports as shipped.
 # ----------------------------------------------------------------------------------------------------------------------
 
@@ -244,7 +316,7 @@ def make_vjepa(name="vjepa_tiny"):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["mim", "vjepa"]
+    which = sys.argv[1:] or ["mim", "vjepa", "encoder"]
     if "mim" in which:
         make_masks()
         for n, s in GOLDEN_CONFIGS.items():
@@ -252,3 +324,5 @@ if __name__ == "__main__":
     if "vjepa" in which:
         make_vjepa_masks()
         make_vjepa()
+    if "encoder" in which:
+        make_encoder()

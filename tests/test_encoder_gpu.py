@@ -1,0 +1,75 @@
+"""Encoder-only forwards on the HIP path (smbv_encoder_forward through the drop-in classes) against the reference goldens: embedding
+export over all tokens, over the visible tokens, with the final LayerNorm, the classification logits, and model.videomae(image) on the
+pre-training model (src/run_inference.py:78-83).  Tolerances: bf16 operands / fp32 accumulation as everywhere."""
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+CFG = dict(image_size=64, num_frames=32, patch_size=16, tubelet_size=16, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+           intermediate_size=256)
+
+
+@pytest.fixture(scope="module")
+def blob():
+    return load_file(os.path.join(G, "encoder_tiny.safetensors"))
+
+
+def _params(blob, pre):
+    return {k[len(pre):]: v for k, v in blob.items() if k.startswith(pre)}
+
+
+def close(got, ref, tol=2e-2):
+    got, ref = got.float().cpu(), ref.float()
+    assert float((got - ref).abs().max() / ref.abs().max()) < tol
+    assert float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()) < tol / 2
+
+
+def test_classification_and_embedding_export(blob):
+    from transformers import VideoMAEConfig
+    from smb_vision_amd.modeling_videomae_encoder import SmbVideoMAEForVideoClassification
+    m = SmbVideoMAEForVideoClassification(VideoMAEConfig(num_channels=1, num_labels=3, use_mean_pooling=True, **CFG))
+    m.load_state_dict(_params(blob, "cls.param."), strict=True)
+    m = m.cuda().eval()
+    pix, mask = blob["in.pixel_values"].cuda(), blob["in.bool_masked_pos"].bool().cuda()
+    with torch.no_grad():
+        out = m(pixel_values=pix)
+        # logits are O(0.1) sums of +-O(1) LayerNorm'ed features times 0.05-scale weights: the bf16 noise of the features is not averaged down
+        close(out.logits, blob["cls.out.logits"], tol=5e-2)
+        close(m.videomae(pix).last_hidden_state, blob["cls.out.last_hidden_state"])
+        close(m.videomae(pix, bool_masked_pos=mask).last_hidden_state, blob["cls.out.visible_hidden_state"])
+        labels = torch.tensor([0, 2]).cuda()
+        ref_loss = torch.nn.functional.cross_entropy(blob["cls.out.logits"], labels.cpu())
+        assert float(m(pixel_values=pix, labels=labels).loss) == pytest.approx(float(ref_loss), rel=3e-2)
+    with pytest.raises(NotImplementedError, match="forward-only"):
+        m(pixel_values=pix)
+
+
+def test_model_with_final_layernorm(blob):
+    from transformers import VideoMAEConfig
+    from smb_vision_amd.modeling_videomae_encoder import SmbVideoMAEModel
+    e = SmbVideoMAEModel(VideoMAEConfig(num_channels=1, use_mean_pooling=False, **CFG))
+    e.load_state_dict(_params(blob, "enc.param."), strict=True)
+    e = e.cuda().eval()
+    with torch.no_grad():
+        out = e(blob["in.pixel_values"].cuda())
+    assert out.last_hidden_state.shape == (2, 32, 128)
+    close(out.last_hidden_state, blob["enc.out.last_hidden_state"])
+
+
+def test_pretraining_model_videomae_call_matches_its_own_encoder(blob):
+    """model.videomae(image) on SmbVideoMAEForPreTraining: same encoder weights as the classification golden -> same embeddings."""
+    from transformers import VideoMAEConfig
+    from smb_vision_amd.modeling_videomae import SmbVideoMAEForPreTraining
+    cfg = VideoMAEConfig(num_channels=1, decoder_hidden_size=64, decoder_num_hidden_layers=1, decoder_num_attention_heads=1,
+                         decoder_intermediate_size=128, **CFG)
+    m = SmbVideoMAEForPreTraining(cfg)
+    enc = {k: v for k, v in _params(blob, "cls.param.").items() if k.startswith("videomae.")}
+    missing = m.load_state_dict(enc, strict=False)
+    assert all(not k.startswith("videomae.") for k in missing.missing_keys)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        close(m.videomae(blob["in.pixel_values"].cuda()).last_hidden_state, blob["cls.out.last_hidden_state"])
