@@ -149,6 +149,8 @@ def main():
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward only (diagnostic; not the metric)")
     ap.add_argument("--torch-optimizer", action="store_true", help="clip_grad_norm_ + torch fused AdamW instead of the fused HIP optimizer tail")
     ap.add_argument("--tiny", action="store_true", help="64x64x32 smoke shape (diagnostic; not the metric)")
+    ap.add_argument("--vit-large", action="store_true", help="BASELINE.json config 5's model in bf16 (encoder 1024/24L/16H/4096; decoder 512/12L/8H/2048 - the reference "
+                                                               "specifies none, SURVEY.md 8d) - diagnostic; not the metric")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse the N>1 path on one GPU)")
     args = ap.parse_args()
 
@@ -174,6 +176,9 @@ def main():
     if args.tiny:
         cfg_kw.update(image_size=64, num_frames=32, hidden_size=128, num_attention_heads=2, num_hidden_layers=2, intermediate_size=512,
                       decoder_hidden_size=64, decoder_num_attention_heads=1, decoder_num_hidden_layers=1, decoder_intermediate_size=256)
+    if args.vit_large:
+        cfg_kw.update(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, decoder_hidden_size=512,
+                      decoder_num_hidden_layers=12, decoder_num_attention_heads=8, decoder_intermediate_size=2048)
     model, pix, mask, n_masked = build(rank, device, cfg_kw)
     params = [p for p in model.parameters()]
     opt = None
@@ -237,11 +242,12 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "ViT-base MIM, 512x512x320 volume, patch_size=16, mask_ratio=0.65 (mask_patch 32), B=1/GPU, "
                                    "fwd+loss+bwd+clip+AdamW" + ("" if opt is not None else " [NO OPTIMIZER: diagnostic]")
-                                   + (" [TINY: diagnostic]" if args.tiny else ""),
+                                   + (" [TINY: diagnostic]" if args.tiny else "") + (" [ViT-LARGE bf16: diagnostic, 64.41 TFLOP/volume]" if args.vit_large else ""),
                        "tokens": model.num_patches, "masked": n_masked, "parallelism": f"dp{world}", "final_loss": final_loss,
                        "replicas_in_sync": in_sync},
         }
-        step_tf = world * STEP_TFLOP / (ms * 1e-3) if not args.tiny else None  # whole job, TFLOP/s
+        step_flop = 64.41 if args.vit_large else STEP_TFLOP
+        step_tf = world * step_flop / (ms * 1e-3) if not args.tiny else None  # whole job, TFLOP/s
         if world > 1 and not args.tiny:  # multi-GPU lines carry the whole-step roofline only (the kernel figure is a 1-GPU property)
             line["roofline"] = {"bound": "mfma", "kernel": "whole step (per GPU)", "achieved": step_tf / world, "peak": MFMA_PEAK_TFLOPS,
                                 "unit": "TFLOP/s", "frac": step_tf / world / MFMA_PEAK_TFLOPS, "traffic": None}
@@ -257,7 +263,7 @@ def main():
                                 "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic,
                                 "launch_ms": dom["ms"], "flop_per_launch": dom["flop"],
                                 "other": {"attn_dq_kernel": {"launch_ms": kr["attn_dq_kernel"]["ms"], "achieved": kr["attn_dq_kernel"]["tflops"]}},
-                                "step": {"achieved": step_tf, "flop_per_volume_T": STEP_TFLOP, "frac": step_tf / MFMA_PEAK_TFLOPS}}
+                                "step": {"achieved": step_tf, "flop_per_volume_T": step_flop, "frac": step_tf / MFMA_PEAK_TFLOPS}}
         if world == 1 and not args.no_cpu_baseline and not args.tiny:
             try:
                 line["cpu_baseline"] = cpu_baseline(cpu_threads())
