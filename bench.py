@@ -60,7 +60,7 @@ def build(rank, device, cfg_kw):
     return model, pix, mask, gen.num_masked
 
 
-def kernel_roofline(device, iters=5):
+def kernel_roofline(device, iters=20, warm=10):
     """Decoder attention backward dK/dV kernel at the bench shape, timed with HIP events on the stream it is launched on."""
     from smb_vision_amd import ops
     B, S, H = 1, 20480, 6
@@ -73,7 +73,8 @@ def kernel_roofline(device, iters=5):
     ops.attention_bwd(qkv, O, dO, lse, B, S, H, parts=1, out=out)
     res = {}
     for name, parts, flop in (("attn_dkv_kernel", 2, 4 * 2.0 * S * S * 64 * H), ("attn_dq_kernel", 4, 3 * 2.0 * S * S * 64 * H)):
-        ops.attention_bwd(qkv, O, dO, lse, B, S, H, parts=parts, out=out)
+        for _ in range(warm):  # the host-side set-up above leaves the GPU idle long enough for its clocks to drop
+            ops.attention_bwd(qkv, O, dO, lse, B, S, H, parts=parts, out=out)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         for _ in range(iters):
