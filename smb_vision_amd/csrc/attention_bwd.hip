@@ -18,7 +18,6 @@
 
 namespace smbv {
 extern int g_variant;
-bool attn_prefer_3waves(long blocks);
 
 #define HIPRC(x) do { hipError_t _e = (x); if (_e != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(_e)); return (int)_e; } } while (0)
 
@@ -829,10 +828,7 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
   }
   if (parts & 2) {
 #define DKV(W, QT) hipLaunchKernelGGL((attn_dkv_kernel<W, QT>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale)
-    // measured (tools/attn_ab.py): 128-query iterations at 2 waves/SIMD beat 64/32-query ones and the 3-wave build on both shapes
-    if (g_variant & 4) DKV(3, 32);
-    else if (g_variant & 256) DKV(2, 64);
-    else if (g_variant & 1024) DKV(2, 128);
+    if (g_variant & 1024) DKV(2, 128);  // previous generation, kept as the A/B reference (bitwise-identical results)
     else hipLaunchKernelGGL((attn_dkv2_kernel<128>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale);
 #undef DKV
     rc = check_launch("attn_dkv");
@@ -840,8 +836,7 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
   }
   if (parts & 4) {
 #define DQ(W, KT) hipLaunchKernelGGL((attn_dq_kernel<W, KT>), dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale)
-    if (g_variant & 512) DQ(2, 64);
-    else if (g_variant & 2048) DQ(2, 128);
+    if (g_variant & 2048) DQ(2, 128);  // previous generation (A/B reference)
     else hipLaunchKernelGGL((attn_dq2_kernel<128>), dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale);
 #undef DQ
     rc = check_launch("attn_dq");

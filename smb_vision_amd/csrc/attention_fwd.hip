@@ -434,11 +434,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
   }
 }
 
-int g_variant = 0;  // tuning / A-B hook (tools/attn_*ab.py): 32 previous fwd kernel (2: its 3-wave build, 16: its 2-wave build), 1024 / 2048 previous dkv / dq kernels
-
-// A block-per-CU round holds 2 (<=256 VGPR) or 3 (<=168 VGPR) 4-wave blocks per CU.  The 3-wave build is a little slower per
-// block but wins whenever it saves a whole round of blocks (e.g. encoder: 56 x 12 = 672 blocks fit 768 slots, not 512).
-bool attn_prefer_3waves(long blocks) { return cdiv(blocks, 768) < cdiv(blocks, 512); }
+int g_variant = 0;  // tuning / A-B hook (tools/attn_*ab.py): 32 / 1024 / 2048 previous generation of the fwd / dkv / dq kernels,
+                    // 8192 dQ and dK/dV on one stream; gemm.hip: 32 register-staged GEMMs, 64 / 128 epilogue debug
 
 int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf16_t* O, int ldo, float* LSE, int B, int S, int H, int Dh,
                   float scale, int Sq, int qoff, hipStream_t st) {
@@ -447,9 +444,7 @@ int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf1
   if (Dh != 64) { set_error("attention_fwd: head_dim %d not supported (only 64)", Dh); return SMBV_ERR_SHAPE; }
   if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 3)) { set_error("attention_fwd: bad shape B=%d S=%d H=%d ld=%d ldo=%d", B, S, H, ld, ldo); return SMBV_ERR_SHAPE; }
   if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || ((uintptr_t)O & 7)) { set_error("attention_fwd: alignment"); return SMBV_ERR_ALIGN; }
-  const bool w3 = (g_variant & 2) || (!(g_variant & 16) && attn_prefer_3waves((long)cdiv(Sq, 128) * H * B));
   if (!(g_variant & 32)) hipLaunchKernelGGL(attn_fwd2_kernel, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale);
-  else if (w3) hipLaunchKernelGGL(attn_fwd_kernel<3>, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale);
   else hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale);
   return check_launch("attention_fwd");
 }
