@@ -164,7 +164,7 @@ int smbv_mim_backward(const smbv_mim_cfg* cfg, const smbv_mim_tensors* params, c
                       void* ws, size_t ws_bytes, void** events, int n_events, smbv_stream stream);
 
 /* ---- encoder-only forward: VideoMAEModel.forward (spec :509-655) as src/run_inference.py:78-83 calls it for the
- *      embedding export (all tokens, no mask) and as the classification head (spec :917-989) sits on it.  Forward only. ---- */
+ *      embedding export (all tokens, no mask) and as the classification head (spec :917-989) sits on it. ---- */
 
 typedef struct smbv_encoder_cfg {
   int B, T, H, W;                 /* pixel_values fp32 [B,T,1,H,W] */
@@ -174,6 +174,7 @@ typedef struct smbv_encoder_cfg {
   float ln_eps;                   /* config.layer_norm_eps */
   int final_ln;                   /* VideoMAEModel.layernorm: present iff !config.use_mean_pooling (spec :517-520) */
   float final_ln_eps;
+  int train;                      /* 0: inference (one shared activation set); 1: every layer keeps its activations for smbv_encoder_backward */
 } smbv_encoder_cfg;
 
 typedef struct smbv_encoder_tensors {
@@ -192,6 +193,10 @@ typedef struct smbv_encoder_io {
 size_t smbv_encoder_workspace_bytes(const smbv_encoder_cfg* cfg);
 int smbv_encoder_forward(const smbv_encoder_cfg* cfg, const smbv_encoder_tensors* params, const smbv_encoder_io* io, void* ws, size_t ws_bytes,
                          smbv_stream stream);
+/* Fine-tuning (src/run_classification.py): gradients of every tensor in `grads` (overwritten) from d(last_hidden_state) fp32 [B*Nsel, d];
+ * same cfg (train = 1), io and workspace as the forward that preceded it. */
+int smbv_encoder_backward(const smbv_encoder_cfg* cfg, const smbv_encoder_tensors* params, const smbv_encoder_tensors* grads, const smbv_encoder_io* io,
+                          const float* d_last_hidden_state, void* ws, size_t ws_bytes, smbv_stream stream);
 
 /* ---- fused optimizer tail: clip_grad_norm_ + AdamW as HF Trainer runs them for the reference
  *      (site-packages/transformers/trainer.py:2539, :1785; --max_grad_norm / adamw_torch of scripts/training/run_mim.sh) ---- */

@@ -49,7 +49,7 @@ class MimIO(C.Structure):
 
 class EncoderCfg(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "T", "H", "W", "ps", "ts", "N", "Nsel", "d", "heads", "ff", "layers")] + \
-               [("ln_eps", C.c_float), ("final_ln", C.c_int), ("final_ln_eps", C.c_float)]
+               [("ln_eps", C.c_float), ("final_ln", C.c_int), ("final_ln_eps", C.c_float), ("train", C.c_int)]
 
 
 class EncoderTensors(C.Structure):
@@ -125,6 +125,7 @@ _SIGS = {
     "smbv_vjepa_backward": (C.c_int, [C.POINTER(VjepaCfg), C.POINTER(VjepaTensors), C.POINTER(VjepaTensors), C.POINTER(VjepaIO), c_f, C.c_size_t, c_f]),
     "smbv_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderCfg)]),
     "smbv_encoder_forward": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(EncoderTensors), C.POINTER(EncoderIO), c_f, C.c_size_t, c_f]),
+    "smbv_encoder_backward": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(EncoderTensors), C.POINTER(EncoderTensors), C.POINTER(EncoderIO), c_f, c_f, C.c_size_t, c_f]),
     "smbv_mim_workspace_bytes": (C.c_size_t, [C.POINTER(MimCfg)]),
     "smbv_mim_forward": (C.c_int, [C.POINTER(MimCfg), C.POINTER(MimTensors), C.POINTER(MimIO), c_f, C.c_size_t, c_f]),
     "smbv_mim_backward": (C.c_int, [C.POINTER(MimCfg), C.POINTER(MimTensors), C.POINTER(MimTensors), C.POINTER(MimIO), c_f, C.c_size_t,

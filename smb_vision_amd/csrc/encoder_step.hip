@@ -1,7 +1,9 @@
 // Encoder-only forward: VideoMAEModel.forward (src/models/videomae/modeling_videomae.py:509-655) - patch
 // embedding + sin-cos rows of the selected tokens, L pre-LN blocks, optional final LayerNorm (absent when config.use_mean_pooling,
 // :517-520) - as used by the embedding export (src/run_inference.py:78-83: model.videomae(image), all 20,480 tokens, no mask) and
-// under the classification head (spec :917-989).  Forward only: one shared set of activation buffers serves every layer.
+// under the classification head (spec :917-989).  cfg.train == 0 (inference): one shared set of activation buffers serves every
+// layer.  cfg.train != 0 (fine-tuning, src/run_classification.py): every layer keeps its activations and smbv_encoder_backward turns the
+// gradient of last_hidden_state into parameter gradients (the classification head itself is a [B, d] computation left to the caller).
 #include "block.h"
 #include "../../include/smbv.h"
 
@@ -12,6 +14,9 @@ struct EncWs {
   LayerWs L[SMBV_MAX_LAYERS];
   bf16_t *a_patch, *lnf_bf16;
   float *x0, *x1, *meanf, *rstdf;
+  float* x[SMBV_MAX_LAYERS + 1];  // train: residual stream per layer
+  float *g0, *g1;                 // train: gradient ping-pong (fp32 + bf16 copies)
+  bf16_t *gb0, *gb1;
   BwdScratch sc;
   PrepJob* prep_table;
   size_t prep_cap, total;
@@ -40,6 +45,36 @@ static void carve(const smbv_encoder_cfg& c, void* base, EncWs& w) {
   w.prep_cap = 8 + (size_t)c.layers * layer_prep_job_count(de);
   w.prep_table = cv.take<PrepJob>(w.prep_cap);
   w.pe_w = cv.take<bf16_t>((size_t)c.d * K);
+  if (c.train) {
+    for (int l = 0; l < c.layers; l++) carve_layer(cv, w.L[l], de);
+    w.a_patch = cv.take<bf16_t>(R * K);
+    for (int l = 0; l <= c.layers; l++) w.x[l] = cv.take<float>(R * c.d);
+    w.x0 = w.x[0]; w.x1 = nullptr;
+    w.lnf_bf16 = cv.take<bf16_t>(R * c.d);
+    w.meanf = cv.take<float>(R);
+    w.rstdf = cv.take<float>(R);
+    w.g0 = cv.take<float>(R * c.d);
+    w.g1 = cv.take<float>(R * c.d);
+    w.gb0 = cv.take<bf16_t>(R * c.d);
+    w.gb1 = cv.take<bf16_t>(R * c.d);
+    size_t act = 0, we = 0, qkv = 0, gpad = 0, sb = 0, delta = 0;
+    bwd_scratch_requirements(de, act, we, qkv, gpad, sb, delta);
+    sb = std::max(sb, gemm_tn_workspace_bytes((int)R, c.d, K));
+    sb = std::max(sb, colsum_workspace_bytes((int)R, std::max(c.d, K)));
+    w.sc = BwdScratch{};
+    w.sc.d_act = cv.take<bf16_t>(act);
+    w.sc.d_ln = cv.take<bf16_t>(we);
+    w.sc.d_o = cv.take<bf16_t>(we);
+    w.sc.d_qkv = cv.take<bf16_t>(qkv);
+    w.sc.gath0 = cv.take<bf16_t>(16);
+    w.sc.gath1 = cv.take<bf16_t>(16);
+    w.sc.delta = cv.take<float>(delta);
+    w.sc.gpad = nullptr;
+    w.sc.scratch = cv.take<char>(sb);
+    w.sc.scratch_bytes = sb;
+    w.total = (cv.off + 255) & ~(size_t)255;
+    return;
+  }
   carve_layer(cv, w.L[0], de);  // weights of layer 0 + the ONE set of activation buffers
   const size_t ww = (size_t)c.d * c.d, fw = (size_t)c.ff * c.d;
   for (int l = 1; l < c.layers; l++) {
@@ -98,15 +133,60 @@ static int encoder_forward(const smbv_encoder_cfg& c, const smbv_encoder_tensors
     GemmEpi e; e.bias = p.pe_b; e.rowadd = io.pos_enc; e.rowidx = io.sel_idx; e.ldr = c.d; e.out_f32 = xin; e.ld_of = c.d;
     RC(gemm_nt(W.a_patch, K, W.pe_w, K, (int)R, c.d, K, e, st));
   }
-  for (int l = 0; l < c.layers; l++) {
-    const bool last = l == c.layers - 1;
-    float* dst = (last && !c.final_ln) ? io.last_hidden_state : xout;
-    RC(layer_fwd(blk(l), W.L[l], de, W.sc, xin, dst, nullptr, 0, 0, st));
-    xout = xin;
-    xin = dst;
+  if (c.train) {
+    for (int l = 0; l < c.layers; l++) RC(layer_fwd(blk(l), W.L[l], de, W.sc, W.x[l], W.x[l + 1], nullptr, 0, 0, st));
+    xin = W.x[c.layers];
+    if (!c.final_ln) HIPRC(hipMemcpyAsync(io.last_hidden_state, xin, R * c.d * sizeof(float), hipMemcpyDeviceToDevice, st));
+  } else {
+    for (int l = 0; l < c.layers; l++) {
+      const bool last = l == c.layers - 1;
+      float* dst = (last && !c.final_ln) ? io.last_hidden_state : xout;
+      RC(layer_fwd(blk(l), W.L[l], de, W.sc, xin, dst, nullptr, 0, 0, st));
+      xout = xin;
+      xin = dst;
+    }
   }
   if (c.final_ln)
     RC(layernorm_fwd(xin, p.lnf_w, p.lnf_b, W.lnf_bf16, W.meanf, W.rstdf, (int)R, c.d, c.final_ln_eps, 0, 0, 0, st, io.last_hidden_state));
+  return SMBV_OK;
+}
+
+// Gradients of every encoder parameter from d(last_hidden_state) (fp32 [B*Nsel, d]); needs the workspace of a train-mode forward.
+static int encoder_backward(const smbv_encoder_cfg& c, const smbv_encoder_tensors& p, const smbv_encoder_tensors& gr, const smbv_encoder_io& io,
+                            const float* d_out, void* ws, size_t ws_bytes, hipStream_t st) {
+  RC(check_cfg(c));
+  if (!c.train) { set_error("encoder_backward: the forward ran in inference mode (cfg.train == 0)"); return SMBV_ERR_ARG; }
+  EncWs W;
+  carve(c, ws, W);
+  if (!ws || ws_bytes < W.total || ((uintptr_t)ws & 255)) { set_error("encoder_backward: workspace too small or misaligned"); return SMBV_ERR_WORKSPACE; }
+  if (!d_out) { set_error("encoder_backward: null gradient"); return SMBV_ERR_ARG; }
+  const int K = c.ts * c.ps * c.ps;
+  const size_t R = (size_t)c.B * c.Nsel;
+  const BlockDims de = edims(c);
+  auto blk = [&](const smbv_encoder_tensors& t, int l) {
+    const smbv_layer_ptrs& q = t.enc[l];
+    BlockPtrs b;
+    b.ln1_w = q.ln1_w; b.ln1_b = q.ln1_b; b.q_w = q.q_w; b.k_w = q.k_w; b.v_w = q.v_w; b.q_b = q.q_b; b.k_b = nullptr; b.v_b = q.v_b;
+    b.proj_w = q.proj_w; b.proj_b = q.proj_b; b.ln2_w = q.ln2_w; b.ln2_b = q.ln2_b; b.fc1_w = q.fc1_w; b.fc1_b = q.fc1_b; b.fc2_w = q.fc2_w; b.fc2_b = q.fc2_b;
+    return b;
+  };
+  if (c.final_ln) {
+    RC(cast_f32_bf16(d_out, W.gb1, R * c.d, st));
+    RC(layernorm_bwd(W.gb1, W.x[c.layers], W.meanf, W.rstdf, p.lnf_w, nullptr, W.g0, W.gb0, gr.lnf_w, gr.lnf_b, (int)R, c.d, 0, 0, 0, W.sc.scratch,
+                     W.sc.scratch_bytes, st));
+  } else {
+    HIPRC(hipMemcpyAsync(W.g0, d_out, R * c.d * sizeof(float), hipMemcpyDeviceToDevice, st));
+    RC(cast_f32_bf16(d_out, W.gb0, R * c.d, st));
+  }
+  float *g = W.g0, *g2 = W.g1;
+  bf16_t *gb = W.gb0, *gb2 = W.gb1;
+  for (int l = c.layers - 1; l >= 0; l--) {
+    RC(layer_bwd(blk(p, l), blk(gr, l), W.L[l], de, W.sc, W.x[l], g, gb, g2, gb2, 0, 0, st));
+    // layer_bwd leaves the gradient w.r.t. its input in (g, gb) again (see block.h)
+  }
+  RC(colsum_bf16(gb, c.d, (int)R, c.d, gr.pe_b, 0, 0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
+  RC(gemm_tn(gb, c.d, W.a_patch, K, (int)R, c.d, K, gr.pe_w, W.sc.scratch, W.sc.scratch_bytes, st));
+  (void)io;
   return SMBV_OK;
 }
 
@@ -124,6 +204,12 @@ size_t smbv_encoder_workspace_bytes(const smbv_encoder_cfg* cfg) {
 int smbv_encoder_forward(const smbv_encoder_cfg* cfg, const smbv_encoder_tensors* params, const smbv_encoder_io* io, void* ws, size_t ws_bytes, smbv_stream stream) {
   if (!cfg || !params || !io) { smbv::set_error("smbv_encoder_forward: null argument"); return SMBV_ERR_ARG; }
   return smbv::encoder_forward(*cfg, *params, *io, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int smbv_encoder_backward(const smbv_encoder_cfg* cfg, const smbv_encoder_tensors* params, const smbv_encoder_tensors* grads, const smbv_encoder_io* io,
+                          const float* d_last_hidden_state, void* ws, size_t ws_bytes, smbv_stream stream) {
+  if (!cfg || !params || !grads || !io) { smbv::set_error("smbv_encoder_backward: null argument"); return SMBV_ERR_ARG; }
+  return smbv::encoder_backward(*cfg, *params, *grads, *io, d_last_hidden_state, ws, ws_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -9,7 +9,9 @@ reference, same constructor / ``from_pretrained`` / ``forward`` signature / outp
 * ``encode_with(model, pixel_values, bool_masked_pos=None)`` - ``model.videomae(image)`` of ``src/run_inference.py:78-83`` for a
   ``SmbVideoMAEForPreTraining`` (it is also installed as ``model.videomae.forward``).
 
-Forward only (inference): one C call, ``smbv_encoder_forward``; call under ``torch.no_grad()``.  No CPU fallback.
+Under ``torch.no_grad()`` one C call (``smbv_encoder_forward``, one shared activation set); with autograd enabled the layers keep their
+activations and ``smbv_encoder_backward`` returns the encoder's parameter gradients (fine-tuning, ``src/run_classification.py``); the
+``[B, d]`` head (mean pool, ``fc_norm``, classifier, loss) is ordinary tensor code on the device.  No CPU fallback.
 """
 from __future__ import annotations
 
@@ -41,6 +43,22 @@ def encoder_table(config, prefix: str, final_ln: bool):
     if final_ln:
         out += [(prefix + "layernorm.weight", (d,), ("lnf_w",)), (prefix + "layernorm.bias", (d,), ("lnf_b",))]
     return out
+
+
+class _EncoderFn(torch.autograd.Function):
+    """Autograd edge around smbv_encoder_forward (train mode) / smbv_encoder_backward.  Inputs: every encoder parameter."""
+
+    @staticmethod
+    def forward(ctx, runner, pix, sel, nsel, *params):
+        out, st = runner._run(pix, sel, nsel, params, train=True)
+        ctx.runner, ctx.st = runner, st
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        grads = ctx.runner._run_backward(ctx.st, d_out)
+        ctx.st = None
+        return (None, None, None, None, *grads)
 
 
 class _EncoderRunner:
@@ -76,14 +94,66 @@ class _EncoderRunner:
             self._structs = (sig, t)
         return self._structs[1]
 
+    def _grad_arena(self, params, dev):
+        """One flat fp32 arena for the encoder's gradients (256-byte aligned slots), and the C struct that points into it."""
+        sig = tuple(p.data_ptr() for p in params)
+        if getattr(self, "_garena", None) is None or self._garena[0] != sig:
+            offs, off = [], 0
+            for p in params:
+                offs.append(off)
+                off += (p.numel() + 63) & ~63
+            flat = torch.zeros(off, dtype=torch.float32, device=dev)
+            t = _lib.EncoderTensors()
+            views = []
+            for (name, _, path), p, o in zip(self.table, params, offs):
+                v = flat[o:o + p.numel()].view(p.shape)
+                views.append(v)
+                if len(path) == 1:
+                    setattr(t, path[0], v.data_ptr())
+                else:
+                    setattr(getattr(t, path[0])[path[1]], path[2], v.data_ptr())
+            self._garena = (sig, flat, t, views)
+        return self._garena
+
+    def _run(self, pix, sel, nsel, params, train):
+        c = self.config
+        dev = pix.device
+        lib = _lib.load()
+        B, T, _, H, W = pix.shape
+        cfg = _lib.EncoderCfg()
+        cfg.B, cfg.T, cfg.H, cfg.W, cfg.ps, cfg.ts = B, T, H, W, self.ps, self.ts
+        cfg.N, cfg.Nsel = self.N, nsel
+        cfg.d, cfg.heads, cfg.ff, cfg.layers = c.hidden_size, c.num_attention_heads, c.intermediate_size, c.num_hidden_layers
+        cfg.ln_eps, cfg.final_ln, cfg.final_ln_eps, cfg.train = c.layer_norm_eps, int(self.final_ln), c.layer_norm_eps, int(train)
+        need = lib.smbv_encoder_workspace_bytes(C.byref(cfg))
+        if need == 0:
+            raise _lib.SmbvError("smbv_encoder_workspace_bytes: " + _lib.last_error())
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        out = torch.empty(B, nsel, c.hidden_size, dtype=torch.float32, device=dev)
+        io = _lib.EncoderIO()
+        io.pixel_values, io.sel_idx, io.pos_enc, io.last_hidden_state = pix.data_ptr(), sel.data_ptr(), self._pos.data_ptr(), out.data_ptr()
+        tens = self._tensors(list(params))
+        _lib.check(lib.smbv_encoder_forward(C.byref(cfg), C.byref(tens), C.byref(io), self._ws.data_ptr(), self._ws.numel(),
+                                            torch.cuda.current_stream().cuda_stream), "smbv_encoder_forward")
+        return out, dict(cfg=cfg, io=io, tens=tens, keep=(pix, sel, out), params=list(params))
+
+    def _run_backward(self, st, d_out):
+        lib = _lib.load()
+        dev = d_out.device
+        with torch.cuda.device(dev):
+            _, flat, gt, views = self._grad_arena(st["params"], dev)
+            d = d_out.to(torch.float32).contiguous()
+            _lib.check(lib.smbv_encoder_backward(C.byref(st["cfg"]), C.byref(st["tens"]), C.byref(gt), C.byref(st["io"]), d.data_ptr(), self._ws.data_ptr(),
+                                                 self._ws.numel(), torch.cuda.current_stream().cuda_stream), "smbv_encoder_backward")
+        return [v.clone() for v in views]  # autograd accumulates into .grad; the arena is rewritten by the next backward
+
     def encode(self, pixel_values: torch.Tensor, bool_masked_pos: Optional[torch.Tensor] = None) -> torch.Tensor:
         c = self.config
         if pixel_values is None:
             raise ValueError("You have to specify pixel_values")
         if not pixel_values.is_cuda:
             raise _lib.SmbvError("smb_vision_amd: pixel_values must live on a HIP device; there is no CPU fallback")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self._params()):
-            raise NotImplementedError("smb_vision_amd: the encoder-only path is forward-only; call it under torch.no_grad()")
         B, T, Cc, H, W = pixel_values.shape
         if Cc != c.num_channels:
             raise ValueError("Make sure that the channel dimension of the pixel values match with the one set in the configuration.")
@@ -92,7 +162,7 @@ class _EncoderRunner:
         if T != c.num_frames:
             raise ValueError(f"Input has {T} frames, the model is configured for {c.num_frames}.")
         dev = pixel_values.device
-        lib = _lib.load()
+        _lib.load()
         with torch.cuda.device(dev):
             params = self._params()
             if any(p.device != dev for p in params):
@@ -106,26 +176,14 @@ class _EncoderRunner:
             else:
                 m = bool_masked_pos.to(device=dev, dtype=torch.bool)
                 counts = m.sum(1)
-                n_masked = int(counts[0])  # (host sync: inference path)
+                n_masked = int(counts[0])  # (host sync: not the pre-training hot path)
                 if bool((counts != n_masked).any()):
                     raise ValueError("every volume of the batch must mask the same number of tokens")
                 nsel = self.N - n_masked
                 sel, _ = split_mask_indices(m, n_masked)
-            cfg = _lib.EncoderCfg()
-            cfg.B, cfg.T, cfg.H, cfg.W, cfg.ps, cfg.ts = B, T, H, W, self.ps, self.ts
-            cfg.N, cfg.Nsel = self.N, nsel
-            cfg.d, cfg.heads, cfg.ff, cfg.layers = c.hidden_size, c.num_attention_heads, c.intermediate_size, c.num_hidden_layers
-            cfg.ln_eps, cfg.final_ln, cfg.final_ln_eps = c.layer_norm_eps, int(self.final_ln), c.layer_norm_eps
-            need = lib.smbv_encoder_workspace_bytes(C.byref(cfg))
-            if need == 0:
-                raise _lib.SmbvError("smbv_encoder_workspace_bytes: " + _lib.last_error())
-            if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-                self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
-            out = torch.empty(B, nsel, c.hidden_size, dtype=torch.float32, device=dev)
-            io = _lib.EncoderIO()
-            io.pixel_values, io.sel_idx, io.pos_enc, io.last_hidden_state = pix.data_ptr(), sel.data_ptr(), self._pos.data_ptr(), out.data_ptr()
-            _lib.check(lib.smbv_encoder_forward(C.byref(cfg), C.byref(self._tensors(params)), C.byref(io), self._ws.data_ptr(), self._ws.numel(),
-                                                torch.cuda.current_stream().cuda_stream), "smbv_encoder_forward")
+            if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+                return _EncoderFn.apply(self, pix, sel, nsel, *params)  # fine-tuning: activations kept, backward available
+            out, _ = self._run(pix, sel, nsel, params, train=False)
         return out
 
 

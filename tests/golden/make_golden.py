@@ -209,6 +209,13 @@ def make_encoder(name="encoder_tiny"):
     blob["in.pixel_values"], blob["in.bool_masked_pos"] = pix, mask.to(torch.uint8)
     for k, v in _pinned_from_hf(cls.state_dict()).items():
         blob["cls.param." + k] = v.contiguous()
+    # fine-tuning step (src/run_classification.py): cross-entropy on labels, gradients of every parameter
+    labels = torch.tensor([0, 2])
+    out = cls(pixel_values=pix, labels=labels)
+    out.loss.backward()
+    blob["in.labels"], blob["cls.out.loss"] = labels, out.loss.detach().reshape(1)
+    for k, v in pinned_grads_from_hf(cls).items():
+        blob["cls.grad." + k] = v.detach().contiguous()
     cfg2 = VideoMAEConfig(num_channels=1, use_mean_pooling=False, **ENC_TINY)
     cfg2._attn_implementation = "eager"
     enc = VideoMAEModel(cfg2).float().eval()

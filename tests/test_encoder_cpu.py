@@ -42,6 +42,16 @@ def test_oracle_matches_reference_encoder_outputs(blob):
         assert rel(mo.encoder_forward(pe, ocfg(), pix, None, prefix="", final_ln=True), blob["enc.out.last_hidden_state"]) < 1e-5
 
 
+def test_oracle_fine_tune_gradients_match_reference(blob):
+    p = {k: v.clone().requires_grad_(True) for k, v in _params(blob, "cls.param.").items()}
+    logits = mo.classification_forward(p, ocfg(), blob["in.pixel_values"])
+    loss = torch.nn.functional.cross_entropy(logits, blob["in.labels"])
+    assert float(loss) == pytest.approx(float(blob["cls.out.loss"]), rel=1e-5)
+    loss.backward()
+    for k, g in _params(blob, "cls.grad.").items():
+        assert rel(p[k].grad, g) < 2e-4, k
+
+
 def test_drop_in_class_surface(blob):
     from transformers import VideoMAEConfig
     from smb_vision_amd import _lib
