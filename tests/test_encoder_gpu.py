@@ -97,3 +97,14 @@ def test_pretraining_model_videomae_call_matches_its_own_encoder(blob):
     m = m.cuda().eval()
     with torch.no_grad():
         close(m.videomae(blob["in.pixel_values"].cuda()).last_hidden_state, blob["cls.out.last_hidden_state"])
+
+
+@pytest.mark.parametrize("task,extra", [("classification", 0), ("regression", 2), ("multilabel_classification", 0)])
+def test_hf_trainer_fine_tunes(tmp_path, task, extra):
+    from smb_vision_amd.run_classification import main
+    metrics = main(["--output_dir", str(tmp_path), "--image_size", "32", "--depth", "16", "--patch_size", "8", "--task_type", task, "--num_labels", "3",
+                    "--num_additional_features", str(extra), "--hidden_size", "128", "--num_hidden_layers", "2", "--num_attention_heads", "2",
+                    "--intermediate_size", "256", "--max_steps", "6", "--per_device_train_batch_size", "2", "--report_to", "none", "--bf16", "true",
+                    "--learning_rate", "1e-3", "--logging_steps", "1", "--save_strategy", "no", "--dataloader_num_workers", "0"])
+    assert 0 < metrics["train_loss"] < 3.0
+    assert os.path.exists(os.path.join(tmp_path, "model.safetensors"))
