@@ -195,8 +195,8 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __res
 // Hand-phased, rotated forward: while the matrix pipe runs the QK^T chains of tile j+1 and the PV products of tile j, the wave's
 // VALU slots carry the exp2 / row-sum / bf16-convert work of tile j and the row maximum of tile j+1, and every LDS fragment is read
 // at least four MFMAs before its consumer.  Per 64-key tile, four groups of 4 MFMAs:
-//   G1  S'^T(j+1)[keys 0..31]   | P(j) k-step 0 (8 exp2, 8 adds, 4 converts) | reads: V^T fragments of k-steps 0,1
-//   G2  S'^T(j+1)[keys 32..63]  | P(j) k-step 1                              | reads: V^T fragments of k-steps 2,3
+//   G1  S'^T(j+1)[keys 0..31]   | P(j) k-step 0 (8 exp2, 8 adds, 4 converts) | reads: all V^T fragments of tile j
+//   G2  S'^T(j+1)[keys 32..63]  | P(j) k-step 1
 //   -- barrier: tile j is dead -> its ring slot takes tile j+4 (LDS-DMA); tile j+2 has landed (counted vmcnt) --
 //   G3  O^T += V^T P^T, k-steps 0,1 | P(j) k-step 2                          | reads: K rows 0..31 of tile j+2
 //   G4  O^T += V^T P^T, k-steps 2,3 | P(j) k-step 3, then max of S'(j+1)     | reads: K rows 32..63 of tile j+2
@@ -346,30 +346,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
     pgroup(sc[0], 0, pf[0]);
     vread(j, 0, vt[0]);
     vread(j, 1, vt[1]);
+    vread(j, 2, vt[2]);  // all of tile j's V^T fragments are requested here, a whole MFMA chain ahead of the hand-over barrier:
+    vread(j, 3, vt[3]);  // the lgkmcnt(0) in front of it then costs nothing
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
       __builtin_amdgcn_sched_group_barrier(SG_TRANS, 2, 0);
       __builtin_amdgcn_sched_group_barrier(SG_VALU, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(SG_DSR, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_DSR, 4, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- G2
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[ks], qf[ks], ks == 0 ? cneg : sn[1], 0, 0, 0);
     pgroup(sc[0], 1, pf[1]);
-    vread(j, 2, vt[2]);
-    vread(j, 3, vt[3]);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
       __builtin_amdgcn_sched_group_barrier(SG_TRANS, 2, 0);
       __builtin_amdgcn_sched_group_barrier(SG_VALU, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(SG_DSR, 2, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- every wave is past its last read of tile j; this wave's pieces of tile j+2 have landed (tile j+3 may still fly)
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");  // (lgkmcnt: this wave's reads of tile j have returned before its slot is handed back)
     __builtin_amdgcn_s_barrier();
     stage(j + 4);
     __builtin_amdgcn_sched_barrier(0);
