@@ -285,3 +285,19 @@ def test_attention_query_subrange(ops, B, S, H, Sq, qoff):
     for i, name in enumerate("qkv"):
         a, b = dqkv[:, i * w:(i + 1) * w], qf.grad[:, i * w:(i + 1) * w]
         assert rel_err(a, b) < 2.5e-2 and rms_err(a, b) < 1e-2, name
+
+
+def test_attention_kernels_are_run_to_run_identical(ops):
+    """No atomics anywhere and every LDS hand-over (LDS-DMA ring slots, tile seams) is ordered by counted waits + barriers: repeated launches
+    on a shape with many tiles per block must agree bit for bit (a race would show up as run-to-run differences)."""
+    B, S, H = 1, 4224, 4   # 33 tiles of 128: ring wrap-around, odd tile count, ragged nothing
+    w = H * 64
+    qkv = rnd(B * S, 3 * w, seed=31).bfloat16()
+    dO = rnd(B * S, w, seed=32).bfloat16()
+    O0, lse0 = ops.attention_fwd(qkv, B, S, H)
+    d0, _ = ops.attention_bwd(qkv, O0, dO, lse0, B, S, H)
+    for _ in range(8):
+        O, lse = ops.attention_fwd(qkv, B, S, H)
+        assert torch.equal(O, O0) and torch.equal(lse, lse0)
+        d, _ = ops.attention_bwd(qkv, O0, dO, lse0, B, S, H)
+        assert torch.equal(d, d0)
