@@ -520,6 +520,118 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
   }
 }
 
+// TN, 256 x 256 output tile, for wide outputs (gemm_tn_use_256).  A 128 x 128 block is bound by its own copy latency: its LDS (64 KiB,
+// 2 blocks per CU) lets 2 x 32 KiB fly per CU.  A 256 x 256 tile needs half the operand bytes per MAC and, alone on its CU, keeps three
+// 32-token slices (96 KiB) in flight: 8 waves (2 x 4), each 128 x 64 of the output, slices [32 tokens][512 B] of X and of Y
+// through a ring of four LDS slots filled by LDS-DMA hidden from hipcc (smbv_common.h), one counted vmcnt + one barrier per slice, fragments
+// by ds_read_b64_tr_b16 (same 32-byte-column XOR swizzle as the 128 kernel; 512-B rows keep its bank pattern).  The token range is split
+// into slabs so that tiles x slabs fills one round of 256 blocks; slabs are summed by reduce_slabs_kernel in slab order.
+__global__ __launch_bounds__(512, 1) void gemm_tn_256_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y, int ldy,
+                                                              int M, int N1, int N2, float* __restrict__ out, int ldo, int tiles_1,
+                                                              int mchunk, size_t slab_stride) {
+  constexpr int SLICE = 2 * 32 * 512;  // X image | Y image
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * SLICE];
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int w1 = w >> 2, w2 = w & 3;  // 2 (n1) x 4 (n2)
+  const int tile_1 = blockIdx.x % tiles_1, tile_2 = blockIdx.x / tiles_1;
+  const int a0 = tile_1 * 256, b0 = tile_2 * 256;
+  const int z = blockIdx.y;
+  const int mbeg = z * mchunk, mend = min(M, mbeg + mchunk);
+  const int nks = (mend - mbeg + 31) / 32;
+
+  const i32x4 rx = dma_rsrc(X, mend > 0 ? (unsigned)(((size_t)(mend - 1) * ldx + N1) * 2) : 0u);
+  const i32x4 ry = dma_rsrc(Y, mend > 0 ? (unsigned)(((size_t)(mend - 1) * ldy + N2) * 2) : 0u);
+  // wave w stages token rows 4w..4w+3 of both images as 2 + 2 pieces of 2 rows x 512 B (lane -> row l>>5, 16-B chunk position l&31)
+  const int cp = l & 31;
+  int ox[2], oy[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int row = 4 * w + 2 * i + (l >> 5);
+    const int csrc = 2 * ((cp >> 1) ^ sw_tn(row)) + (cp & 1);
+    ox[i] = ((mbeg + row) * ldx + a0 + csrc * 8) * 2;
+    oy[i] = ((mbeg + row) * ldy + b0 + csrc * 8) * 2;
+  }
+  const int ox0 = ox[0], ox1 = ox[1], oy0 = oy[0], oy1 = oy[1];
+  const int kx = 32 * ldx * 2, ky = 32 * ldy * 2;
+  const unsigned lds_w = __builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem) + w * 2048));
+  auto stage = [&](int ks) __attribute__((always_inline)) {
+    const unsigned dx = lds_w + (unsigned)(ks & 3) * SLICE, dy = dx + 32 * 512;
+    dma16_hidden(rx, dx, ox0 + ks * kx);
+    dma16_hidden(ry, dy, oy0 + ks * ky);
+    dma16_hidden(rx, dx + 1024, ox1 + ks * kx);
+    dma16_hidden(ry, dy + 1024, oy1 + ks * ky);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int g = l >> 4, q = (l >> 2) & 3, p = l & 3;
+  const int mA = 8 * g + q, mB = mA + 4;
+  const int swA = sw_tn(mA), swB = sw_tn(mB);
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  stage(0); stage(1); stage(2);
+  for (int ks = 0; ks < nks; ks++) {
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");  // own pieces of slice ks landed (ks+1, ks+2 may fly); own reads of slice ks-1 returned
+    __builtin_amdgcn_s_barrier();
+    stage(ks + 3);  // into the slot of slice ks-1; token rows >= mend lie outside the descriptors and arrive as zeros
+    const unsigned char* sx = smem + (ks & 3) * SLICE;
+    const unsigned char* sy = sx + 32 * 512;
+    bf16x8 xf[8], yf[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int nt2 = w2 * 4 + j;
+      const s16x4 y0 = lds_read_tr16(sy + mA * 512 + 32 * (nt2 ^ swA) + 8 * p);
+      const s16x4 y1 = lds_read_tr16(sy + mB * 512 + 32 * (nt2 ^ swB) + 8 * p);
+      const s16x8 yy = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+      yf[j] = __builtin_bit_cast(bf16x8, yy);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int nt1 = w1 * 8 + i;
+      const s16x4 x0 = lds_read_tr16(sx + mA * 512 + 32 * (nt1 ^ swA) + 8 * p);
+      const s16x4 x1 = lds_read_tr16(sx + mB * 512 + 32 * (nt1 ^ swB) + 8 * p);
+      const s16x8 xx = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+      xf[i] = __builtin_bit_cast(bf16x8, xx);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[j], xf[i], acc[i][j], 0, 0, 0);  // D[n2][n1]
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+
+  float* o = out + (size_t)z * slab_stride;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int n1 = a0 + w1 * 128 + i * 16 + (l & 15);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int n2 = b0 + w2 * 64 + j * 16 + 4 * (l >> 4);
+      *(f32x4*)(o + (size_t)n1 * ldo + n2) = acc[i][j];
+    }
+  }
+}
+
+// slabs for the 256 x 256 kernel: tiles x slabs as close to one full round of 256 blocks as the token count allows (>= 256 tokens a slab)
+static int gemm_tn_splits_256(int M, int N1, int N2) {
+  const int tiles = (N1 / 256) * (N2 / 256);
+  int s = std::max(1, 256 / tiles);
+  while (s > 1 && M / s < 256) s--;
+  return s;
+}
+static bool gemm_tn_use_256(int M, int N1, int N2) {
+  if ((N1 % 256) || (N2 % 256) || (g_variant & (32 | 32768))) return false;
+  const int tiles = (N1 / 256) * (N2 / 256);
+  const int s = gemm_tn_splits_256(M, N1, N2);
+  // measured (tools/gemm_tn_ab.py): ahead of the 128 x 128 kernel when a slab still holds >= ~900 tokens (36-48 tiles: +3..26 %), behind it
+  // when many short slabs are needed (9-27 tiles: -10..14 %)
+  return tiles >= 32 && tiles <= 256 && tiles * s >= 192;
+}
+
 __global__ void reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ slabs, int nslab, size_t n4, size_t slab_stride4) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const f32x4* p = (const f32x4*)slabs + i;
@@ -554,7 +666,7 @@ int gemm_tn_splits(int M, int N1, int N2) {
 }
 
 size_t gemm_tn_workspace_bytes(int M, int N1, int N2) {
-  const int s = gemm_tn_splits(M, N1, N2);
+  const int s = std::max(gemm_tn_splits(M, N1, N2), (N1 % 256 == 0 && N2 % 256 == 0) ? gemm_tn_splits_256(M, N1, N2) : 1);
   return s > 1 ? (size_t)s * N1 * N2 * sizeof(float) : 0;
 }
 
@@ -562,6 +674,19 @@ int gemm_tn(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int M, int N1, i
   if (M <= 0 || N1 <= 0 || N2 <= 0) { set_error("gemm_tn: empty problem"); return SMBV_ERR_SHAPE; }
   if ((N1 & 7) || (N2 & 7) || (ldx & 7) || (ldy & 7)) { set_error("gemm_tn: N1,N2,ldx,ldy must be multiples of 8 (N1=%d N2=%d ldx=%d ldy=%d)", N1, N2, ldx, ldy); return SMBV_ERR_SHAPE; }
   if (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)out) & 15) { set_error("gemm_tn: operands must be 16-byte aligned"); return SMBV_ERR_ALIGN; }
+  if (gemm_tn_use_256(M, N1, N2) && ((size_t)M * ldx * 2 < (1ull << 31)) && ((size_t)M * ldy * 2 < (1ull << 31))) {
+    const int s2 = gemm_tn_splits_256(M, N1, N2);
+    const int mchunk2 = cdiv(cdiv(M, s2), 32) * 32;
+    const size_t need2 = (size_t)s2 * N1 * N2 * sizeof(float);
+    if (s2 > 1 && (!ws || ws_bytes < need2 || ((uintptr_t)ws & 15))) { set_error("gemm_tn: workspace too small (%zu < %zu)", ws_bytes, need2); return SMBV_ERR_WORKSPACE; }
+    hipLaunchKernelGGL(gemm_tn_256_kernel, dim3((N1 / 256) * (N2 / 256), s2), dim3(512), 0, st, X, ldx, Y, ldy, M, N1, N2, s2 > 1 ? (float*)ws : out, N2, N1 / 256,
+                       mchunk2, s2 > 1 ? (size_t)N1 * N2 : (size_t)0);
+    int rc2 = check_launch("gemm_tn_256");
+    if (rc2 || s2 == 1) return rc2;
+    const size_t n4b = (size_t)N1 * N2 / 4;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)std::min<size_t>(2048, (n4b + 255) / 256)), dim3(256), 0, st, out, (const float*)ws, s2, n4b, n4b);
+    return check_launch("reduce_slabs");
+  }
   const int s = gemm_tn_splits(M, N1, N2);
   const int t1 = cdiv(N1, 128), t2 = cdiv(N2, 128);
   const bool dma = (N1 % 128 == 0) && (N2 % 128 == 0) && ((size_t)M * ldx * 2 < (1ull << 31)) && ((size_t)M * ldy * 2 < (1ull << 31)) && !(g_variant & 32);
