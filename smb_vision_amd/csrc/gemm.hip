@@ -573,14 +573,14 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_256_kernel(const bf16_t* __res
   const int mA = 8 * g + q, mB = mA + 4;
   const int swA = sw_tn(mA), swB = sw_tn(mB);
   typedef __attribute__((ext_vector_type(8))) short s16x8;
-  stage(0); stage(1); stage(2);
-  for (int ks = 0; ks < nks; ks++) {
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");  // own pieces of slice ks landed (ks+1, ks+2 may fly); own reads of slice ks-1 returned
-    __builtin_amdgcn_s_barrier();
-    stage(ks + 3);  // into the slot of slice ks-1; token rows >= mend lie outside the descriptors and arrive as zeros
+  // Ping-pong: the block's two wave groups (w1 = 0 / 1: one wave of each per SIMD) run half a slice apart - while one group reads its
+  // fragments of a slice from LDS, the other issues its 32 MFMAs, so every SIMD always has a wave feeding the matrix pipe.  Both groups
+  // execute the same barrier sequence (two per slice); group 1 is shifted by one barrier (an extra one in front, group 0 makes it up
+  // at the end).  Barrier 2k is "slice k is readable" for group 0, barrier 2k+1 for group 1; every wave has waited for its own pieces
+  // of slice k (vmcnt) before barrier 2k, whichever phase it is in.
+  auto read_frags = [&](int ks, bf16x8* xf, bf16x8* yf) __attribute__((always_inline)) {
     const unsigned char* sx = smem + (ks & 3) * SLICE;
     const unsigned char* sy = sx + 32 * 512;
-    bf16x8 xf[8], yf[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int nt2 = w2 * 4 + j;
@@ -597,12 +597,44 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_256_kernel(const bf16_t* __res
       const s16x8 xx = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
       xf[i] = __builtin_bit_cast(bf16x8, xx);
     }
+  };
+  stage(0); stage(1); stage(2);
+  bf16x8 xf[8], yf[4];
+  if (w1 == 0) {
+    for (int ks = 0; ks < nks; ks++) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // own pieces of slice ks (ks+1, ks+2 may fly)
+      __builtin_amdgcn_s_barrier();                     // barrier 2ks: slice ks readable; everyone's reads of slice ks-1 are retired
+      stage(ks + 3);                                    // into the slot of slice ks-1
+      read_frags(ks, xf, yf);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                     // barrier 2ks+1
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+      for (int i = 0; i < 8; i++)
 #pragma unroll
-      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[j], xf[i], acc[i][j], 0, 0, 0);  // D[n2][n1]
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[j], xf[i], acc[i][j], 0, 0, 0);  // D[n2][n1]
+      __builtin_amdgcn_s_setprio(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the barrier group 1 executed in front
+  } else {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // own pieces of slice 0
+    __builtin_amdgcn_s_barrier();                       // barrier 0
+    for (int ks = 0; ks < nks; ks++) {
+      __builtin_amdgcn_s_barrier();                     // barrier 2ks+1: slice ks readable for this group (pieces waited before barrier 2ks)
+      stage(ks + 3);                                    // slot of slice ks-1: group 0 retired its reads before barrier 2ks, this group before 2ks-1... 2ks
+      read_frags(ks, xf, yf);
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");  // own reads returned; own pieces of slice ks+1 landed (ks+2, ks+3 may fly)
+      __builtin_amdgcn_s_barrier();                     // barrier 2ks+2
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[j], xf[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
 
   float* o = out + (size_t)z * slab_stride;
 #pragma unroll
@@ -629,7 +661,7 @@ static bool gemm_tn_use_256(int M, int N1, int N2) {
   const int s = gemm_tn_splits_256(M, N1, N2);
   // measured (tools/gemm_tn_ab.py): ahead of the 128 x 128 kernel when a slab still holds >= ~900 tokens (36-48 tiles: +3..26 %), behind it
   // when many short slabs are needed (9-27 tiles: -10..14 %)
-  return tiles >= 32 && tiles <= 256 && tiles * s >= 192;
+  return ((g_variant & 65536) ? tiles >= 1 : tiles >= 32) && tiles <= 256 && tiles * s >= 192;
 }
 
 __global__ void reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ slabs, int nslab, size_t n4, size_t slab_stride4) {

@@ -92,6 +92,22 @@ def test_gemm_tn(ops, M, N1, N2):
     assert rel_err(out, ref) < 1e-5 * math.sqrt(M) + 1e-6
 
 
+@pytest.mark.parametrize("M,N1,N2", [(2100, 2048, 1024), (7168, 768, 3072), (4100, 3072, 768)])
+def test_gemm_tn_wide_outputs_take_the_256_tile_kernel(ops, M, N1, N2):
+    """>= 32 tiles of 256 x 256 with slabs of >= 256 tokens: gemm_tn_256_kernel (ping-pong wave groups, 4-slot hidden LDS-DMA ring); ragged last slab;
+    an identity block in X pins the operand orientation (out[n1, n2] = sum_m X[m, n1] Y[m, n2])."""
+    X = rnd(M, N1, seed=5).bfloat16()
+    Y = rnd(M, N2, seed=6).bfloat16()
+    out = ops.gemm_tn(X, Y)
+    ref = X.float().t() @ Y.float()
+    assert rel_err(out, ref) < 1e-5 * math.sqrt(M) + 1e-6
+    assert torch.equal(out, ops.gemm_tn(X, Y))  # run-to-run identical (slabs summed in slab order)
+    Xi = torch.zeros(M, N1, device="cuda").bfloat16()
+    Xi[:N1 if N1 < M else M].fill_diagonal_(1.0)
+    n = min(N1, M)
+    assert torch.equal(ops.gemm_tn(Xi, Y)[:n], Y.float()[:n])
+
+
 def test_gemm_tn_asymmetric(ops):
     M = 128
     X = torch.eye(M, device="cuda").bfloat16()                       # X^T Y = Y
