@@ -273,6 +273,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
       pf[i] = (__bf16)p0;
       pf[i + 1] = (__bf16)p1;
     }
+    // (pinned: hipcc otherwise sinks the row-sum adds - nothing in the tile needs them - below the tile's last MFMA, where they run
+    // with the matrix pipe idle; row sums as a fifth MFMA product (ones * P^T) were tried too: same speed, the bound just moves)
+    asm volatile("" : "+v"(l_a), "+v"(l_b));
   };
   const int nt = (S + 63) / 64;
   auto tile_max = [&](const f32x16* sn) __attribute__((always_inline)) -> float {
@@ -394,7 +397,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
 #pragma unroll
       for (int dt = 0; dt < 2; dt++) ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt[ks][dt], pf[ks], ot[dt], 0, 0, 0);
     kread(j + 2, 1, kfb);
-    const float mx = tile_max(sn);
+    float mx = tile_max(sn);
+    asm volatile("" : "+v"(mx));  // (pinned inside this group: see pgroup)
     __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
     __builtin_amdgcn_sched_group_barrier(SG_TRANS, 4, 0);
     __builtin_amdgcn_sched_group_barrier(SG_VALU, 6, 0);
