@@ -48,9 +48,9 @@ def allreduce_mean_(flat: torch.Tensor, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return None
-    if flat.is_cuda:
+    if flat.is_cuda and dist.get_backend(group) == "nccl":  # RCCL: averaging collective, asynchronous on its own stream
         return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group, async_op=True)
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)  # gloo (CPU tensors, or device tensors when rehearsing on one GPU)
     flat.mul_(1.0 / world)
     return None
 
@@ -95,6 +95,12 @@ class DataParallelEngine:
         if not self.overlap or self._ev_array is None:
             return None, 0
         return self._ev_array, len(self._events)
+
+    def record_all(self):
+        """For a model whose backward call does not record per-group events (V-JEPA): mark every group complete at this point of the
+        current stream, i.e. gate all buckets on the end of the backward."""
+        for ev in self._events:
+            ev.record(torch.cuda.current_stream())
 
     def prepare(self, model):
         if self._buckets is None:

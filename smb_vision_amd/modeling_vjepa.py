@@ -146,6 +146,7 @@ class SmbVJEPA2Model(PreTrainedModel):
         self.gradient_checkpointing = False
         self.mask_index = 1  # VJEPA2PredictorEmbeddings.forward default (modeling_vjepa.py:593)
         self._gflat = self._structs = self._ws = self._ws_key = self._rope = None
+        self.dp = None  # optional smb_vision_amd.dp.DataParallelEngine (gradient averaging after the backward)
         self._fwd_count = 0
         self.reset_parameters()
         self.post_init()
@@ -304,7 +305,19 @@ class SmbVJEPA2Model(PreTrainedModel):
         stream = torch.cuda.current_stream().cuda_stream
         _lib.check(lib.smbv_vjepa_backward(C.byref(st["cfg"]), C.byref(ps), C.byref(gs), C.byref(io), self._ws.data_ptr(), self._ws.numel(), stream),
                    "smbv_vjepa_backward")
+        if self.dp is not None:  # data parallel: average the whole arena once the backward is enqueued (no per-group overlap yet)
+            self.dp.prepare(self)
+            self.dp.record_all()
+            self.dp.allreduce_after_backward(self)
         return self.grad_views()
+
+    # -- data parallel hooks (smb_vision_amd.dp.DataParallelEngine) --------------------------------------------------------------
+    def flat_grads(self) -> torch.Tensor:
+        return self._gflat
+
+    def grad_group_ranges(self):
+        """One completion group: the whole arena (smbv_vjepa_backward records no intermediate events)."""
+        return [(0, int(self._gflat.numel()))]
 
     def forward(self, pixel_values_videos: torch.Tensor, context_head_mask=None, context_mask: Optional[List[torch.Tensor]] = None,
                 target_head_mask=None, target_mask: Optional[List[torch.Tensor]] = None, skip_predictor: bool = False, output_attentions=None,

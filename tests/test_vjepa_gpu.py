@@ -153,3 +153,50 @@ def test_hf_trainer_runs_vjepa(tmp_path):
                     "--max_grad_norm", "1.0", "--dataloader_num_workers", "0"])
     assert 0 < metrics["train_loss"] < 2.0
     assert os.path.exists(os.path.join(tmp_path, "model.safetensors"))
+
+
+TINY = dict(patch_size=8, crop_size=32, frames_per_clip=8, tubelet_size=2, in_chans=1, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+            mlp_ratio=4.0, pred_hidden_size=64, pred_num_hidden_layers=2, pred_num_attention_heads=2, pred_num_mask_tokens=10, pred_mlp_ratio=4.0)
+
+
+def _vjepa_dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from transformers import VJEPA2Config
+        from smb_vision_amd.dp import DataParallelEngine
+        from smb_vision_amd.modeling_vjepa import SmbVJEPA2Model
+        torch.cuda.set_device(0)
+        torch.manual_seed(0)
+        m = SmbVJEPA2Model(VJEPA2Config(**TINY)).cuda().train()
+        dp = DataParallelEngine(m, overlap=False)  # gloo has no device-side AVG: the engine's SUM + scale path, as in tests/test_dp_cpu.py
+        dp.broadcast_parameters(m)
+        g = torch.Generator().manual_seed(10 + rank)      # different data per rank
+        pix = torch.rand(1, TINY["frames_per_clip"], 1, TINY["crop_size"], TINY["crop_size"], generator=g).cuda()
+        n = (TINY["frames_per_clip"] // TINY["tubelet_size"]) * (TINY["crop_size"] // TINY["patch_size"]) ** 2
+        perm = torch.randperm(n, generator=torch.Generator().manual_seed(5))
+        cm, tm = perm[: n // 2].sort().values[None].cuda(), perm[n // 2:].sort().values[None].cuda()
+        out = m(pixel_values_videos=pix, context_mask=[cm], target_mask=[tm])
+        out.predictor_output.last_hidden_state.square().mean().backward()
+        q.put((rank, m.flat_grads().double().sum().item(), m.flat_grads().abs().double().sum().item()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_vjepa_gradients_are_averaged_across_ranks():
+    """Two processes on the one GPU (gloo): after backward both ranks hold the same, non-trivial, averaged gradient arena."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_vjepa_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in ps)
+    assert res[0][1] == pytest.approx(res[1][1], rel=1e-12, abs=1e-12) and res[0][2] == pytest.approx(res[1][2], rel=1e-12) and res[0][2] > 0
