@@ -48,7 +48,7 @@ def allreduce_mean_(flat: torch.Tensor, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return None
-    if flat.is_cuda and dist.get_backend(group) == "nccl":  # RCCL: averaging collective, asynchronous on its own stream
+    if flat.is_cuda and "nccl" in str(dist.get_backend(group)).lower():  # RCCL: averaging collective, asynchronous on its own stream
         return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group, async_op=True)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)  # gloo (CPU tensors, or device tensors when rehearsing on one GPU)
     flat.mul_(1.0 / world)
