@@ -806,6 +806,7 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
   if (Dh != 64) { set_error("attention_bwd: head_dim %d not supported (only 64)", Dh); return SMBV_ERR_SHAPE; }
   if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 7) || (ldd & 3)) { set_error("attention_bwd: bad shape"); return SMBV_ERR_SHAPE; }
   if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)dO) & 15) || (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 7)) { set_error("attention_bwd: alignment"); return SMBV_ERR_ALIGN; }
+  if ((size_t)(S + 256) * ld * 2 >= (1ull << 31) || (size_t)(S + 256) * ldo * 2 >= (1ull << 31)) { set_error("attention_bwd: one sequence spans >= 2 GiB of an operand matrix; the LDS-DMA offsets are 32-bit"); return SMBV_ERR_SHAPE; }
   const long pairs = (long)B * Sq * H;
   int rc = SMBV_OK;
   if (parts & 1) {
