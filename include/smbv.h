@@ -285,8 +285,11 @@ typedef struct smbv_vjepa_io {
 size_t smbv_vjepa_workspace_bytes(const smbv_vjepa_cfg* cfg);
 int smbv_vjepa_forward(const smbv_vjepa_cfg* cfg, const smbv_vjepa_tensors* params, const smbv_vjepa_io* io, void* ws, size_t ws_bytes,
                        smbv_stream stream);
+/* events / n_events: optional hipEvent_t array recorded on `stream` as gradient groups complete (for the data-parallel all-reduce), in this
+ * order: [0] predictor.proj + predictor.layernorm, [1..players] predictor layers (last first), [players+1] mask tokens + predictor_embeddings,
+ * [players+2] encoder.layernorm, [players+3 .. players+2+layers] encoder layers (last first), [last] patch embedding. */
 int smbv_vjepa_backward(const smbv_vjepa_cfg* cfg, const smbv_vjepa_tensors* params, const smbv_vjepa_tensors* grads, const smbv_vjepa_io* io,
-                        void* ws, size_t ws_bytes, smbv_stream stream);
+                        void* ws, size_t ws_bytes, void** events, int n_events, smbv_stream stream);
 
 #ifdef __cplusplus
 }

@@ -122,7 +122,8 @@ _SIGS = {
     "smbv_ema_update": (C.c_int, [c_f, C.c_int, C.c_float, c_f]),
     "smbv_vjepa_workspace_bytes": (C.c_size_t, [C.POINTER(VjepaCfg)]),
     "smbv_vjepa_forward": (C.c_int, [C.POINTER(VjepaCfg), C.POINTER(VjepaTensors), C.POINTER(VjepaIO), c_f, C.c_size_t, c_f]),
-    "smbv_vjepa_backward": (C.c_int, [C.POINTER(VjepaCfg), C.POINTER(VjepaTensors), C.POINTER(VjepaTensors), C.POINTER(VjepaIO), c_f, C.c_size_t, c_f]),
+    "smbv_vjepa_backward": (C.c_int, [C.POINTER(VjepaCfg), C.POINTER(VjepaTensors), C.POINTER(VjepaTensors), C.POINTER(VjepaIO), c_f, C.c_size_t,
+                                      C.POINTER(C.c_void_p), C.c_int, c_f]),
     "smbv_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderCfg)]),
     "smbv_encoder_forward": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(EncoderTensors), C.POINTER(EncoderIO), c_f, C.c_size_t, c_f]),
     "smbv_encoder_backward": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(EncoderTensors), C.POINTER(EncoderTensors), C.POINTER(EncoderIO), c_f, c_f, C.c_size_t, c_f]),

@@ -171,8 +171,16 @@ static int vjepa_forward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, c
 }
 
 static int vjepa_backward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, const smbv_vjepa_tensors& gr, const smbv_vjepa_io& io, void* ws,
-                          size_t ws_bytes, hipStream_t st) {
+                          size_t ws_bytes, void** events, int n_events, hipStream_t st) {
   RC(vcheck(c));
+  const int need_events = 4 + c.layers + c.players;
+  if (events && n_events < need_events) { set_error("vjepa_backward: need %d events, got %d", need_events, n_events); return SMBV_ERR_ARG; }
+  int ev = 0;
+  auto mark = [&]() -> int {  // a gradient group is final: the data-parallel engine may start averaging it
+    if (events) HIPRC(hipEventRecord((hipEvent_t)events[ev], st));
+    ev++;
+    return SMBV_OK;
+  };
   VjepaWs W;
   vcarve(c, ws, W);
   if (!ws || ws_bytes < W.total || ((uintptr_t)ws & 255)) { set_error("vjepa_backward: workspace too small or misaligned"); return SMBV_ERR_WORKSPACE; }
@@ -194,8 +202,11 @@ static int vjepa_backward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, 
   RC(scatter_rows_idx_bf16(W.d_tgt, W.d_lnfull, io.tgt_slot, (long)Rt, c.Ntgt, Sp, c.pd, st));
   RC(layernorm_bwd(W.d_lnfull, W.xp[c.players], W.pred_mean, W.pred_rstd, p.pred_ln_w, nullptr, W.g0, W.gb0, gr.pred_ln_w, gr.pred_ln_b, (int)Rp, c.pd, 0,
                    0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
-  for (int l = c.players - 1; l >= 0; l--)
+  RC(mark());  // [0] predictor.proj + predictor.layernorm
+  for (int l = c.players - 1; l >= 0; l--) {
     RC(layer_bwd(vblock(p.pred[l]), vblock(gr.pred[l]), W.pred[l], dp, W.sc, W.xp[l], W.g0, W.gb0, W.g1, W.gb1, 0, 0, st));
+    RC(mark());  // [1 .. players] predictor layers, last first
+  }
   // predictor input: mask-token gradient = sum over the target slots; context slots flow into predictor_embeddings
   RC(gather_rows_idx_f32(W.g0, W.gtmp, io.tgt_slot, (long)Rt, c.Ntgt, Sp, c.pd, st));
   RC(colsum_f32(W.gtmp, c.pd, (int)Rt, c.pd, gr.mask_token, 0, 0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
@@ -206,16 +217,21 @@ static int vjepa_backward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, 
     GemmEpi e; e.out_bf16 = W.d_encctx; e.ld_ob = c.d;
     RC(gemm_nt(W.d_ctx, c.pd, W.pemb_t, c.pd, (int)Rc, c.d, c.pd, e, st));
   }
+  RC(mark());  // [players+1] mask tokens + predictor_embeddings
   // encoder.layernorm: only the context tokens receive gradient
   HIPRC(hipMemsetAsync(W.d_lnfull, 0, Re * c.d * sizeof(bf16_t), st));
   RC(scatter_rows_idx_bf16(W.d_encctx, W.d_lnfull, io.ctx_idx, (long)Rc, c.Nctx, c.N, c.d, st));
   RC(layernorm_bwd(W.d_lnfull, W.x[c.layers], W.enc_mean, W.enc_rstd, p.enc_ln_w, nullptr, W.g0, W.gb0, gr.enc_ln_w, gr.enc_ln_b, (int)Re, c.d, 0, 0, 0,
                    W.sc.scratch, W.sc.scratch_bytes, st));
-  for (int l = c.layers - 1; l >= 0; l--)
+  RC(mark());  // [players+2] encoder.layernorm
+  for (int l = c.layers - 1; l >= 0; l--) {
     RC(layer_bwd(vblock(p.enc[l]), vblock(gr.enc[l]), W.enc[l], de, W.sc, W.x[l], W.g0, W.gb0, W.g1, W.gb1, 0, 0, st));
+    RC(mark());  // [players+3 ..] encoder layers, last first
+  }
   // patch embedding
   RC(colsum_bf16(W.gb0, c.d, (int)Re, c.d, gr.pe_b, 0, 0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
   RC(gemm_tn(W.gb0, c.d, W.a_patch, K, (int)Re, c.d, K, gr.pe_w, W.sc.scratch, W.sc.scratch_bytes, st));
+  RC(mark());  // [last] patch embedding
   return SMBV_OK;
 }
 
@@ -234,9 +250,9 @@ int smbv_vjepa_forward(const smbv_vjepa_cfg* cfg, const smbv_vjepa_tensors* para
   return smbv::vjepa_forward(*cfg, *params, *io, ws, ws_bytes, (hipStream_t)stream);
 }
 int smbv_vjepa_backward(const smbv_vjepa_cfg* cfg, const smbv_vjepa_tensors* params, const smbv_vjepa_tensors* grads, const smbv_vjepa_io* io, void* ws,
-                        size_t ws_bytes, smbv_stream stream) {
+                        size_t ws_bytes, void** events, int n_events, smbv_stream stream) {
   if (!cfg || !params || !grads || !io) { smbv::set_error("smbv_vjepa_backward: null argument"); return SMBV_ERR_ARG; }
-  return smbv::vjepa_backward(*cfg, *params, *grads, *io, ws, ws_bytes, (hipStream_t)stream);
+  return smbv::vjepa_backward(*cfg, *params, *grads, *io, ws, ws_bytes, events, n_events, (hipStream_t)stream);
 }
 
 }  // extern "C"

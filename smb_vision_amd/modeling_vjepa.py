@@ -303,11 +303,13 @@ class SmbVJEPA2Model(PreTrainedModel):
         _, ps, gs = self._structs
         self._gflat.zero_()  # rows of mask_tokens that were not selected keep a zero gradient
         stream = torch.cuda.current_stream().cuda_stream
-        _lib.check(lib.smbv_vjepa_backward(C.byref(st["cfg"]), C.byref(ps), C.byref(gs), C.byref(io), self._ws.data_ptr(), self._ws.numel(), stream),
-                   "smbv_vjepa_backward")
-        if self.dp is not None:  # data parallel: average the whole arena once the backward is enqueued (no per-group overlap yet)
+        events, n_ev = None, 0
+        if self.dp is not None:
             self.dp.prepare(self)
-            self.dp.record_all()
+            events, n_ev = self.dp.event_array()
+        _lib.check(lib.smbv_vjepa_backward(C.byref(st["cfg"]), C.byref(ps), C.byref(gs), C.byref(io), self._ws.data_ptr(), self._ws.numel(), events, n_ev,
+                                           stream), "smbv_vjepa_backward")
+        if self.dp is not None:  # data parallel: each bucket's all-reduce starts when its last gradient group is final
             self.dp.allreduce_after_backward(self)
         return self.grad_views()
 
@@ -316,8 +318,27 @@ class SmbVJEPA2Model(PreTrainedModel):
         return self._gflat
 
     def grad_group_ranges(self):
-        """One completion group: the whole arena (smbv_vjepa_backward records no intermediate events)."""
-        return [(0, int(self._gflat.numel()))]
+        """Element ranges of the flat gradient arena in the order smbv_vjepa_backward completes them (its event order): predictor.proj +
+        predictor.layernorm, predictor layers (last first), mask tokens + predictor_embeddings, encoder.layernorm, encoder layers (last
+        first), patch embedding."""
+        names = [n for n, _, _ in self._table]
+        sizes = [(p.numel() + 63) // 64 * 64 for p in self._ordered_params()]
+        offs = self._goffs
+
+        def span(pred):
+            idx = [i for i, n in enumerate(names) if pred(n)]
+            return (offs[idx[0]], offs[idx[-1]] + sizes[idx[-1]])
+
+        c = self.config
+        out = [span(lambda n: n.startswith("predictor.layernorm.") or n.startswith("predictor.proj."))]
+        for l in reversed(range(c.pred_num_hidden_layers)):
+            out.append(span(lambda n, l=l: n.startswith(f"predictor.layer.{l}.")))
+        out.append(span(lambda n: n.startswith("predictor.embeddings.")))
+        out.append(span(lambda n: n.startswith("encoder.layernorm.")))
+        for l in reversed(range(c.num_hidden_layers)):
+            out.append(span(lambda n, l=l: n.startswith(f"encoder.layer.{l}.")))
+        out.append(span(lambda n: n.startswith("encoder.embeddings.")))
+        return out
 
     def forward(self, pixel_values_videos: torch.Tensor, context_head_mask=None, context_mask: Optional[List[torch.Tensor]] = None,
                 target_head_mask=None, target_mask: Optional[List[torch.Tensor]] = None, skip_predictor: bool = False, output_attentions=None,

@@ -97,3 +97,21 @@ def test_bucketed_allreduce_world2_gloo():
 def test_engine_requires_process_group():
     with pytest.raises(RuntimeError):
         DataParallelEngine(FakeModel(4, [(0, 4)]))
+
+
+def test_vjepa_gradient_groups_tile_the_arena():
+    """SmbVJEPA2Model.grad_group_ranges(): the completion groups smbv_vjepa_backward signals (4 + layers + predictor layers events) are
+    disjoint, cover the whole flat arena, and come in reverse forward order, so that adjacent groups merge into contiguous buckets."""
+    from transformers import VJEPA2Config
+    from smb_vision_amd.modeling_vjepa import SmbVJEPA2Model
+    c = dict(patch_size=8, crop_size=32, frames_per_clip=8, tubelet_size=2, in_chans=1, hidden_size=128, num_hidden_layers=3, num_attention_heads=2,
+             mlp_ratio=4.0, pred_hidden_size=64, pred_num_hidden_layers=2, pred_num_attention_heads=2, pred_num_mask_tokens=10, pred_mlp_ratio=4.0)
+    m = SmbVJEPA2Model(VJEPA2Config(**c))
+    m._ensure_device_state(torch.device("cpu"))
+    r = m.grad_group_ranges()
+    assert len(r) == 4 + 3 + 2
+    assert all(a < b for a, b in r)
+    assert [b for _, b in r[1:]] == [a for a, _ in r[:-1]]          # each group ends where the previously completed one starts
+    assert r[-1][0] == 0 and r[0][1] == m.flat_grads().numel()
+    b = merge_ranges(r, 1 << 62)
+    assert b == [(0, m.flat_grads().numel(), len(r) - 1)]
