@@ -148,6 +148,9 @@ def rope3d(qk, ids, grid_size):
     return torch.cat(parts, dim=-1)
 
 
+SDPA = False  # full-size checks set this: the same softmax(QK^T/sqrt(Dh))V through torch's fused CPU kernel (no S x S matrix in memory)
+
+
 def attention(x, p, prefix, heads, ids, grid_size):
     B, S, D = x.shape
     dh = D // heads
@@ -157,6 +160,9 @@ def attention(x, p, prefix, heads, ids, grid_size):
     v = F.linear(x, p[a + "value.weight"], p[a + "value.bias"]).view(B, S, heads, dh).transpose(1, 2)
     k = rope3d(k, ids, grid_size)
     q = rope3d(q, ids, grid_size)
+    if SDPA:
+        o = F.scaled_dot_product_attention(q, k, v, scale=dh ** -0.5).transpose(1, 2).reshape(B, S, D)
+        return F.linear(o, p[a + "proj.weight"], p[a + "proj.bias"])
     s = torch.matmul(q, k.transpose(-1, -2)) * (dh ** -0.5)
     o = torch.matmul(torch.softmax(s, dim=-1), v).transpose(1, 2).reshape(B, S, D)
     return F.linear(o, p[a + "proj.weight"], p[a + "proj.bias"])
@@ -178,11 +184,17 @@ def patch_embed(pix, w, b, cfg: VJEPAConfig):
     return x.flatten(2).transpose(1, 2)
 
 
-def encoder(p, cfg: VJEPAConfig, pix):
+def encoder_body(p, cfg: VJEPAConfig, pix):
+    """Embeddings + the L layers, WITHOUT the final LayerNorm (:507-529)."""
     x = patch_embed(pix, p["encoder.embeddings.patch_embeddings.proj_3d.weight"], p["encoder.embeddings.patch_embeddings.proj_3d.bias"], cfg)
     ids = torch.arange(x.shape[1])
     for i in range(cfg.num_hidden_layers):
         x = layer(x, p, f"encoder.layer.{i}.", cfg.num_attention_heads, cfg.layer_norm_eps, ids, cfg.grid_size)
+    return x
+
+
+def encoder(p, cfg: VJEPAConfig, pix):
+    x = encoder_body(p, cfg, pix)
     return F.layer_norm(x, (cfg.hidden_size,), p["encoder.layernorm.weight"], p["encoder.layernorm.bias"], cfg.layer_norm_eps)
 
 

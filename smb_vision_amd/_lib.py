@@ -158,6 +158,20 @@ def load():
     return lib
 
 
+def detach_aliased_grads(params, arena):
+    """Gradient accumulation support.  A step's gradients are written into ONE persistent flat arena and handed to autograd as views of
+    it; when ``p.grad`` is None autograd keeps such a view as ``p.grad`` (no copy).  If a parameter still holds that alias when the
+    next backward starts (``gradient_accumulation_steps > 1`` as scripts/training/run_vjepa.sh:28 sets, or ``zero_grad(set_to_none=
+    False)``), the arena is about to be overwritten underneath it: give the parameter its own copy first, so that autograd's
+    ``p.grad += view`` afterwards is the sum the reference computes.  Costs nothing when every ``p.grad`` is None."""
+    lo = arena.data_ptr()
+    hi = lo + arena.numel() * arena.element_size()
+    for p in params:
+        g = p.grad
+        if g is not None and lo <= g.data_ptr() < hi:
+            p.grad = g.clone()
+
+
 def last_error() -> str:
     buf = C.create_string_buffer(512)
     load().smbv_last_error(buf, 512)

@@ -388,6 +388,7 @@ class SmbVideoMAEForPreTraining(PreTrainedModel):
         if st["step"] != self._fwd_count:
             raise _lib.SmbvError("smb_vision_amd: backward() after a later forward() reused the step workspace "
                                  "(one forward/backward pair at a time per model)")
+        _lib.detach_aliased_grads(self._ordered_params(), self._gflat)  # accumulation / zero_grad(set_to_none=False)
         gscale = grad_loss.detach().to(torch.float32).reshape(1).contiguous()
         io = st["io"]
         io.grad_scale = gscale.data_ptr()
@@ -395,6 +396,7 @@ class SmbVideoMAEForPreTraining(PreTrainedModel):
         stream = torch.cuda.current_stream().cuda_stream
         events, n_ev = None, 0
         if self.dp is not None:
+            self.dp.prepare(self)  # per-group events exist before the first backward records them
             events, n_ev = self.dp.event_array()
         _lib.check(lib.smbv_mim_backward(C.byref(st["cfg"]), C.byref(ps), C.byref(gs), C.byref(io), self._ws.data_ptr(), self._ws.numel(),
                                          events, n_ev, stream), "smbv_mim_backward")

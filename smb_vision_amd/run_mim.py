@@ -6,7 +6,8 @@ dataclasses → dataset → ``VideoMAEConfig`` patched with ``num_channels=1, nu
 (``:302-330``) → model → ``collate_fn`` producing ``{"pixel_values", "bool_masked_pos"}`` (``:194-219``) → HF ``Trainer`` →
 ``train`` / ``save_model`` / metrics.  Differences, all on purpose:
 
-* the model is ``SmbVideoMAEForPreTraining`` (HIP kernels behind the same interface);
+* the model is ``SmbVideoMAEForPreTraining`` (HIP kernels behind the same interface) and the ``Trainer`` is ``SmbTrainer`` (``trainer.py``): under a
+  one-process-per-GPU launch it averages gradients over RCCL itself (replacing ``acc_configs/multi_gpu_config.yaml``) and runs the fused optimizer tail;
 * the dataset here is synthetic and in-memory (``SyntheticVolumeDataset``: U[0,1) volumes in the post-``ScaleIntensityRanged`` range,
   ``(D,1,H,W)`` layout of ``PermuteImage``, masks from the bit-exact ``MaskGenerator``): NIfTI/MONAI ingestion is out of scope
   (SURVEY.md §2.1) and absent from this image; plug a real dataset in by returning the same two keys;
@@ -26,10 +27,11 @@ from typing import Optional
 import numpy as np
 import torch
 from torch.utils.data import Dataset
-from transformers import HfArgumentParser, Trainer, TrainingArguments, VideoMAEConfig, set_seed
+from transformers import HfArgumentParser, TrainingArguments, VideoMAEConfig, set_seed
 
 from .masking import MaskGenerator
 from .modeling_videomae import SmbVideoMAEForPreTraining
+from .trainer import SmbTrainer
 
 logger = logging.getLogger(__name__)
 os.environ.setdefault("HF_HUB_OFFLINE", "1")
@@ -88,7 +90,8 @@ def collate_fn(examples):
     return {"pixel_values": pixel_values, "bool_masked_pos": mask}
 
 
-def main(argv=None):
+def build_trainer(argv=None):
+    """Everything of ``src/run_mim.py:222-436`` up to and including the ``Trainer`` construction."""
     parser = HfArgumentParser((ModelArguments, DataTrainingArguments, TrainingArguments))
     model_args, data_args, training_args = parser.parse_args_into_dataclasses(args=argv)
     logging.basicConfig(format="%(asctime)s - %(levelname)s - %(name)s - %(message)s", level=logging.INFO, handlers=[logging.StreamHandler(sys.stdout)])
@@ -113,7 +116,12 @@ def main(argv=None):
         logger.info("Training new model from scratch")
         model = SmbVideoMAEForPreTraining(config)
 
-    trainer = Trainer(model=model, args=training_args, train_dataset=train, data_collator=collate_fn)
+    # SmbTrainer == HF Trainer + RCCL gradient averaging (instead of accelerate's DDP wrap, acc_configs/multi_gpu_config.yaml) + the fused clip/AdamW tail
+    return SmbTrainer(model=model, args=training_args, train_dataset=train, data_collator=collate_fn)
+
+
+def main(argv=None):
+    trainer = build_trainer(argv)
     result = trainer.train()
     trainer.save_model()
     trainer.log_metrics("train", result.metrics)

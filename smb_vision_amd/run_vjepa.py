@@ -16,10 +16,11 @@ from typing import Optional
 
 import torch
 from torch.utils.data import Dataset
-from transformers import HfArgumentParser, Trainer, TrainingArguments, VJEPA2Config, set_seed
+from transformers import HfArgumentParser, TrainingArguments, VJEPA2Config, set_seed
 
 from .masking import VJEPAMaskGenerator
-from .modeling_vjepa import MomentumEncoder, SmbVJEPA2Model, make_target_encoder, vjepa_loss
+from .modeling_vjepa import MomentumEncoder, SmbVJEPA2Model, l1_loss, make_target_encoder, vjepa_loss
+from .trainer import SmbTrainer
 
 logger = logging.getLogger(__name__)
 os.environ.setdefault("HF_HUB_OFFLINE", "1")
@@ -28,14 +29,19 @@ os.environ.setdefault("WANDB_MODE", "disabled")
 random.seed(42)  # run_vjepa.py:30
 
 
-class SmbVJEPATrainer(Trainer):
-    """``VJEPATrainer`` (run_vjepa.py:101-141)."""
+class SmbVJEPATrainer(SmbTrainer):
+    """``VJEPATrainer`` (run_vjepa.py:101-141) on top of ``SmbTrainer`` (RCCL gradient averaging of the ONLINE model only — the target encoder is a
+    function of the online parameters, identical on every rank — and the fused optimizer tail)."""
 
     def __init__(self, *args, momentum=0.99925, **kwargs):
         super().__init__(*args, **kwargs)
         self.target_encoder = None
         self.momentum = momentum
         self.momentum_encoder = None
+        # The reference assigns ``self.compute_loss_func = nn.L1Loss()`` (run_vjepa.py:108); with this transformers version that attribute switches
+        # OFF the division of the loss by gradient_accumulation_steps in training_step (SURVEY.md row T / Appendix A.8).  Reproduced: any non-None
+        # value has that effect, and compute_loss below never calls it.
+        self.compute_loss_func = l1_loss
 
     def compute_loss(self, model, inputs, return_outputs=False, num_items_in_batch=None):
         if self.target_encoder is None:  # created once the online model sits on its device

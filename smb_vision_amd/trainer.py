@@ -1,0 +1,94 @@
+"""``SmbTrainer`` — HF ``Trainer`` with the MI355X data-parallel and optimizer tail wired in.
+
+What the reference gets from ``accelerate launch --config_file acc_configs/multi_gpu_config.yaml`` (``scripts/training/run_vjepa.sh:16``,
+``acc_configs/multi_gpu_config.yaml:1-17``: ``distributed_type: MULTI_GPU`` -> accelerate wraps the model in
+``DistributedDataParallel``, 25 MB NCCL buckets) is replaced here, inside the same ``Trainer`` skeleton the reference scripts use
+(``src/run_mim.py:429-436``, ``src/run_vjepa.py:249-256``):
+
+* the model is NOT wrapped: ``accelerator.prepare_model`` hands a smb_vision_amd model back as is, and ``smb_vision_amd.dp.DataParallelEngine``
+  is attached to it instead (RCCL all-reduce of the flat gradient arena on a side HIP stream, gated per layer group by HIP events the backward
+  C call records — ``dp.py``).  Rank 0's parameters are broadcast at start, as DDP does at wrap time;
+* the optimizer is ``SmbvAdamW`` (global-norm clip + AdamW as two HIP launches, ``optim.py``) with HF's decay / no-decay grouping, unless the
+  caller passed ``optimizers=`` or asked for a non-AdamW ``--optim``; ``--max_grad_norm`` is honoured INSIDE its ``step`` and the logged
+  ``grad_norm`` is the same pre-clip global norm HF reports, handed over as a device scalar (no per-step host sync);
+* everything else (sampler sharding, schedule, logging, checkpointing, ``save_model``) is the stock ``Trainer``.
+
+Launch exactly as the contract says: one process per GPU (``python -m torch.distributed.run --nproc-per-node N -m smb_vision_amd.run_mim ...``);
+``torch.distributed`` backend "nccl" is RCCL on ROCm.  With gradient accumulation every micro-batch's gradients are averaged when they are
+produced (accelerate's ``sync_each_batch`` behaviour): mean of sums == sum of means, so the result equals DDP's.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+from transformers import Trainer
+
+from .dp import DataParallelEngine
+from .optim import SmbvAdamW
+
+_NATIVE_OPTIMS = ("adamw_torch", "adamw_torch_fused", "adamw_hf")
+
+
+def _is_native(model) -> bool:
+    return hasattr(model, "flat_grads") and hasattr(model, "grad_group_ranges")
+
+
+class SmbTrainer(Trainer):
+    def __init__(self, *args, dp_bucket_bytes: int = 32 << 20, **kwargs):
+        self._dp_bucket_bytes = dp_bucket_bytes
+        self.dp_engine = None
+        super().__init__(*args, **kwargs)
+
+    # -- no DDP wrap ----------------------------------------------------------------------------------------------------------------------
+    def create_accelerator_and_postprocess(self) -> None:
+        super().create_accelerator_and_postprocess()
+        acc = self.accelerator
+        stock = acc.prepare_model
+
+        def prepare_model(model, device_placement=None, evaluation_mode=False):
+            if _is_native(model):  # gradient averaging belongs to the model's DataParallelEngine
+                if model not in acc._models:
+                    acc._models.append(model)
+                return model
+            return stock(model, device_placement=device_placement, evaluation_mode=evaluation_mode)
+
+        acc.prepare_model = prepare_model
+
+    def _prepare_for_training(self, *args, **kwargs):
+        out = super()._prepare_for_training(*args, **kwargs)
+        model = self.model
+        if _is_native(model) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and self.dp_engine is None:
+            overlap = "nccl" in str(dist.get_backend()).lower()  # the side-stream overlap needs RCCL's stream-ordered collectives
+            self.dp_engine = DataParallelEngine(model, bucket_bytes=self._dp_bucket_bytes, overlap=overlap)
+            self.dp_engine.broadcast_parameters(model)
+        return out
+
+    # -- fused optimizer tail -------------------------------------------------------------------------------------------------------------
+    def create_optimizer(self, model=None):
+        opt_model = self.model if model is None else model
+        if self.optimizer is None and self.optimizer_cls_and_kwargs is None and str(getattr(self.args.optim, "value", self.args.optim)) in _NATIVE_OPTIMS \
+                and _is_native(opt_model):
+            decay = self.get_decay_parameter_names(opt_model)
+            groups = [{"params": [p for n, p in opt_model.named_parameters() if n in decay and p.requires_grad], "weight_decay": self.args.weight_decay},
+                      {"params": [p for n, p in opt_model.named_parameters() if n not in decay and p.requires_grad], "weight_decay": 0.0}]
+            groups = [g for g in groups if g["params"]]
+            mgn = self.args.max_grad_norm if self.args.max_grad_norm is not None and self.args.max_grad_norm > 0 else None
+            self.optimizer = SmbvAdamW(groups, lr=self.args.learning_rate, betas=(self.args.adam_beta1, self.args.adam_beta2), eps=self.args.adam_epsilon,
+                                       max_grad_norm=mgn)
+            return self.optimizer
+        return super().create_optimizer(model)
+
+    def _native_optimizer(self):
+        opt = self.optimizer
+        opt = getattr(opt, "optimizer", opt)  # accelerate's AcceleratedOptimizer
+        return opt if isinstance(opt, SmbvAdamW) else None
+
+    def _clip_grad_norm(self, model):
+        opt = self._native_optimizer()
+        if opt is None or not opt.max_grad_norm:
+            return super()._clip_grad_norm(model)
+        return opt.compute_grad_norm()  # device scalar; the clip itself happens inside opt.step() with this same value
+
+
+def unwrap_optimizer(optimizer):
+    return getattr(optimizer, "optimizer", optimizer)

@@ -1,0 +1,221 @@
+"""GPU: gradient accumulation semantics and the data-parallel drop-in (SmbTrainer).
+
+* Accumulation (scripts/training/run_vjepa.sh:28 trains with --gradient_accumulation_steps 4): the step's gradients are views of ONE persistent
+  arena; two micro-batches must still sum, and ``zero_grad(set_to_none=False)`` must still work — for MIM and V-JEPA.
+* DP: two processes on the one GPU over gloo (RCCL needs one device per rank; the bucket / event / averaging code is the same, the 8-GPU run is
+  the driver's): ``p.grad`` of the real MIM model equals the mean of the two single-process gradients, and ``run_mim.main`` launched the way
+  ``torch.distributed.run`` would (RANK / WORLD_SIZE / MASTER_* in the env) keeps the replicas identical through optimizer steps without a DDP wrap.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+MIM_TINY = dict(image_size=64, num_frames=32, patch_size=16, tubelet_size=16, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                intermediate_size=256, decoder_hidden_size=64, decoder_num_hidden_layers=1, decoder_num_attention_heads=1, decoder_intermediate_size=128)
+VJ_TINY = dict(patch_size=8, crop_size=32, frames_per_clip=8, tubelet_size=2, in_chans=1, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+               mlp_ratio=4.0, pred_hidden_size=64, pred_num_hidden_layers=2, pred_num_attention_heads=2, pred_num_mask_tokens=10, pred_mlp_ratio=4.0)
+
+
+def _mim_model(seed=0):
+    from transformers import VideoMAEConfig
+    from smb_vision_amd.modeling_videomae import SmbVideoMAEForPreTraining
+    torch.manual_seed(seed)
+    return SmbVideoMAEForPreTraining(VideoMAEConfig(num_channels=1, **MIM_TINY)).cuda().train()
+
+
+def _mim_batch(seed):
+    from smb_vision_amd.masking import MaskGenerator
+    np.random.seed(seed)
+    gen = MaskGenerator(64, 32, 16, 16, 0.6)
+    pix = torch.rand(2, 32, 1, 64, 64, generator=torch.Generator().manual_seed(seed)).cuda()
+    return pix, torch.stack([gen(), gen()]).cuda()
+
+
+def _single_grads(model, fn):
+    model.zero_grad(set_to_none=True)
+    fn().backward()
+    torch.cuda.synchronize()
+    return [p.grad.detach().clone() for p in model.parameters()]
+
+
+@pytest.mark.parametrize("set_to_none", [True, False])
+def test_mim_gradient_accumulation_sums_micro_batches(set_to_none):
+    model = _mim_model()
+    b1, b2 = _mim_batch(1), _mim_batch(2)
+    f1 = lambda: model(pixel_values=b1[0], bool_masked_pos=b1[1]).loss * 0.5   # HF divides the loss by the accumulation steps
+    f2 = lambda: model(pixel_values=b2[0], bool_masked_pos=b2[1]).loss * 0.5
+    g1, g2 = _single_grads(model, f1), _single_grads(model, f2)
+    # zero_grad(set_to_none=False) leaves p.grad ALIASING the arena, zeroed; the next backward must not lose what autograd adds to it
+    model.zero_grad(set_to_none=set_to_none)
+    f1().backward()
+    f2().backward()
+    torch.cuda.synchronize()
+    for p, a, b in zip(model.parameters(), g1, g2):
+        assert torch.allclose(p.grad, a + b, rtol=1e-5, atol=1e-9)
+    # and a third round after zero_grad(set_to_none=False): p.grad now are private tensors, the arena views are added into them
+    model.zero_grad(set_to_none=False)
+    f2().backward()
+    torch.cuda.synchronize()
+    for p, b in zip(model.parameters(), g2):
+        assert torch.allclose(p.grad, b, rtol=1e-5, atol=1e-9)
+
+
+def test_vjepa_gradient_accumulation_sums_micro_batches():
+    from transformers import VJEPA2Config
+    from smb_vision_amd.modeling_vjepa import SmbVJEPA2Model
+    torch.manual_seed(0)
+    model = SmbVJEPA2Model(VJEPA2Config(**VJ_TINY)).cuda().train()
+    n = (VJ_TINY["frames_per_clip"] // VJ_TINY["tubelet_size"]) * (VJ_TINY["crop_size"] // VJ_TINY["patch_size"]) ** 2
+
+    def batch(seed):
+        g = torch.Generator().manual_seed(seed)
+        pix = torch.rand(2, VJ_TINY["frames_per_clip"], 1, VJ_TINY["crop_size"], VJ_TINY["crop_size"], generator=g).cuda()
+        perm = torch.randperm(n, generator=g)
+        cm, tm = perm[: n // 2].sort().values, perm[n // 2:].sort().values
+        return pix, cm[None].repeat(2, 1).cuda(), tm[None].repeat(2, 1).cuda()
+
+    def fn(b):
+        return lambda: model(pixel_values_videos=b[0], context_mask=[b[1]], target_mask=[b[2]]).predictor_output.last_hidden_state.square().mean()
+
+    b1, b2 = batch(1), batch(2)
+    g1, g2 = _single_grads(model, fn(b1)), _single_grads(model, fn(b2))
+    for stn in (True, False):
+        model.zero_grad(set_to_none=stn)
+        fn(b1)().backward()
+        fn(b2)().backward()
+        torch.cuda.synchronize()
+        for p, a, b in zip(model.parameters(), g1, g2):
+            assert torch.allclose(p.grad, a + b, rtol=1e-5, atol=1e-9)
+
+
+def test_trainer_with_gradient_accumulation_matches_manual_loop(tmp_path):
+    """SmbTrainer (HF Trainer + fused clip/AdamW) with --gradient_accumulation_steps 2 lands on the same weights as a hand-written loop with
+    torch's clip_grad_norm_ + AdamW over the same four micro-batches."""
+    from transformers import TrainingArguments
+    from smb_vision_amd.run_mim import collate_fn
+    from smb_vision_amd.trainer import SmbTrainer
+    batches = [_mim_batch(s) for s in (1, 2, 3, 4)]
+    data = [{"image": pix[i].cpu(), "mask": m[i].cpu()} for pix, m in batches for i in range(2)]
+    args = TrainingArguments(output_dir=str(tmp_path), per_device_train_batch_size=2, gradient_accumulation_steps=2, max_steps=2, learning_rate=1e-3,
+                             lr_scheduler_type="constant", weight_decay=0.05, max_grad_norm=0.5, report_to="none", save_strategy="no", bf16=True,
+                             dataloader_num_workers=0, remove_unused_columns=False, logging_steps=1, seed=0, adam_beta2=0.95)
+    model = _mim_model(3)
+    start = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    class InOrder(SmbTrainer):
+        def _get_train_sampler(self, *a, **k):
+            return torch.utils.data.SequentialSampler(self.train_dataset)
+
+    tr = InOrder(model=model, args=args, train_dataset=data, data_collator=collate_fn)
+    tr.train()
+    from smb_vision_amd.optim import SmbvAdamW
+    assert isinstance(getattr(tr.optimizer, "optimizer", tr.optimizer), SmbvAdamW)
+    assert any("grad_norm" in h for h in tr.state.log_history)
+
+    ref = _mim_model(3)
+    ref.load_state_dict(start)
+    decay = set(tr.get_decay_parameter_names(ref))
+    opt = torch.optim.AdamW([{"params": [p for n, p in ref.named_parameters() if n in decay], "weight_decay": 0.05},
+                             {"params": [p for n, p in ref.named_parameters() if n not in decay], "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.95), eps=1e-8)
+    for s in range(2):
+        opt.zero_grad(set_to_none=True)
+        for pix, m in batches[2 * s: 2 * s + 2]:
+            (ref(pixel_values=pix, bool_masked_pos=m).loss / 2).backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+        opt.step()
+    for (k, a), (_, b) in zip(model.state_dict().items(), ref.state_dict().items()):
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-6), k
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from smb_vision_amd.dp import DataParallelEngine
+        torch.cuda.set_device(0)
+        model = _mim_model(100 + rank)                   # different initial weights per rank: the broadcast must fix that
+        dp = DataParallelEngine(model, overlap=False)    # gloo: the engine's SUM + scale path; RCCL uses AVG on the side stream
+        dp.broadcast_parameters(model)
+        pix, mask = _mim_batch(10 + rank)                # different data per rank
+        model(pixel_values=pix, bool_masked_pos=mask).loss.backward()
+        torch.cuda.synchronize()
+        q.put((rank, {k: p.grad.detach().cpu() for k, p in model.named_parameters()}, {k: v.detach().cpu() for k, v in model.state_dict().items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mim_dp_param_grads_are_the_mean_of_the_rank_gradients():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in ps), key=lambda t: t[0])
+    for p in ps:
+        p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in ps)
+    (_, ga, wa), (_, gb, wb) = res
+    for k in wa:
+        assert torch.equal(wa[k], wb[k]), k               # rank 0's parameters everywhere
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k               # both ranks hold the same averaged p.grad
+    # single-process gradients of the same two batches with rank 0's weights
+    model = _mim_model(100)
+    model.load_state_dict(wa)
+    singles = []
+    for r in range(2):
+        pix, mask = _mim_batch(10 + r)
+        singles.append(_single_grads(model, lambda: model(pixel_values=pix, bool_masked_pos=mask).loss))
+    for (k, _), a, b in zip(model.named_parameters(), *singles):
+        assert torch.allclose(ga[k].cuda(), 0.5 * (a + b), rtol=1e-5, atol=1e-9), k
+
+
+def test_run_mim_under_a_two_process_launch_keeps_replicas_in_sync(tmp_path):
+    """``smb_vision_amd.run_mim`` (its ``build_trainer`` + ``train``, via tests/dp_worker_mim.py) as torch.distributed.run starts it (2 ranks, gloo, both on the one GPU): no DDP wrap, the engine
+    averages, SmbvAdamW steps; after 3 optimizer steps both ranks hold bit-identical weights that differ from the start."""
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        cmd = [sys.executable, os.path.join(ROOT, "tests", "dp_worker_mim.py"), str(tmp_path / f"state{rank}.pt"), "--output_dir", str(tmp_path / f"out{rank}"), "--image_size", "64", "--depth", "32",
+               "--patch_size", "16", "--mask_patch_size", "16", "--mask_ratio", "0.6", "--max_steps", "3", "--per_device_train_batch_size", "2",
+               "--report_to", "none", "--bf16", "true", "--hidden_size", "128", "--num_hidden_layers", "2", "--num_attention_heads", "2",
+               "--intermediate_size", "256", "--decoder_hidden_size", "64", "--decoder_num_hidden_layers", "1", "--decoder_num_attention_heads", "1",
+               "--decoder_intermediate_size", "128", "--learning_rate", "1e-3", "--logging_steps", "1", "--save_strategy", "no", "--max_grad_norm", "1.0",
+               "--dataloader_num_workers", "0", "--ddp_backend", "gloo", "--seed", "5"]
+        procs.append(subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    s0 = torch.load(tmp_path / "state0.pt", weights_only=True)
+    s1 = torch.load(tmp_path / "state1.pt", weights_only=True)
+    assert s0["meta"]["wrapped"] is False and s0["meta"]["dp_world"] == 2 and s0["meta"]["optimizer"] == "SmbvAdamW"
+    assert s0["meta"]["first_batch_sum"] != s1["meta"]["first_batch_sum"]          # the ranks really saw different shards
+    moved = 0
+    for k in s0["final"]:
+        assert torch.equal(s0["final"][k], s1["final"][k]), k
+        assert torch.equal(s0["initial"][k], s1["initial"][k]), k
+        moved += int(not torch.equal(s0["final"][k], s0["initial"][k]))
+    assert moved > 0.9 * len(s0["final"])
