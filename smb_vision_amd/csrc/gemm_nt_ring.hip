@@ -1,0 +1,218 @@
+// gemm_nt, second generation: 256 x 128 output tile, 8 waves, LDS ring of 32-deep K slices filled by LDS-DMA, counted vmcnt, one raw
+// barrier per slice, epilogue straight from the accumulators with full-line stores.
+//
+// Why: the 128 x 128 x 64 kernel (gemm.hip) moves 64 FLOP per byte it pulls from L2 into LDS and keeps ONE K-step in flight
+// per block - at this model's K = 384..768 it sat at 21 % of the MFMA peak waiting for copies (SQ_WAIT_ANY 0.4-0.5) and spent a third of a
+// tile's life in an LDS-staged epilogue.  Here:
+//   * 256 x 128 tile: 85 FLOP per staged byte; 8 waves as 4 (M) x 2 (N), each 64 x 64 = 4 x 4 v_mfma_f32_16x16x32_bf16 accumulators;
+//   * K in slices of 32 (one MFMA K-step): a slice is [256 + 128 rows][64 B] = 24 KiB = 24 LDS-DMA pieces of 1 KiB, 3 per wave; a ring of
+//     NS slots keeps NS-1 slices in flight; each wave waits for ITS pieces with a counted s_waitcnt vmcnt, one s_barrier publishes the
+//     slice and retires everybody's reads of the previous one, whose slot the next copy then overwrites (issued from asm, hidden from
+//     hipcc's own wait insertion - smbv_common.h); past the end of K the copies run off the buffer and read zeros, so the count stays fixed;
+//   * NS = 3 -> 72 KiB of LDS and <= 128 VGPRs: TWO blocks per CU (16 waves), whose main loops and epilogues overlap each other;
+//   * 64-byte LDS rows, 16-B chunk c of row r stored at chunk c ^ ((-(r >> 2)) & 3): every ds_read_b128 lane group covers all 16 bank
+//     slots; the same involution is applied to the per-lane SOURCE address of the copy (the LDS side of an LDS-DMA is lane-linear);
+//   * the B tile is staged with its rows permuted inside each 64-row group (LDS row 16 j + t holds weight row 4 t + j), which costs nothing
+//     (a per-lane source address) and makes lane t of the four N-direction MFMAs j = 0..3 own four CONSECUTIVE output columns of a row:
+//     every epilogue access (bias, residual / position rows, saved pre-activation, dGELU operand, fp32 and bf16 outputs) is a 16-byte (fp32)
+//     or 8-byte (bf16) per-lane piece of a 256 / 128-byte contiguous row segment - no LDS round trip, no wave barriers.
+// Reference call sites: the nn.Linear calls of src/models/videomae/modeling_videomae.py:261-264, 311-313, 368-370, 384-386, 720-722, 741 and
+// src/models/vjepa/modeling_vjepa.py:251-253, 410-423 (forward and input-gradient products).
+#include "smbv_common.h"
+#include "smbv_kernels.h"
+
+namespace smbv {
+
+static constexpr int RBM = 256, RBN = 128, RBK = 32;
+static constexpr int RSLOT = (RBM + RBN) * RBK * 2;  // 24 KiB
+
+// Four output rows (one register index r each) of one lane: v[r] are columns n .. n+3 of row m[r].  Loads of all four rows are issued
+// before the first use so that they are in flight together; rows past M are clamped for the loads and masked for the stores.
+// EPI: 0 plain (bias / row addend / outputs), 1 + GELU (saving the pre-activation), 2 + dGELU multiplier - compiled separately to bound registers
+template <int EPI>
+__device__ __forceinline__ void epi_rows4(const GemmEpi& e, const int (&m)[4], const int M, const int n, f32x4 (&v)[4], const f32x4 bias) {
+  int mc[4];
+  unsigned orow[4];  // 32-bit element offsets throughout (gemm_nt_ring_ok bounds every operand below 2^30 elements): base pointer in SGPRs + one VGPR
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    mc[r] = min(m[r], M - 1);
+    orow[r] = (unsigned)mc[r];
+    v[r] = v[r] * e.alpha + bias;
+  }
+  if (e.grp_in > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) orow[r] = (unsigned)((mc[r] / e.grp_in) * e.grp_out + (mc[r] % e.grp_in));
+  }
+  if (e.rowadd) {
+    unsigned rr[4];
+    if (e.rowidx) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) rr[r] = (unsigned)e.rowidx[mc[r]];
+    } else if (e.radd_grp_in > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) rr[r] = (unsigned)((mc[r] / e.radd_grp_in) * e.radd_grp_out + mc[r] % e.radd_grp_in + e.radd_off);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; r++) rr[r] = (unsigned)mc[r];
+    }
+    f32x4 a[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) a[r] = *(const f32x4*)(e.rowadd + (rr[r] * (unsigned)e.ldr + (unsigned)n));
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] += a[r];
+  }
+  if constexpr (EPI == 2) {
+    u32x2 p[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) p[r] = *(const u32x2*)(e.dgelu_pre + ((unsigned)mc[r] * (unsigned)e.ld_pre + (unsigned)n));
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      v[r][0] *= gelu_erf_grad(bf_lo(p[r][0])); v[r][1] *= gelu_erf_grad(bf_hi(p[r][0]));
+      v[r][2] *= gelu_erf_grad(bf_lo(p[r][1])); v[r][3] *= gelu_erf_grad(bf_hi(p[r][1]));
+    }
+  }
+  if constexpr (EPI == 1) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (e.aux_pre) {
+        const u32x2 p = {pack_bf16(v[r][0], v[r][1]), pack_bf16(v[r][2], v[r][3])};
+        if (m[r] < M) *(u32x2*)(e.aux_pre + (orow[r] * (unsigned)e.ld_aux + (unsigned)n)) = p;
+        // GELU is applied to the bf16-rounded pre-activation (what autocast's bf16 linear output feeds gelu)
+        v[r][0] = bf_lo(p[0]); v[r][1] = bf_hi(p[0]); v[r][2] = bf_lo(p[1]); v[r][3] = bf_hi(p[1]);
+      }
+      v[r][0] = gelu_erf(v[r][0]); v[r][1] = gelu_erf(v[r][1]); v[r][2] = gelu_erf(v[r][2]); v[r][3] = gelu_erf(v[r][3]);
+    }
+  }
+  if (e.out_f32) {
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      if (m[r] < M) *(f32x4*)(e.out_f32 + (orow[r] * (unsigned)e.ld_of + (unsigned)n)) = v[r];
+  }
+  if (e.out_bf16) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const u32x2 p = {pack_bf16(v[r][0], v[r][1]), pack_bf16(v[r][2], v[r][3])};
+      if (m[r] < M) *(u32x2*)(e.out_bf16 + (orow[r] * (unsigned)e.ld_ob + (unsigned)n)) = p;
+    }
+  }
+}
+
+template <int NS, int EPI>
+__global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_nt_ring_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
+                                                                          int M, int N, int K, int tiles_m, int tiles_n, GemmEpi e_in) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * RSLOT];
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  // bijective XCD remap (blocks b, b+8, ... share an XCD): XCD x owns a contiguous chunk of the tile list, tile_n fastest, so its L2 keeps
+  // an A panel while it sweeps the weight matrix
+  const int nwg = tiles_m * tiles_n, bid = blockIdx.x;
+  const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
+  const int tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+  const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+  const int m0 = tile_m * RBM, n0 = tile_n * RBN;
+  const int nks = K / RBK;
+
+  const i32x4 ra = dma_rsrc(A, (unsigned)(((size_t)(M - 1) * lda + K) * 2));
+  const i32x4 rb = dma_rsrc(B, (unsigned)(((size_t)(N - 1) * ldb + K) * 2));
+  // copy side: piece = 16 LDS rows x 64 B; lane -> (row l >> 2, physical chunk l & 3) holding logical chunk (l & 3) ^ f, f = (-(row >> 2)) & 3
+  const int prow = l >> 2;
+  const int csrc = (l & 3) ^ ((-(l >> 4)) & 3);
+  const int oa0 = ((m0 + 32 * w + prow) * lda + csrc * 8) * 2;             // A rows 32 w .. + 15
+  const int oa1 = oa0 + 16 * lda * 2;                                       //        32 w + 16 .. + 31
+  const int ob0 = ((n0 + 64 * (w >> 2) + 4 * prow + (w & 3)) * ldb + csrc * 8) * 2;  // LDS B row 16 w + prow <- weight row 64 (w >> 2) + 4 prow + (w & 3)
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((int)lds_addr_of(smem));
+  const unsigned la = lds0 + (unsigned)w * 2048, lb = lds0 + RBM * RBK * 2 + (unsigned)w * 1024;
+  auto stage = [&](int s) __attribute__((always_inline)) {
+    const unsigned so = (unsigned)(s % NS) * RSLOT;
+    const int kb = s * (RBK * 2);
+    dma16_hidden(ra, la + so, oa0 + kb);
+    dma16_hidden(ra, la + so + 1024, oa1 + kb);
+    dma16_hidden(rb, lb + so, ob0 + kb);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // read side: lane -> row (l & 15) of a 16-row fragment tile, logical chunk l >> 4
+  const int fr = l & 15;
+  const int pch = ((l >> 4) ^ ((-(fr >> 2)) & 3)) * 16;
+  const int a_off = (64 * wm + fr) * 64 + pch;
+  const int b_off = RBM * RBK * 2 + (64 * wn + fr) * 64 + pch;
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; s++) stage(s);
+  for (int s = 0; s < nks; s++) {
+    // own pieces of slice s have landed (the NS-2 younger slices may still fly); the barrier publishes the slice and tells everybody that
+    // every wave is done reading slice s-1
+    if constexpr (NS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    stage(s + NS - 1);  // into the slot of slice s-1 (beyond K: zeros, never read)
+    const unsigned char* sp = smem + (s % NS) * RSLOT;
+    bf16x8 af[4], bfr[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      af[i] = *(const bf16x8*)(sp + a_off + i * 1024);
+      bfr[i] = *(const bf16x8*)(sp + b_off + i * 1024);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads are retired before this wave can reach the next barrier
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);  // D rows <-> m (4 (l >> 4) + r), cols <-> lane t
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-off copies still target this block's LDS
+
+  // epilogue: register r of acc[i][j] is row 64 wm + 16 i + 4 (l >> 4) + r, column 64 wn + 4 (l & 15) + j
+  const GemmEpi e = e_in;
+  const int n = n0 + 64 * wn + 4 * (l & 15);
+  const int mb = m0 + 64 * wm + 4 * (l >> 4);
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (e.bias) bias = *(const f32x4*)(e.bias + n);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int m[4] = {mb + 16 * i, mb + 16 * i + 1, mb + 16 * i + 2, mb + 16 * i + 3};
+    f32x4 v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = (f32x4){acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+    epi_rows4<EPI>(e, m, M, n, v, bias);
+    __builtin_amdgcn_sched_barrier(0);  // keep the next row group's loads from being hoisted up here (register budget of the 2-blocks-per-CU build)
+  }
+}
+
+bool gemm_nt_ring_ok(int lda, int ldb, int M, int N, int K, const GemmEpi& e) {
+  // the epilogue addresses every operand with 32-bit element offsets
+  const size_t lim = (size_t)1 << 30;
+  const size_t rows_out = e.grp_in > 0 ? (size_t)cdiv(M, e.grp_in) * e.grp_out : (size_t)M;
+  const size_t rows_add = e.radd_grp_in > 0 ? (size_t)cdiv(M, e.radd_grp_in) * e.radd_grp_out + e.radd_off : (size_t)M;
+  if (rows_out * std::max(std::max(e.ld_ob, e.ld_of), e.ld_aux) >= lim || (size_t)M * e.ld_pre >= lim || (e.rowadd && !e.rowidx && rows_add * e.ldr >= lim) ||
+      (e.rowidx && (size_t)e.ldr * (1u << 22) >= ((size_t)1 << 32)))  // indexed rows (position table): at most 4 Mi rows assumed addressable
+    return false;
+  return M >= 128 && (N % RBN) == 0 && (K % RBK) == 0 && ((size_t)M * lda * 2 < (1ull << 31)) && ((size_t)N * ldb * 2 < (1ull << 31)) &&
+         (!e.out_bf16 || ((e.ld_ob & 3) == 0 && ((uintptr_t)e.out_bf16 & 7) == 0)) && (!e.aux_pre || ((e.ld_aux & 3) == 0 && ((uintptr_t)e.aux_pre & 7) == 0)) &&
+         (!e.dgelu_pre || ((e.ld_pre & 3) == 0 && ((uintptr_t)e.dgelu_pre & 7) == 0));
+}
+
+template <int NS>
+static void launch_ring(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, hipStream_t st) {
+  const int tm = cdiv(M, RBM), tn = N / RBN;
+  const dim3 grid(tm * tn), block(512);
+  if (e.act_gelu) hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 1>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e);
+  else if (e.dgelu_pre) hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 2>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e);
+  else hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 0>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e);
+}
+
+int gemm_nt_ring(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, int slots, hipStream_t st) {
+  if (e.act_gelu && e.dgelu_pre) { set_error("gemm_nt_ring: GELU and dGELU epilogues are exclusive"); return SMBV_ERR_ARG; }
+  if (slots == 4) launch_ring<4>(A, lda, B, ldb, M, N, K, e, st);
+  else launch_ring<3>(A, lda, B, ldb, M, N, K, e, st);
+  return check_launch("gemm_nt_ring");
+}
+
+}  // namespace smbv

@@ -28,6 +28,9 @@ struct GemmEpi {
 };
 
 int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, hipStream_t st);
+// second-generation NT kernel (gemm_nt_ring.hip): 256 x 128 tiles, LDS ring of K slices, register epilogue; gemm_nt dispatches to it
+bool gemm_nt_ring_ok(int lda, int ldb, int M, int N, int K, const GemmEpi& e);
+int gemm_nt_ring(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, int slots, hipStream_t st);
 int gemm_tn(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int M, int N1, int N2, float* out, void* ws, size_t ws_bytes, hipStream_t st);
 size_t gemm_tn_workspace_bytes(int M, int N1, int N2);
 

@@ -132,8 +132,12 @@ def test_trainer_with_gradient_accumulation_matches_manual_loop(tmp_path):
             (ref(pixel_values=pix, bool_masked_pos=m).loss / 2).backward()
         torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
         opt.step()
+    # Adam normalises the update, and a 1-ulp difference after step 1 (fused vs torch optimizer arithmetic) flips bf16 roundings in step 2's
+    # forward: compare the two-step UPDATES, per tensor, at 1e-2 of their size (a lost or doubled micro-batch changes them by O(1))
     for (k, a), (_, b) in zip(model.state_dict().items(), ref.state_dict().items()):
-        assert torch.allclose(a, b, rtol=2e-4, atol=2e-6), k
+        upd = float((b - start[k]).norm())
+        assert upd > 0, k
+        assert float((a - b).norm()) <= 1e-2 * upd, (k, float((a - b).norm()), upd)
 
 
 def _free_port():

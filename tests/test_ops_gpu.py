@@ -317,3 +317,38 @@ def test_attention_kernels_are_run_to_run_identical(ops):
         assert torch.equal(O, O0) and torch.equal(lse, lse0)
         d, _ = ops.attention_bwd(qkv, O0, dO, lse0, B, S, H)
         assert torch.equal(d, d0)
+
+
+@pytest.mark.parametrize("M,N,K", [(7168, 2304, 768), (1000, 1152, 384), (20480, 384, 1536), (257, 128, 32), (4096, 4096, 96)])
+def test_gemm_nt_ring_kernel_matches_reference_and_first_generation(ops, M, N, K):
+    """gemm_nt_ring_kernel (256 x 128 tiles, LDS ring of 32-deep K slices, weight rows permuted in LDS so that the register epilogue writes whole
+    lines): every epilogue kind against fp32 PyTorch, and - same MFMA shape, same K order - bit for bit against the 128 x 128 kernel."""
+    import ctypes
+    from smb_vision_amd import _lib
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    A = rnd(M, K, seed=1).bfloat16()
+    B = rnd(N, K, seed=2, scale=0.05).bfloat16()
+    bias = rnd(N, seed=3)
+    resid = rnd(M, N, seed=4)
+    pre_b = rnd(M, N, seed=7).bfloat16()
+    ref = A.float() @ B.float().t()
+    runs = {}
+    for v in (0, 256, 512):       # ring with 3 slots (two blocks per CU), first generation, ring with 4 slots
+        raw.smbv_set_variant(v)
+        try:
+            runs[v] = (ops.gemm_nt(A, B, bias=bias, rowadd=resid, out_bf16=True, out_f32=True), ops.gemm_nt(A, B, bias=bias, gelu=True, save_pre=True),
+                       ops.gemm_nt(A, B, dgelu_pre=pre_b), ops.gemm_nt(A, B, out_bf16=False, out_f32=True, alpha=0.5))
+        finally:
+            raw.smbv_set_variant(0)
+    r0, r1, r2, r3 = runs[0]
+    assert rel_err(r0["f32"], ref + bias + resid) < 1e-5 * math.sqrt(K) + 1e-5
+    assert rel_err(r1["pre"], ref + bias) < 6e-3
+    assert rel_err(r1["bf16"], torch.nn.functional.gelu(r1["pre"].float())) < 6e-3
+    x = pre_b.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    assert rel_err(r2["bf16"], ref * x.grad) < 8e-3
+    assert rel_err(r3["f32"], 0.5 * ref) < 1e-5 * math.sqrt(K) + 1e-5
+    for v in (256, 512):
+        for a, b in zip(runs[0], runs[v]):
+            for k in a:
+                assert torch.equal(a[k], b[k]), (v, k)
