@@ -249,6 +249,9 @@ typedef struct smbv_vjepa_cfg {
   int d, heads, ff, layers;        /* encoder: hidden_size, num_attention_heads, hidden_size*mlp_ratio, num_hidden_layers */
   int pd, pheads, pff, players;    /* predictor: pred_hidden_size, pred_num_attention_heads, ..., pred_num_hidden_layers */
   float ln_eps;                    /* config.layer_norm_eps (1e-6) */
+  int n_masks;                     /* number of (context, target) mask pairs in the lists handed to VJEPA2Model.forward (0 or 1 = one pair).  apply_masks
+                                      (modeling_vjepa.py:542-556) concatenates them along the batch: the predictor runs on P = n_masks * B sequences, sequence
+                                      m * B + b pairing volume b with mask pair m; every per-sequence array below then has P rows instead of B */
 } smbv_vjepa_cfg;
 
 /* fp32 tensors of one VJEPA2Layer: norm1, attention.{query,key,value,proj}.{weight,bias}, norm2, mlp.{fc1,fc2} */
@@ -270,16 +273,16 @@ typedef struct smbv_vjepa_tensors {
 typedef struct smbv_vjepa_io {
   const float* pixel_values;       /* fp32 [B,T,1,H,W] */
   const int32_t* all_idx;          /* int32 [B,N] = 0..N-1 per volume (brick ids) */
-  const int32_t* ctx_idx;          /* int32 [B,Nctx] context token ids */
-  const int32_t* tgt_idx;          /* int32 [B,Ntgt] target token ids */
-  const int32_t* pred_pos;         /* int32 [B,Nctx+Ntgt] position ids of the predictor sequence, sorted (modeling_vjepa.py:718-719) */
-  const int32_t* ctx_slot;         /* int32 [B,Nctx] row of each context token in the sorted predictor sequence */
-  const int32_t* tgt_slot;         /* int32 [B,Ntgt] row of each target token in the sorted predictor sequence */
+  const int32_t* ctx_idx;          /* int32 [P,Nctx] ROW of enc_out ([B*N] rows) each context token comes from: b * N + token id; distinct within a sequence */
+  const int32_t* tgt_idx;          /* int32 [P,Ntgt] target token ids (not read by the library: the caller's target_hidden_state gather uses them) */
+  const int32_t* pred_pos;         /* int32 [P,Nctx+Ntgt] position ids of the predictor sequence, sorted (modeling_vjepa.py:718-719) */
+  const int32_t* ctx_slot;         /* int32 [P,Nctx] row of each context token in the sorted predictor sequence */
+  const int32_t* tgt_slot;         /* int32 [P,Ntgt] row of each target token in the sorted predictor sequence */
   const float* rope_enc;           /* fp32 [P][2][seg/2] cos|sin table for the encoder head_dim (see smbv_rope3d) */
   const float* rope_pred;          /* same for the predictor head_dim */
   float* enc_out;                  /* out: fp32 [B*N, d] last_hidden_state (after encoder.layernorm) */
-  float* pred_out;                 /* out: fp32 [B*Ntgt, d] predictor_output.last_hidden_state (NULL: encoder only = skip_predictor) */
-  const float* d_pred;             /* backward: fp32 [B*Ntgt, d] gradient w.r.t. pred_out */
+  float* pred_out;                 /* out: fp32 [P*Ntgt, d] predictor_output.last_hidden_state (NULL: encoder only = skip_predictor) */
+  const float* d_pred;             /* backward: fp32 [P*Ntgt, d] gradient w.r.t. pred_out */
 } smbv_vjepa_io;
 
 size_t smbv_vjepa_workspace_bytes(const smbv_vjepa_cfg* cfg);

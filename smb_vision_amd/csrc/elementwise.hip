@@ -45,18 +45,25 @@ int transpose_cast_f32_bf16(const float* src, bf16_t* dst, int R, int C, int ldd
   return check_launch("transpose_cast");
 }
 
-// All per-step weight preparation in ONE launch: a device-resident job table (built by the host sequencer) lists, per fp32 master
-// tensor, a bf16 cast (optionally transposed, with a destination leading dimension), an fp32 copy or a zero fill; a block handles
-// one 32x32 tile of one job (binary search over the jobs' first-tile prefix).  Replaces ~200 tiny cast/transpose/copy launches.
-__global__ __launch_bounds__(256) void prep_weights_kernel(const PrepJob* __restrict__ jobs, int njobs) {
+// All per-step weight preparation in a handful of launches: the host sequencer lists, per fp32 master tensor, a bf16 cast (optionally
+// transposed, with a destination leading dimension), an fp32 copy or a zero fill; the list travels BY VALUE in the kernel arguments,
+// 64 jobs (2.5 KiB) per launch - no device-resident table, no host-to-device copy (a pageable hipMemcpyAsync would block the caller
+// behind everything queued on the stream), no state; a block handles one 32x32 tile of one job (binary search over the first-tile
+// prefix).  Replaces ~200 tiny cast / transpose / copy launches by ~5.
+struct PrepBatch {
+  PrepJob jobs[64];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void prep_weights_kernel(const PrepBatch batch) {
   __shared__ float tile[32][33];
-  int lo = 0, hi = njobs - 1;
+  int lo = 0, hi = batch.n - 1;
   const int b = blockIdx.x;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (jobs[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+    if (batch.jobs[mid].tile0 <= b) lo = mid; else hi = mid - 1;
   }
-  const PrepJob j = jobs[lo];
+  const PrepJob j = batch.jobs[lo];
   const int tl = b - j.tile0;
   const int tiles_c = (j.C + 31) >> 5;
   const int r0 = (tl / tiles_c) * 32, c0 = (tl % tiles_c) * 32;
@@ -84,10 +91,24 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const PrepJob* __rest
   }
 }
 
-int prep_weights(const PrepJob* jobs_dev, int njobs, int total_tiles, hipStream_t st) {
-  if (njobs <= 0 || total_tiles <= 0) return SMBV_OK;
-  hipLaunchKernelGGL(prep_weights_kernel, dim3(total_tiles), dim3(256), 0, st, jobs_dev, njobs);
-  return check_launch("prep_weights");
+int prep_weights(const PrepJob* jobs, int njobs, hipStream_t st) {
+  for (int j0 = 0; j0 < njobs; j0 += 64) {
+    PrepBatch b;
+    b.n = std::min(64, njobs - j0);
+    const int base = jobs[j0].tile0;
+    int tiles = 0;
+    for (int i = 0; i < b.n; i++) {
+      b.jobs[i] = jobs[j0 + i];
+      b.jobs[i].tile0 -= base;
+      tiles = b.jobs[i].tile0 + cdiv(b.jobs[i].R, 32) * cdiv(b.jobs[i].C, 32);
+    }
+    for (int i = b.n; i < 64; i++) b.jobs[i] = b.jobs[b.n - 1];
+    if (tiles <= 0) continue;
+    hipLaunchKernelGGL(prep_weights_kernel, dim3(tiles), dim3(256), 0, st, b);
+    int rc = check_launch("prep_weights");
+    if (rc) return rc;
+  }
+  return SMBV_OK;
 }
 
 // decoder input, masked part (src/models/videomae/modeling_videomae.py:811-815): x_full[b, Nvis + i, :] = mask_token + pos[mask_idx[b,i], :]

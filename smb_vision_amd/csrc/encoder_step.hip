@@ -18,8 +18,7 @@ struct EncWs {
   float *g0, *g1;                 // train: gradient ping-pong (fp32 + bf16 copies)
   bf16_t *gb0, *gb1;
   BwdScratch sc;
-  PrepJob* prep_table;
-  size_t prep_cap, total;
+  size_t total;
 };
 
 static BlockDims edims(const smbv_encoder_cfg& c) {
@@ -42,8 +41,6 @@ static void carve(const smbv_encoder_cfg& c, void* base, EncWs& w) {
   const int K = c.ts * c.ps * c.ps;
   const size_t R = (size_t)c.B * c.Nsel;
   const BlockDims de = edims(c);
-  w.prep_cap = 8 + (size_t)c.layers * layer_prep_job_count(de);
-  w.prep_table = cv.take<PrepJob>(w.prep_cap);
   w.pe_w = cv.take<bf16_t>((size_t)c.d * K);
   if (c.train) {
     for (int l = 0; l < c.layers; l++) carve_layer(cv, w.L[l], de);
@@ -122,9 +119,7 @@ static int encoder_forward(const smbv_encoder_cfg& c, const smbv_encoder_tensors
     PrepList pl;
     pl.cast(p.pe_w, W.pe_w, c.d, K);
     for (int l = 0; l < c.layers; l++) RC(prep_layer(pl, blk(l), W.L[l], de, st));
-    if (pl.jobs.size() > W.prep_cap) { set_error("encoder_forward: prep table overflow"); return SMBV_ERR_WORKSPACE; }
-    HIPRC(hipMemcpyAsync(W.prep_table, pl.jobs.data(), pl.jobs.size() * sizeof(PrepJob), hipMemcpyHostToDevice, st));
-    RC(prep_weights(W.prep_table, (int)pl.jobs.size(), pl.tiles, st));
+    RC(prep_weights(pl.jobs.data(), (int)pl.jobs.size(), st));
   }
   RC(gather_bricks(io.pixel_values, io.sel_idx, (int)R, c.Nsel, W.a_patch, c.T, c.H, c.W, c.ts, c.ps, st));
   float* xin = W.x0;

@@ -99,7 +99,7 @@ __device__ __forceinline__ void epi_rows4(const GemmEpi& e, const int (&m)[4], c
 
 template <int NS, int EPI>
 __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_nt_ring_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
-                                                                          int M, int N, int K, int tiles_m, int tiles_n, GemmEpi e_in) {
+                                                                          int M, int N, int K, int tiles_m, int tiles_n, GemmEpi e_in, int dbg) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * RSLOT];
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -151,24 +151,38 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_nt_ring_kernel(cons
     if constexpr (NS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    stage(s + NS - 1);  // into the slot of slice s-1 (beyond K: zeros, never read)
+    if (!(dbg & 2)) stage(s + NS - 1);  // into the slot of slice s-1 (beyond K: zeros, never read)
     const unsigned char* sp = smem + (s % NS) * RSLOT;
     bf16x8 af[4], bfr[4];
+    if (!(dbg & 8)) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      af[i] = *(const bf16x8*)(sp + a_off + i * 1024);
-      bfr[i] = *(const bf16x8*)(sp + b_off + i * 1024);
+      for (int i = 0; i < 4; i++) {
+        af[i] = *(const bf16x8*)(sp + a_off + i * 1024);
+        bfr[i] = *(const bf16x8*)(sp + b_off + i * 1024);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) { af[i] = __builtin_bit_cast(bf16x8, (u32x4){(unsigned)s, 1u, 2u, 3u}); bfr[i] = af[i]; }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads are retired before this wave can reach the next barrier
     __builtin_amdgcn_sched_barrier(0);
+    if (!(dbg & 4)) {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+      for (int i = 0; i < 4; i++)
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);  // D rows <-> m (4 (l >> 4) + r), cols <-> lane t
+        for (int j = 0; j < 4; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);  // D rows <-> m (4 (l >> 4) + r), cols <-> lane t
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) asm volatile("" ::"v"(af[i]), "v"(bfr[i]));
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-off copies still target this block's LDS
 
+  if (dbg & 1) {  // ablation: no epilogue traffic
+    if (acc[0][0][0] == 1234.5f) e_in.out_f32[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3];
+    return;
+  }
   // epilogue: register r of acc[i][j] is row 64 wm + 16 i + 4 (l >> 4) + r, column 64 wn + 4 (l & 15) + j
   const GemmEpi e = e_in;
   const int n = n0 + 64 * wn + 4 * (l & 15);
@@ -200,18 +214,18 @@ bool gemm_nt_ring_ok(int lda, int ldb, int M, int N, int K, const GemmEpi& e) {
 }
 
 template <int NS>
-static void launch_ring(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, hipStream_t st) {
+static void launch_ring(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, int dbg, hipStream_t st) {
   const int tm = cdiv(M, RBM), tn = N / RBN;
   const dim3 grid(tm * tn), block(512);
-  if (e.act_gelu) hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 1>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e);
-  else if (e.dgelu_pre) hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 2>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e);
-  else hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 0>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e);
+  if (e.act_gelu) hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 1>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg);
+  else if (e.dgelu_pre) hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 2>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg);
+  else hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 0>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg);
 }
 
-int gemm_nt_ring(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, int slots, hipStream_t st) {
+int gemm_nt_ring(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, int slots, hipStream_t st, int dbg) {
   if (e.act_gelu && e.dgelu_pre) { set_error("gemm_nt_ring: GELU and dGELU epilogues are exclusive"); return SMBV_ERR_ARG; }
-  if (slots == 4) launch_ring<4>(A, lda, B, ldb, M, N, K, e, st);
-  else launch_ring<3>(A, lda, B, ldb, M, N, K, e, st);
+  if (slots == 4) launch_ring<4>(A, lda, B, ldb, M, N, K, e, dbg, st);
+  else launch_ring<3>(A, lda, B, ldb, M, N, K, e, dbg, st);
   return check_launch("gemm_nt_ring");
 }
 

@@ -22,8 +22,6 @@ struct MimWs {
   float *g0, *g1;
   bf16_t *gb0, *gb1, *dlogits, *d_vis;
   BwdScratch sc;        // block-backward scratch (d_act, d_ln, d_o, d_qkv, gathers, delta, reduction scratch)
-  PrepJob* prep_table;  // device copy of the weight-preparation job list (uploaded by every forward)
-  size_t prep_cap;
   size_t total;
 };
 
@@ -57,8 +55,6 @@ static void carve(const smbv_mim_cfg& c, void* base, MimWs& w) {
   const int K = c.ts * c.ps * c.ps;
   const size_t R = (size_t)c.B * c.Nvis, Rd = (size_t)c.B * c.N, Rm = (size_t)c.B * c.Nmask;
   const BlockDims de = enc_dims(c), dd = dec_dims(c);
-  w.prep_cap = 16 + (size_t)c.layers * layer_prep_job_count(de) + (size_t)c.dlayers * layer_prep_job_count(dd);
-  w.prep_table = cv.take<PrepJob>(w.prep_cap);
   w.pe_w = cv.take<bf16_t>((size_t)c.d * K);
   w.e2d = cv.take<bf16_t>((size_t)c.dd * c.d);
   w.e2d_t = cv.take<bf16_t>((size_t)c.dd * c.d);
@@ -125,10 +121,7 @@ static int mim_forward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const s
     pl.tcast(p.head_w, W.head_t, K, c.dd, K);
     for (int l = 0; l < c.layers; l++) RC(prep_layer(pl, to_block(p.enc[l]), W.enc[l], de, st));
     for (int l = 0; l < c.dlayers; l++) RC(prep_layer(pl, to_block(p.dec[l]), W.dec[l], dd, st));
-    if (pl.jobs.size() > W.prep_cap) { set_error("mim_forward: prep table overflow"); return SMBV_ERR_WORKSPACE; }
-    // pageable-source H2D: HIP stages the bytes before returning, so the vector may die at the end of this scope
-    HIPRC(hipMemcpyAsync(W.prep_table, pl.jobs.data(), pl.jobs.size() * sizeof(PrepJob), hipMemcpyHostToDevice, st));
-    RC(prep_weights(W.prep_table, (int)pl.jobs.size(), pl.tiles, st));
+    RC(prep_weights(pl.jobs.data(), (int)pl.jobs.size(), st));
   }
 
   // patch embedding of the visible bricks + bias + sin-cos rows (spec :124-139, :179-192)

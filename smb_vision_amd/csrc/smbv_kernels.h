@@ -30,7 +30,7 @@ struct GemmEpi {
 int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, hipStream_t st);
 // second-generation NT kernel (gemm_nt_ring.hip): 256 x 128 tiles, LDS ring of K slices, register epilogue; gemm_nt dispatches to it
 bool gemm_nt_ring_ok(int lda, int ldb, int M, int N, int K, const GemmEpi& e);
-int gemm_nt_ring(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, int slots, hipStream_t st);
+int gemm_nt_ring(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, int slots, hipStream_t st, int dbg = 0);
 int gemm_tn(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int M, int N1, int N2, float* out, void* ws, size_t ws_bytes, hipStream_t st);
 size_t gemm_tn_workspace_bytes(int M, int N1, int N2);
 
@@ -64,7 +64,7 @@ struct PrepJob {
   int tile0;  // first block of this job
   int lds;    // source leading dimension (elements)
 };
-int prep_weights(const PrepJob* jobs_dev, int njobs, int total_tiles, hipStream_t st);
+int prep_weights(const PrepJob* jobs_host, int njobs, hipStream_t st);  // jobs travel in the kernel arguments, 64 per launch
 int cast_f32_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st);
 int transpose_cast_f32_bf16(const float* src, bf16_t* dst, int R, int C, int ldd, hipStream_t st);
 int fill_mask_rows(float* xfull, const float* mask_token, const float* pos, const int* mask_idx, int B, int nmask, int nvis, int D, hipStream_t st);
@@ -78,6 +78,7 @@ int rope3d(bf16_t* qkv, int ld, int k_off, long rows, int S, int H, int hs, int 
            hipStream_t st);
 int gather_rows_idx_bf16(const bf16_t* src, bf16_t* dst, const int* idx, long nidx, int per_batch, long src_batch_rows, int D, hipStream_t st);
 int scatter_rows_idx_bf16(const bf16_t* src, bf16_t* dst, const int* idx, long nidx, int per_batch, long dst_batch_rows, int D, hipStream_t st);
+int scatter_add_rows_idx_bf16(const bf16_t* src, bf16_t* dst, const int* idx, long nidx, int D, hipStream_t st);  // dst[idx[r]] += src[r], idx = absolute rows
 int gather_rows_idx_f32(const float* src, float* dst, const int* idx, long nidx, int per_batch, long src_batch_rows, int D, hipStream_t st);
 int scatter_rows_idx_f32(const float* src, float* dst, const int* idx, long nidx, int per_batch, long dst_batch_rows, int D, hipStream_t st);
 int fill_rows_idx_f32(float* dst, const float* vec, const int* idx, long nidx, int per_batch, long dst_batch_rows, int D, hipStream_t st);

@@ -68,6 +68,26 @@ __global__ void rows_idx_kernel(const T* __restrict__ src, T* __restrict__ dst, 
   for (int c = threadIdx.x; c < D16; c += blockDim.x) d[c] = s[c];
 }
 
+// dst row idx[r] += src row r, bf16 (one row per block, rows distinct within a launch: plain read-modify-write, reproducible)
+__global__ void rows_idx_add_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, const int* __restrict__ idx, int D8) {
+  const long r = blockIdx.x;
+  const u32x4* s = (const u32x4*)(src + r * (size_t)D8 * 8);
+  u32x4* d = (u32x4*)(dst + (size_t)idx[r] * D8 * 8);
+  for (int c = threadIdx.x; c < D8; c += blockDim.x) {
+    const u32x4 a = s[c], b = d[c];
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) o[e] = pack_bf16(bf_lo(a[e]) + bf_lo(b[e]), bf_hi(a[e]) + bf_hi(b[e]));
+    d[c] = o;
+  }
+}
+
+int scatter_add_rows_idx_bf16(const bf16_t* src, bf16_t* dst, const int* idx, long nidx, int D, hipStream_t st) {
+  if (nidx <= 0 || (D & 7) || (((uintptr_t)src | (uintptr_t)dst) & 15)) { set_error("scatter_add_rows_idx_bf16: bad shape/alignment"); return SMBV_ERR_SHAPE; }
+  hipLaunchKernelGGL(rows_idx_add_bf16_kernel, dim3(nidx), dim3(64), 0, st, src, dst, idx, D / 8);
+  return check_launch("rows_idx_add");
+}
+
 template <typename T>
 static int rows_idx(const T* src, T* dst, const int* idx, long nidx, int per_batch, long src_batch_rows, long dst_batch_rows, int D, int scatter,
                     hipStream_t st) {

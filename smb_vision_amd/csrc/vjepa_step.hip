@@ -13,8 +13,6 @@
 namespace smbv {
 
 struct VjepaWs {
-  PrepJob* prep_table;
-  size_t prep_cap;
   bf16_t *pe_w, *pemb, *pemb_t, *pproj, *pproj_t;
   LayerWs enc[SMBV_MAX_LAYERS], pred[SMBV_MAX_LAYERS];
   bf16_t* a_patch;
@@ -34,9 +32,11 @@ static BlockDims venc_dims(const smbv_vjepa_cfg& c, const smbv_vjepa_io* io) {
   d.rope_grid = c.W / c.ps; d.pos = nullptr; d.rope_table = io ? io->rope_enc : nullptr;
   return d;
 }
+static inline int vmasks(const smbv_vjepa_cfg& c) { return c.n_masks > 1 ? c.n_masks : 1; }
+static inline int vpb(const smbv_vjepa_cfg& c) { return c.B * vmasks(c); }  // predictor sequences: mask pair m, volume b -> m * B + b
 static BlockDims vpred_dims(const smbv_vjepa_cfg& c, const smbv_vjepa_io* io) {
   const int Sp = c.Nctx + c.Ntgt;
-  BlockDims d; d.rows = (size_t)c.B * Sp; d.w = c.pd; d.ff = c.pff; d.B = c.B; d.S = Sp; d.H = c.pheads; d.Dh = c.pd / c.pheads; d.eps = c.ln_eps;
+  BlockDims d; d.rows = (size_t)vpb(c) * Sp; d.w = c.pd; d.ff = c.pff; d.B = vpb(c); d.S = Sp; d.H = c.pheads; d.Dh = c.pd / c.pheads; d.eps = c.ln_eps;
   d.rope_grid = c.W / c.ps; d.pos = io ? io->pred_pos : nullptr; d.rope_table = io ? io->rope_pred : nullptr;
   return d;
 }
@@ -48,6 +48,7 @@ static BlockPtrs vblock(const smbv_block_ptrs& p) {
 }
 
 static int vcheck(const smbv_vjepa_cfg& c) {
+  if (c.n_masks < 0 || c.n_masks > 64) { set_error("vjepa: n_masks %d out of range", c.n_masks); return SMBV_ERR_SHAPE; }
   if (c.B <= 0 || c.layers <= 0 || c.players < 0 || c.layers > SMBV_MAX_LAYERS || c.players > SMBV_MAX_LAYERS) { set_error("vjepa: bad batch/layer counts"); return SMBV_ERR_SHAPE; }
   if (c.ps <= 0 || c.ts <= 0 || c.T % c.ts || c.H % c.ps || c.W % c.ps || (c.ps & 3) || c.H != c.W) { set_error("vjepa: volume %dx%dx%d vs tubelet %d / patch %d (square crops only)", c.T, c.H, c.W, c.ts, c.ps); return SMBV_ERR_SHAPE; }
   const int N = (c.T / c.ts) * (c.H / c.ps) * (c.W / c.ps);
@@ -63,9 +64,7 @@ static void vcarve(const smbv_vjepa_cfg& c, void* base, VjepaWs& w) {
   Carver cv{(char*)base};
   const int K = c.ts * c.ps * c.ps;
   const BlockDims de = venc_dims(c, nullptr), dp = vpred_dims(c, nullptr);
-  const size_t Re = de.rows, Rp = dp.rows, Rc = (size_t)c.B * c.Nctx, Rt = (size_t)c.B * c.Ntgt;
-  w.prep_cap = 16 + (size_t)c.layers * layer_prep_job_count(de) + (size_t)c.players * layer_prep_job_count(dp);
-  w.prep_table = cv.take<PrepJob>(w.prep_cap);
+  const size_t Re = de.rows, Rp = dp.rows, Rc = (size_t)vpb(c) * c.Nctx, Rt = (size_t)vpb(c) * c.Ntgt;
   w.pe_w = cv.take<bf16_t>((size_t)c.d * K);
   w.pemb = cv.take<bf16_t>((size_t)c.pd * c.d);
   w.pemb_t = cv.take<bf16_t>((size_t)c.pd * c.d);
@@ -125,7 +124,7 @@ static int vjepa_forward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, c
   if (with_pred && (!io.ctx_idx || !io.tgt_idx || !io.pred_pos || !io.ctx_slot || !io.tgt_slot || !io.rope_pred || c.players <= 0)) { set_error("vjepa_forward: predictor inputs missing"); return SMBV_ERR_ARG; }
   const int K = c.ts * c.ps * c.ps;
   const BlockDims de = venc_dims(c, &io), dp = vpred_dims(c, &io);
-  const size_t Re = de.rows, Rp = dp.rows, Rc = (size_t)c.B * c.Nctx, Rt = (size_t)c.B * c.Ntgt;
+  const size_t Re = de.rows, Rp = dp.rows, Rc = (size_t)vpb(c) * c.Nctx, Rt = (size_t)vpb(c) * c.Ntgt;
   const int Sp = c.Nctx + c.Ntgt;
   {
     PrepList pl;
@@ -138,9 +137,7 @@ static int vjepa_forward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, c
       pl.tcast(p.pproj_w, W.pproj_t, c.d, c.pd, c.d);
       for (int l = 0; l < c.players; l++) RC(prep_layer(pl, vblock(p.pred[l]), W.pred[l], dp, st));
     }
-    if (pl.jobs.size() > W.prep_cap) { set_error("vjepa_forward: prep table overflow"); return SMBV_ERR_WORKSPACE; }
-    HIPRC(hipMemcpyAsync(W.prep_table, pl.jobs.data(), pl.jobs.size() * sizeof(PrepJob), hipMemcpyHostToDevice, st));
-    RC(prep_weights(W.prep_table, (int)pl.jobs.size(), pl.tiles, st));
+    RC(prep_weights(pl.jobs.data(), (int)pl.jobs.size(), st));
   }
   // encoder over all N tokens: Conv3d patch embedding (+bias, no position table: RoPE instead), L blocks, final LayerNorm
   RC(gather_bricks(io.pixel_values, io.all_idx, (int)Re, c.N, W.a_patch, c.T, c.H, c.W, c.ts, c.ps, st));
@@ -152,7 +149,7 @@ static int vjepa_forward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, c
   RC(layernorm_fwd(W.x[c.layers], p.enc_ln_w, p.enc_ln_b, W.enc_ln, W.enc_mean, W.enc_rstd, (int)Re, c.d, c.ln_eps, 0, 0, 0, st, io.enc_out));
   if (!with_pred) return SMBV_OK;
   // predictor: context rows -> Linear(d -> pd) -> their slots of the position-sorted sequence; target slots <- mask token
-  RC(gather_rows_idx_bf16(W.enc_ln, W.ctx_bf, io.ctx_idx, (long)Rc, c.Nctx, c.N, c.d, st));
+  RC(gather_rows_idx_bf16(W.enc_ln, W.ctx_bf, io.ctx_idx, (long)Rc, (int)Rc, 0, c.d, st));  // ctx_idx holds absolute rows of enc_out
   {
     GemmEpi e; e.bias = p.pemb_b; e.out_f32 = W.ctx_emb; e.ld_of = c.pd;
     RC(gemm_nt(W.ctx_bf, c.d, W.pemb, c.d, (int)Rc, c.pd, c.d, e, st));
@@ -187,7 +184,7 @@ static int vjepa_backward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, 
   if (!io.d_pred || !io.tgt_slot || !io.ctx_slot || !io.ctx_idx) { set_error("vjepa_backward: null io pointer"); return SMBV_ERR_ARG; }
   const int K = c.ts * c.ps * c.ps;
   const BlockDims de = venc_dims(c, &io), dp = vpred_dims(c, &io);
-  const size_t Re = de.rows, Rp = dp.rows, Rc = (size_t)c.B * c.Nctx, Rt = (size_t)c.B * c.Ntgt;
+  const size_t Re = de.rows, Rp = dp.rows, Rc = (size_t)vpb(c) * c.Nctx, Rt = (size_t)vpb(c) * c.Ntgt;
   const int Sp = c.Nctx + c.Ntgt;
   // predictor.proj
   RC(cast_f32_bf16(io.d_pred, W.dpred_bf, Rt * c.d, st));
@@ -220,7 +217,13 @@ static int vjepa_backward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, 
   RC(mark());  // [players+1] mask tokens + predictor_embeddings
   // encoder.layernorm: only the context tokens receive gradient
   HIPRC(hipMemsetAsync(W.d_lnfull, 0, Re * c.d * sizeof(bf16_t), st));
-  RC(scatter_rows_idx_bf16(W.d_encctx, W.d_lnfull, io.ctx_idx, (long)Rc, c.Nctx, c.N, c.d, st));
+  // mask pair 0 scatters, the others add on top (apply_masks' autograd sums the pairs that read the same encoder row); rows are distinct
+  // inside a pair, the launches are stream-ordered: no atomics, reproducible
+  {
+    const long per = (long)c.B * c.Nctx;
+    RC(scatter_rows_idx_bf16(W.d_encctx, W.d_lnfull, io.ctx_idx, per, (int)per, 0, c.d, st));
+    for (int m = 1; m < vmasks(c); m++) RC(scatter_add_rows_idx_bf16(W.d_encctx + (size_t)m * per * c.d, W.d_lnfull, io.ctx_idx + (size_t)m * per, per, c.d, st));
+  }
   RC(layernorm_bwd(W.d_lnfull, W.x[c.layers], W.enc_mean, W.enc_rstd, p.enc_ln_w, nullptr, W.g0, W.gb0, gr.enc_ln_w, gr.enc_ln_b, (int)Re, c.d, 0, 0, 0,
                    W.sc.scratch, W.sc.scratch_bytes, st));
   RC(mark());  // [players+2] encoder.layernorm

@@ -75,6 +75,22 @@ def split_mask_indices(bool_masked_pos: torch.Tensor, num_masked: int):
     return order[:, :n_vis].to(torch.int32).contiguous(), order[:, n_vis:].to(torch.int32).contiguous()
 
 
+def split_mask_indices_host(bool_masked_pos) -> "tuple[torch.Tensor, torch.Tensor]":
+    """The same two ascending index lists, built on the HOST from the mask the data pipeline just generated (a CPU bool tensor / numpy array
+    [B,N]): two ``flatnonzero`` calls per sample instead of a device sort per step.  Returns CPU int32 tensors ``(vis_idx [B,N-M], mask_idx [B,M])``;
+    raises if the samples mask different numbers of tokens (reference: ``embeddings[~mask].reshape(B, -1, C)`` would fail the same way)."""
+    m = bool_masked_pos.numpy() if torch.is_tensor(bool_masked_pos) else np.asarray(bool_masked_pos)
+    m = m.astype(bool, copy=False)
+    if m.ndim == 1:
+        m = m[None]
+    counts = m.sum(axis=1)
+    if (counts != counts[0]).any():
+        raise ValueError("bool_masked_pos: all samples in a batch must mask the same number of tokens")
+    vis = np.stack([np.flatnonzero(~r) for r in m]).astype(np.int32)
+    msk = np.stack([np.flatnonzero(r) for r in m]).astype(np.int32)
+    return torch.from_numpy(vis), torch.from_numpy(msk)
+
+
 class VJEPAMaskGenerator:
     """Context / target index masks for V-JEPA (reference ``src/dataloader/transforms.py:96-217``, default flags): same constructor
     arguments, same draws (the per-call seed and the block origins from the GLOBAL torch RNG, scale and aspect ratio from a local

@@ -405,7 +405,11 @@ class SmbVideoMAEForPreTraining(PreTrainedModel):
         return self.grad_views()
 
     def forward(self, pixel_values: torch.Tensor, bool_masked_pos: torch.Tensor, head_mask=None, output_attentions=None,
-                output_hidden_states=None, return_dict=None, num_masked: Optional[int] = None, **kwargs):
+                output_hidden_states=None, return_dict=None, num_masked: Optional[int] = None, visible_index: Optional[torch.Tensor] = None,
+                masked_index: Optional[torch.Tensor] = None, **kwargs):
+        """``VideoMAEForPreTraining.forward`` (spec :753-908).  ``visible_index`` / ``masked_index`` (optional, int32 [B, N-M] / [B, M], ascending - what
+        ``masking.split_mask_indices_host`` builds in the collate function from the mask it just generated) spare the per-step device sort that
+        otherwise derives them from ``bool_masked_pos``; they MUST describe the same partition."""
         if output_attentions or output_hidden_states:
             raise NotImplementedError("smb_vision_amd: attention maps / hidden states are never materialised by the fused HIP path")
         if pixel_values.dim() != 5:
@@ -429,8 +433,15 @@ class SmbVideoMAEForPreTraining(PreTrainedModel):
             if bool_masked_pos.shape != (B, self.num_patches):
                 raise ValueError(f"bool_masked_pos must be [{B}, {self.num_patches}], got {tuple(bool_masked_pos.shape)}")
             params = self._ensure_device_state(dev)
-            n_masked = self._token_split(bool_masked_pos, num_masked)
-            vis_idx, mask_idx = split_mask_indices(bool_masked_pos, n_masked)
+            if visible_index is not None and masked_index is not None:
+                vis_idx = visible_index.to(device=dev, dtype=torch.int32, non_blocking=True).contiguous()
+                mask_idx = masked_index.to(device=dev, dtype=torch.int32, non_blocking=True).contiguous()
+                n_masked = mask_idx.shape[1]
+                if vis_idx.shape != (B, self.num_patches - n_masked) or mask_idx.shape[0] != B or not 0 < n_masked < self.num_patches:
+                    raise ValueError(f"visible_index / masked_index must be [{B}, N-M] / [{B}, M] with N = {self.num_patches}")
+            else:
+                n_masked = self._token_split(bool_masked_pos, num_masked)
+                vis_idx, mask_idx = split_mask_indices(bool_masked_pos, n_masked)
             if torch.is_grad_enabled() and any(p.requires_grad for p in params):
                 loss, logits = _MIMStepFn.apply(weakref.ref(self), pixel_values, vis_idx, mask_idx, *params)
             else:

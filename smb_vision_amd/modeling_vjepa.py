@@ -252,17 +252,22 @@ class SmbVJEPA2Model(PreTrainedModel):
         return [self._gflat[o:o + p.numel()].view(p.shape) for p, o in zip(self._ordered_params(), self._goffs)]
 
     # -- the step ------------------------------------------------------------------------------------------------------
-    def _index_plumbing(self, cm, tm, device):
-        """Sorted predictor sequence (modeling_vjepa.py:718-719): positions, and the slot of every context / target token."""
-        B, N = cm.shape[0], self.num_patches
+    def _index_plumbing(self, cms, tms, device):
+        """Sorted predictor sequences (modeling_vjepa.py:718-719).  ``cms`` / ``tms``: the mask lists; ``apply_masks`` (:542-556) concatenates
+        their elements along the batch, so predictor sequence m * B + b pairs volume b with mask pair m.  Returns the arrays of
+        ``smbv_vjepa_io``: absolute encoder rows of the context tokens, sorted positions, and the slot of every context / target token."""
+        B, N = cms[0].shape[0], self.num_patches
         all_idx = torch.arange(N, device=device, dtype=torch.int32).repeat(B, 1).contiguous()
+        cm, tm = torch.cat(cms, dim=0), torch.cat(tms, dim=0)           # [M*B, Nctx], [M*B, Ntgt]
         pos = torch.cat([cm, tm], dim=1)
         order = torch.argsort(pos, dim=1, stable=True)
         rev = torch.argsort(order, dim=1, stable=True)
         n_ctx = cm.shape[1]
-        return dict(all_idx=all_idx, ctx_idx=cm.to(torch.int32).contiguous(), tgt_idx=tm.to(torch.int32).contiguous(),
+        vol = torch.arange(B, device=device).repeat(len(cms)).unsqueeze(1)  # sequence -> volume it reads
+        return dict(all_idx=all_idx, ctx_idx=(cm + vol * N).to(torch.int32).contiguous(), tgt_idx=tm.to(torch.int32).contiguous(),
                     pred_pos=torch.gather(pos, 1, order).to(torch.int32).contiguous(), ctx_slot=rev[:, :n_ctx].to(torch.int32).contiguous(),
-                    tgt_slot=rev[:, n_ctx:].to(torch.int32).contiguous())
+                    tgt_slot=rev[:, n_ctx:].to(torch.int32).contiguous(), n_masks=len(cms),
+                    ctx_tok=[c.to(torch.int32).contiguous() for c in cms], tgt_tok=[t.to(torch.int32).contiguous() for t in tms])
 
     def _run_forward(self, pix, idx, with_pred):
         lib = _lib.load()
@@ -270,17 +275,18 @@ class SmbVJEPA2Model(PreTrainedModel):
         B = pix.shape[0]
         n_ctx, n_tgt = idx["ctx_idx"].shape[1], idx["tgt_idx"].shape[1]
         cfg = self._cfg_struct(B, n_ctx, n_tgt)
+        cfg.n_masks = idx["n_masks"]
         need = lib.smbv_vjepa_workspace_bytes(C.byref(cfg))
         if need == 0:
             raise ValueError("smbv_vjepa_workspace_bytes: " + _lib.last_error())
-        key = (B, n_ctx, n_tgt, dev)
+        key = (B, n_ctx, n_tgt, idx["n_masks"], dev)
         if self._ws is None or self._ws_key != key or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
             self._ws_key = key
         d = self.config.hidden_size
         enc_out = torch.empty(B, self.num_patches, d, dtype=torch.float32, device=dev)
-        pred_out = torch.empty(B, n_tgt, d, dtype=torch.float32, device=dev) if with_pred else None
+        pred_out = torch.empty(B * idx["n_masks"], n_tgt, d, dtype=torch.float32, device=dev) if with_pred else None
         io = _lib.VjepaIO()
         io.pixel_values = pix.data_ptr()
         for k in ("all_idx", "ctx_idx", "tgt_idx", "pred_pos", "ctx_slot", "tgt_slot"):
@@ -363,18 +369,24 @@ class SmbVJEPA2Model(PreTrainedModel):
             if context_mask is None and target_mask is None:
                 ar = torch.arange(N, device=dev).unsqueeze(0).repeat(B, 1)
                 context_mask, target_mask = [ar], [ar]
-            if len(context_mask) != 1 or len(target_mask) != 1:
-                raise NotImplementedError("smb_vision_amd: one context mask and one target mask per step (what run_vjepa.py's collate_fn emits)")
-            cm, tm = context_mask[0].to(dev).long(), target_mask[0].to(dev).long()
+            if len(context_mask) != len(target_mask) or len(context_mask) < 1:
+                raise ValueError("context_mask and target_mask must be lists of the same, non-zero length")
+            cms, tms = [m.to(dev).long() for m in context_mask], [m.to(dev).long() for m in target_mask]
+            if any(m.dim() != 2 or m.shape[0] != B for m in cms + tms):
+                raise ValueError("every mask must be an index tensor [batch, tokens]")
+            if any(m.shape[1] != cms[0].shape[1] for m in cms) or any(m.shape[1] != tms[0].shape[1] for m in tms):
+                raise ValueError("all context masks (and all target masks) must keep the same number of tokens: apply_masks concatenates them "
+                                 "along the batch (modeling_vjepa.py:542-556)")
             params = self._ensure_device_state(dev)
-            idx = self._index_plumbing(cm, tm, dev)
+            idx = self._index_plumbing(cms, tms, dev)
             with_pred = not skip_predictor
             if torch.is_grad_enabled() and with_pred and any(p.requires_grad for p in params):
                 enc_out, pred_out = _VJEPAFn.apply(weakref.ref(self), pix, idx, with_pred, *params)
             else:
                 enc_out, pred_out, _ = self._run_forward(pix, idx, with_pred)
-            masked = gather_rows(enc_out.detach(), idx["ctx_idx"])
-            target = gather_rows(enc_out.detach(), idx["tgt_idx"])
+            # apply_masks(sequence_output, masks) (:1150-1158): one HBM-rate row gather per mask, concatenated along the batch
+            masked = torch.cat([gather_rows(enc_out.detach(), c) for c in idx["ctx_tok"]], dim=0)
+            target = torch.cat([gather_rows(enc_out.detach(), t) for t in idx["tgt_tok"]], dim=0)
         pred = SmbVJEPA2PredictorOutput(last_hidden_state=pred_out, target_hidden_state=target) if with_pred else None
         return SmbVJEPA2ModelOutput(last_hidden_state=enc_out, masked_hidden_state=masked, target_hidden_state=target, predictor_output=pred)
 

@@ -29,7 +29,7 @@ import torch
 from torch.utils.data import Dataset
 from transformers import HfArgumentParser, TrainingArguments, VideoMAEConfig, set_seed
 
-from .masking import MaskGenerator
+from .masking import MaskGenerator, split_mask_indices_host
 from .modeling_videomae import SmbVideoMAEForPreTraining
 from .trainer import SmbTrainer
 
@@ -87,7 +87,10 @@ def collate_fn(examples):
     """``src/run_mim.py:194-219``."""
     pixel_values = torch.stack([e["image"] for e in examples])
     mask = torch.stack([e["mask"] for e in examples])
-    return {"pixel_values": pixel_values, "bool_masked_pos": mask}
+    # extra keys for the HIP path: the two ascending token lists the reference derives with boolean indexing (spec :134-137, :811-812),
+    # built here on the host from the mask that was just generated (the model otherwise sorts on the device every step)
+    vis, msk = split_mask_indices_host(mask)
+    return {"pixel_values": pixel_values, "bool_masked_pos": mask, "visible_index": vis, "masked_index": msk}
 
 
 def build_trainer(argv=None):

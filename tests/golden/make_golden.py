@@ -322,6 +322,48 @@ def make_vjepa(name="vjepa_tiny"):
     print(name, "loss", float(loss), "pred", tuple(pred.shape), "ctx/tgt", cm.shape[1], tm.shape[1], "tensors", len(blob))
 
 
+VJEPA_MULTI = dict(patch_size=8, crop_size=32, frames_per_clip=4, tubelet_size=2, in_chans=1, hidden_size=64, num_hidden_layers=2, num_attention_heads=2,
+                   mlp_ratio=4.0, pred_hidden_size=64, pred_num_hidden_layers=2, pred_num_attention_heads=2, pred_num_mask_tokens=10, pred_mlp_ratio=4.0)
+
+
+def make_vjepa_multimask(name="vjepa_multimask"):
+    """Lists of TWO context and TWO target masks (the case of the reference's tests/test_vjepa_model.py:96-125, same sizes: batch 2, 32 tokens,
+    20 context / 12 target ids drawn as independent random permutations): all four outputs of the reference VJEPA2Model and the gradients of a
+    fixed linear functional of the predictor output."""
+    from safetensors.torch import save_file
+    sys.path.insert(0, os.path.join(REF, "src"))
+    from models.vjepa.configuration_vjepa import VJEPA2Config
+    from models.vjepa.modeling_vjepa import VJEPA2Model
+    from oracle.vjepa_oracle import VJEPAConfig, init_params
+    ocfg = VJEPAConfig(**VJEPA_MULTI)
+    rcfg = VJEPA2Config(**VJEPA_MULTI)
+    rcfg._attn_implementation = "eager"
+    model = VJEPA2Model(rcfg).float().train()
+    p = init_params(ocfg, seed=5, nonzero_small=True)
+    sd = model.state_dict()
+    for k in sd:
+        if k in p:
+            sd[k] = p[k].clone()
+    model.load_state_dict(sd)
+    g = torch.Generator().manual_seed(0)
+    pix = torch.rand(2, 4, 1, 32, 32, generator=g)
+    cms = [torch.randperm(32, generator=g)[:20].unsqueeze(0).repeat(2, 1) for _ in range(2)]
+    tms = [torch.randperm(32, generator=g)[20:].unsqueeze(0).repeat(2, 1) for _ in range(2)]
+    w = torch.randn(4, 12, 64, generator=g)
+    out = model(pixel_values_videos=pix, context_mask=cms, target_mask=tms)
+    (out.predictor_output.last_hidden_state * w).sum().backward()
+    blob = {"in.pixel_values_videos": pix, "in.context_mask": torch.stack(cms), "in.target_mask": torch.stack(tms), "in.w": w,
+            "out.last_hidden_state": out.last_hidden_state.detach(), "out.masked_hidden_state": out.masked_hidden_state.detach(),
+            "out.target_hidden_state": out.target_hidden_state.detach(), "out.predictor": out.predictor_output.last_hidden_state.detach().contiguous()}
+    for k, v in p.items():
+        blob["param." + k] = v.contiguous()
+    for k, v in model.named_parameters():
+        if k in p:
+            blob["grad." + k] = (v.grad if v.grad is not None else torch.zeros_like(v)).detach().contiguous()
+    save_file(blob, os.path.join(HERE, name + ".safetensors"), metadata={"config": repr(VJEPA_MULTI), "generator": "reference VJEPA2Model fp32 eager CPU, 2 mask pairs"})
+    print(name, {k: tuple(v.shape) for k, v in blob.items() if k.startswith("out.")})
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["mim", "vjepa", "encoder"]
     if "mim" in which:
@@ -331,5 +373,7 @@ if __name__ == "__main__":
     if "vjepa" in which:
         make_vjepa_masks()
         make_vjepa()
+    if "vjepa" in which or "vjepa_multimask" in which:
+        make_vjepa_multimask()
     if "encoder" in which:
         make_encoder()

@@ -162,7 +162,8 @@ def _dp_worker(rank, world, port, q):
         pix, mask = _mim_batch(10 + rank)                # different data per rank
         model(pixel_values=pix, bool_masked_pos=mask).loss.backward()
         torch.cuda.synchronize()
-        q.put((rank, {k: p.grad.detach().cpu() for k, p in model.named_parameters()}, {k: v.detach().cpu() for k, v in model.state_dict().items()}))
+        # numpy arrays are pickled by value (torch tensors would travel as shared-memory handles that die with this process)
+        q.put((rank, {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()}, {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}))
     finally:
         dist.destroy_process_group()
 
@@ -179,7 +180,7 @@ def test_mim_dp_param_grads_are_the_mean_of_the_rank_gradients():
     for p in ps:
         p.join(timeout=60)
     assert all(p.exitcode == 0 for p in ps)
-    (_, ga, wa), (_, gb, wb) = res
+    (_, ga, wa), (_, gb, wb) = [(r, {k: torch.from_numpy(v) for k, v in g.items()}, {k: torch.from_numpy(v) for k, v in w.items()}) for r, g, w in res]
     for k in wa:
         assert torch.equal(wa[k], wb[k]), k               # rank 0's parameters everywhere
     for k in ga:

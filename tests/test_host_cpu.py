@@ -206,3 +206,19 @@ def test_vjepa_model_class_surface():
         assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
     with pytest.raises(_lib.SmbvError, match="no CPU fallback"):
         m(pixel_values_videos=torch.zeros(1, 8, 1, 32, 32))
+
+
+def test_host_index_lists_equal_the_device_sort_and_the_reference_boolean_indexing():
+    from smb_vision_amd.masking import MaskGenerator, split_mask_indices, split_mask_indices_host
+    np.random.seed(3)
+    gen = MaskGenerator(128, 64, 32, 16, 0.6)
+    mask = torch.stack([gen() for _ in range(3)])
+    vis, msk = split_mask_indices_host(mask)
+    v2, m2 = split_mask_indices(mask, int(mask[0].sum()))
+    assert vis.dtype == torch.int32 and torch.equal(vis, v2) and torch.equal(msk, m2)
+    ar = torch.arange(mask.shape[1]).expand_as(mask)
+    assert torch.equal(ar[~mask].reshape(3, -1), vis.long()) and torch.equal(ar[mask].reshape(3, -1), msk.long())   # spec :134-137 / :811-812 order
+    bad = mask.clone()
+    bad[1, :] = False
+    with pytest.raises(ValueError, match="same number"):
+        split_mask_indices_host(bad)

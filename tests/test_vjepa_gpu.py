@@ -200,3 +200,44 @@ def test_vjepa_gradients_are_averaged_across_ranks():
         p.join(timeout=60)
     assert all(p.exitcode == 0 for p in ps)
     assert res[0][1] == pytest.approx(res[1][1], rel=1e-12, abs=1e-12) and res[0][2] == pytest.approx(res[1][2], rel=1e-12) and res[0][2] > 0
+
+
+def test_vjepa_mask_lists_match_the_reference_shapes_and_the_oracle():
+    """Lists of masks (reference tests/test_vjepa_model.py:96-125: two context and two target masks -> (4, 20, 64) / (4, 12, 64) at batch 2,
+    32 tokens): apply_masks concatenates the pairs along the batch, the predictor runs on every (volume, pair) sequence, and the encoder
+    receives the SUM of the pairs' gradients.  Shapes as the reference test asserts them; values and every gradient against the oracle."""
+    from oracle.vjepa_oracle import VJEPAConfig, model_forward
+    blob, c = load("vjepa_multimask")          # inputs, weights and the reference VJEPA2Model's own outputs / gradients for this case
+    cfg = VJEPAConfig(**c)
+    assert cfg.num_patches == 32
+    params = {k[6:]: v for k, v in blob.items() if k.startswith("param.")}
+    pix, w = blob["in.pixel_values_videos"], blob["in.w"]
+    cms, tms = list(blob["in.context_mask"]), list(blob["in.target_mask"])
+    model = build(c, params)
+    out = model(pixel_values_videos=pix.cuda(), context_mask=[m.cuda() for m in cms], target_mask=[m.cuda() for m in tms])
+    assert out.last_hidden_state.shape == (2, 32, 64)
+    assert out.masked_hidden_state.shape == (4, 20, 64)
+    assert out.predictor_output.last_hidden_state.shape == (4, 12, 64)
+    assert out.target_hidden_state.shape == out.predictor_output.last_hidden_state.shape
+    (out.predictor_output.last_hidden_state * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    ref = model_forward(leaf, cfg, pix, cms, tms)
+    (ref["predictor_output"] * w).sum().backward()
+    assert rel(out.last_hidden_state.cpu(), ref["last_hidden_state"].detach()) < 3e-2
+    assert rel(out.predictor_output.last_hidden_state.detach().cpu(), ref["predictor_output"].detach()) < 3e-2
+    assert rel(out.masked_hidden_state.cpu(), ref["masked_hidden_state"].detach()) < 3e-2
+    assert rel(out.target_hidden_state.cpu(), ref["target_hidden_state"].detach()) < 3e-2
+    assert rel(out.predictor_output.last_hidden_state.detach().cpu(), blob["out.predictor"]) < 3e-2      # the reference class itself
+    for k, p in model.named_parameters():
+        assert float((leaf[k].grad - blob["grad." + k]).abs().max()) <= 1e-4 * float(blob["grad." + k].abs().max()) + 1e-8, k  # oracle == reference
+        r = leaf[k].grad
+        if r is None or float(r.norm()) < 1e-10:
+            continue
+        e = float((p.grad.cpu() - r).norm() / r.norm())
+        assert e < (2e-1 if k.endswith("attention.key.bias") else 8e-2), (k, e)
+    # a single pair handed over as 1-element lists is the old path; mismatching list lengths / token counts raise
+    with pytest.raises(ValueError):
+        model(pixel_values_videos=pix.cuda(), context_mask=[cms[0].cuda()], target_mask=[t.cuda() for t in tms])
+    with pytest.raises(ValueError):
+        model(pixel_values_videos=pix.cuda(), context_mask=[cms[0].cuda(), cms[1][:, :10].cuda()], target_mask=[t.cuda() for t in tms])

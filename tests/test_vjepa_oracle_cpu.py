@@ -93,3 +93,24 @@ def test_ema_update():
     out = ema_update(a, b, 0.9)
     k = "encoder.layer.0.mlp.fc1.weight"
     assert torch.allclose(out[k], 0.9 * a[k] + 0.1 * b[k])
+
+
+def test_vjepa_oracle_matches_reference_model_with_mask_lists():
+    """Two (context, target) mask pairs (tests/golden/vjepa_multimask.safetensors, written by make_golden.py from the reference VJEPA2Model): the case
+    the reference's tests/test_vjepa_model.py:96-125 exercises - same shapes, plus values and gradients."""
+    blob, c = load("vjepa_multimask")
+    cfg = VJEPAConfig(**c)
+    p = {k[6:]: v for k, v in blob.items() if k.startswith("param.")}
+    leaf = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    cms, tms = list(blob["in.context_mask"]), list(blob["in.target_mask"])
+    out = model_forward(leaf, cfg, blob["in.pixel_values_videos"], cms, tms)
+    assert out["last_hidden_state"].shape == (2, 32, 64) and out["masked_hidden_state"].shape == (4, 20, 64)
+    assert out["predictor_output"].shape == (4, 12, 64) and out["target_hidden_state"].shape == out["predictor_output"].shape
+    for k, name in (("last_hidden_state", "out.last_hidden_state"), ("masked_hidden_state", "out.masked_hidden_state"),
+                    ("target_hidden_state", "out.target_hidden_state"), ("predictor_output", "out.predictor")):
+        assert torch.allclose(out[k], blob[name], rtol=1e-4, atol=2e-5), k
+    (out["predictor_output"] * blob["in.w"]).sum().backward()
+    for k, v in leaf.items():
+        ref = blob["grad." + k]
+        g = v.grad if v.grad is not None else torch.zeros_like(v)
+        assert float((g - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-8, k

@@ -11,13 +11,17 @@ def timeit(fn, iters=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
 variants = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 32]
-shapes = [(7168, 2304, 768, {}), (7168, 2304, 3072, {}), (7168, 768, 768, {}), (7168, 3072, 768, dict(gelu=True, save_pre=True)), (7168, 768, 3072, {}),
-          (20480, 1152, 384, {}), (20480, 384, 1536, {}), (20480, 1536, 384, dict(gelu=True, save_pre=True)), (13312, 4096, 384, {}), (7168, 768, 4096, {})]
+shapes = [(7168, 2304, 768, {}), (7168, 768, 2304, {}), (7168, 768, 768, {}), (7168, 3072, 768, dict(gelu=True, save_pre=True)), (7168, 768, 3072, {}),
+          (7168, 3072, 768, dict(dgelu=True)),
+          (20480, 1152, 384, {}), (20480, 384, 1152, {}), (20480, 384, 384, {}), (20480, 384, 1536, {}), (20480, 1536, 384, dict(gelu=True, save_pre=True)),
+          (20480, 1536, 384, dict(dgelu=True)), (13312, 4096, 384, {}), (13312, 384, 4096, {}), (7168, 768, 4096, {}), (7168, 384, 768, {})]
 g = torch.Generator(device="cuda").manual_seed(0)
 for M, N, K, kw in shapes:
     A = torch.randn(M, K, generator=g, device="cuda").bfloat16()
     B = (torch.randn(N, K, generator=g, device="cuda") * 0.02).bfloat16()
     bias = torch.randn(N, generator=g, device="cuda")
+    if kw.pop("dgelu", False):
+        kw = dict(dgelu_pre=torch.randn(M, N, generator=g, device="cuda").bfloat16())
     outs = {}
     res = {v: [] for v in variants}
     for rnd in range(5):
@@ -28,5 +32,5 @@ for M, N, K, kw in shapes:
             res[v].append(timeit(lambda: ops.gemm_nt(A, B, bias=bias, **kw)))
     same = all(torch.equal(outs[variants[0]], outs[v]) for v in variants)
     f = 2.0 * M * N * K
-    print(f"M{M} N{N} K{K} {'gelu' if kw else '    '}: " + "  ".join(f"v{v}: {sorted(res[v])[2]*1e3:7.1f}us {f/sorted(res[v])[2]/1e9:6.1f}TF" for v in variants) + f"  same={same}")
+    print(f"M{M} N{N} K{K} {'gelu' if 'gelu' in kw else ('dgel' if kw else '    ')}: " + "  ".join(f"v{v}: {sorted(res[v])[2]*1e3:7.1f}us {f/sorted(res[v])[2]/1e9:6.1f}TF" for v in variants) + f"  same={same}")
 raw.smbv_set_variant(0)
