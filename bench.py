@@ -4,18 +4,25 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A step = forward + loss + backward (+ RCCL gradient all-reduce when N > 1) + global-norm clip + AdamW + zero_grad on one
-synthetic volume per GPU already resident in HBM (fp32 [1,320,1,512,512] U[0,1), mask from MaskGenerator(512,320,32,16,0.65):
-BASELINE.json configs[1], the shape README.md:56-68 of the reference recommends).  Weights: random init of the ViT-base
-VideoMAE-for-pretraining architecture.  Rank 0 prints ONE JSON line (see the task contract): value = volumes/s over all GPUs.
+A step = forward + loss + backward (+ RCCL gradient all-reduce when N > 1) + global-norm clip + AdamW + zero_grad on one synthetic
+volume per GPU (fp32 [1,320,1,512,512] U[0,1), mask from MaskGenerator(512,320,32,16,0.65): BASELINE.json configs[1], the shape
+README.md:56-68 of the reference recommends).  Weights: random init of the ViT-base VideoMAE-for-pretraining architecture.  Rank 0
+prints ONE JSON line (the task contract):
 
-Extra objects on that line:
-  roofline      dominant kernel (decoder attention backward dK/dV, S=20,480, 6 heads): algorithmic FLOP per launch / average
-                launch duration measured with HIP events on the launch stream inside this process, vs the 2.5 PFLOP/s dense
-                bf16 MFMA peak;  `step` adds the whole-step figure (18.46 TFLOP algorithmic fwd+bwd per volume).
-  cpu_baseline  the CPU oracle (oracle/mim_oracle.py, kind "port") timed on this host's cores on a bounded sample
-                (one encoder layer + one decoder layer at full sequence length + embedding/head/loss, fwd+bwd, extrapolated to
-                12 + 4 layers).  Rank 0, N == 1 only.  Skipped with --no-cpu-baseline.
+  value / ms_per_step   the contract's number: K steps on a volume ALREADY RESIDENT in HBM, between barriers, max over ranks.
+  fed                   the same K steps with SURVEY.md §8(d)'s full step: every step takes a NEW raw int16 volume from page-locked host
+                        memory through smb_vision_amd.feed.VolumeFeeder (copy stream + device-side ScaleIntensityRange / pad / crop / permute) and
+                        a NEW mask from the bit-exact MaskGenerator with host-built token lists; same barrier protocol.  PCIe-inclusive, therefore
+                        reported beside `value`, never as it.
+  roofline              dominant kernel = the decoder attention backward (attn_dkv2_kernel running beside attn_dq2_kernel, S = 20,480, 6 heads),
+                        timed with HIP events on its launch stream: `frac` counts the ALGORITHMIC five products (S, dP, dV, dK, dQ: 10 S^2 Dh H FLOP),
+                        `executed_frac` the seven products the two kernels execute (dQ's kernel recomputes S and dP); `dkv` is the dK/dV kernel alone;
+                        `step` the whole-step figure (18.46 TFLOP algorithmic fwd+bwd per volume).  Peak 2.5 PFLOP/s dense bf16.
+  cpu_baseline          the CPU oracle (oracle/mim_oracle.py, kind "port", fused CPU attention as the reference defaults to SDPA) on this host's cores:
+                        one warm-up step on a 2+1-layer model, then 2 timed FULL steps (forward + loss + backward) of the same workload.  Rank 0, N == 1.
+  config.trainer_ms_per_step   the same workload through the shipped harness (smb_vision_amd.run_mim: HF Trainer + SmbTrainer's optimizer tail) with
+                        volumes handed over as pinned fp32 CPU tensors the way the reference's DataLoader does; N == 1 only.
+Diagnostics (not the metric): --vjepa (BASELINE.json config 4), --vit-large (config 5's model), --tiny, --no-optimizer, --torch-optimizer.
 """
 from __future__ import annotations
 
@@ -35,6 +42,7 @@ os.environ.setdefault("TRANSFORMERS_OFFLINE", "1")
 
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 STEP_TFLOP = 18.461           # algorithmic fwd+bwd per volume
+VJEPA_STEP_TFLOP = 102.2      # 3 x encoder + 3 x predictor + 1 x target encoder
 
 VIT_BASE = dict(image_size=512, num_frames=320, patch_size=16, tubelet_size=16, num_channels=1, hidden_size=768, num_hidden_layers=12,
                 num_attention_heads=12, intermediate_size=3072, decoder_hidden_size=384, decoder_num_hidden_layers=4,
@@ -57,11 +65,12 @@ def build(rank, device, cfg_kw):
     gen = MaskGenerator(input_size=cfg_kw["image_size"], depth=cfg_kw["num_frames"], mask_patch_size=32, model_patch_size=cfg_kw["patch_size"],
                         mask_ratio=0.65)
     mask = gen().unsqueeze(0).to(device)
-    return model, pix, mask, gen.num_masked
+    return model, pix, mask, gen
 
 
 def kernel_roofline(device, iters=20, warm=10):
-    """Decoder attention backward dK/dV kernel at the bench shape, timed with HIP events on the stream it is launched on."""
+    """Decoder attention backward at the bench shape, timed with HIP events on the stream it is launched on: the dK/dV kernel alone, the dQ
+    kernel alone, and the pair as the step runs it (dQ forked onto the library's side stream and joined back before the second event)."""
     from smb_vision_amd import ops
     B, S, H = 1, 20480, 6
     w = H * 64
@@ -71,8 +80,9 @@ def kernel_roofline(device, iters=20, warm=10):
     O, lse = ops.attention_fwd(qkv, B, S, H)
     out = (torch.empty_like(qkv), torch.empty(B, H, S, dtype=torch.float32, device=device))
     ops.attention_bwd(qkv, O, dO, lse, B, S, H, parts=1, out=out)
+    unit = 2.0 * S * S * 64 * H  # one S x S x 64 product over all heads
     res = {}
-    for name, parts, flop in (("attn_dkv_kernel", 2, 4 * 2.0 * S * S * 64 * H), ("attn_dq_kernel", 4, 3 * 2.0 * S * S * 64 * H)):
+    for name, parts in (("dkv", 2), ("dq", 4), ("pair", 6)):
         for _ in range(warm):  # the host-side set-up above leaves the GPU idle long enough for its clocks to drop
             ops.attention_bwd(qkv, O, dO, lse, B, S, H, parts=parts, out=out)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -81,9 +91,8 @@ def kernel_roofline(device, iters=20, warm=10):
             ops.attention_bwd(qkv, O, dO, lse, B, S, H, parts=parts, out=out)
         ev1.record()
         torch.cuda.synchronize()
-        ms = ev0.elapsed_time(ev1) / iters
-        res[name] = dict(ms=ms, tflops=flop / (ms * 1e-3) / 1e12, flop=flop)
-    return res
+        res[name] = ev0.elapsed_time(ev1) / iters
+    return res, unit
 
 
 def cpu_threads():
@@ -100,44 +109,176 @@ def cpu_threads():
     return int(env) if env else min(n, 64) if n <= 64 else 16
 
 
-def cpu_baseline(threads):
-    """Oracle (port) timed on the host: bounded sample, extrapolated (see module docstring)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(threads, timed=2):
+    """The oracle's whole train step (forward + loss + backward, fp32, fused CPU attention) on the bench workload, on the host's cores."""
     import oracle.mim_oracle as o
+    from smb_vision_amd.masking import MaskGenerator
     torch.set_num_threads(threads)
     o.SDPA = True
-    cfg = o.MIMConfig()
-    g = torch.Generator().manual_seed(0)
+    try:
+        kw = {k: v for k, v in VIT_BASE.items() if k != "num_channels"}
+        np.random.seed(42)
+        mask = MaskGenerator(512, 320, 32, 16, 0.65)().unsqueeze(0)
+        pix = torch.rand(1, 320, 1, 512, 512, generator=torch.Generator().manual_seed(1234))
+        small = o.MIMConfig(**dict(kw, num_hidden_layers=2, decoder_num_hidden_layers=1))
+        o.mim_step(o.init_params(small, seed=42), small, pix, mask)  # warm-up: thread pool, allocator, kernels selected
+        cfg = o.MIMConfig(**kw)
+        params = o.init_params(cfg, seed=42)
+        ts = []
+        for _ in range(timed):
+            t0 = time.perf_counter()
+            loss, _, _ = o.mim_step(params, cfg, pix, mask)
+            ts.append(time.perf_counter() - t0)
+    finally:
+        o.SDPA = False
+    mean = sum(ts) / len(ts)
+    return dict(value=1.0 / mean, unit="volumes/s", cores=threads, kind="port", cpu=cpu_model(), seconds_per_step=[round(t, 2) for t in ts],
+                loss=float(loss),
+                sample=f"oracle/mim_oracle.py mim_step (fp32, SDPA attention): forward + loss + backward of the whole ViT-base 512x512x320 workload, 1 warm-up "
+                       f"step on a 2+1-layer model then {timed} timed full steps ({', '.join(f'{t:.1f}s' for t in ts)}), optimizer excluded")
 
-    def layer_time(S, w, ff, heads):
-        c = o.MIMConfig(hidden_size=w, intermediate_size=ff, num_attention_heads=heads)
-        names = o.layer_param_names("l.")
-        shapes = [(w,), (w,), (w, w), (w, w), (w, w), (w,), (w,), (w, w), (w,), (w,), (w,), (ff, w), (ff,), (w, ff), (w,)]
-        p = {n: (torch.randn(s, generator=g) * 0.02).requires_grad_(True) for n, s in zip(names, shapes)}
-        x = torch.randn(1, S, w, generator=g).requires_grad_(True)
-        t0 = time.perf_counter()
-        y = o.layer(x, p, "l.", heads, c.layer_norm_eps)
-        y.sum().backward()
-        return time.perf_counter() - t0
 
-    t_enc = layer_time(7168, 768, 3072, 12)
-    t_dec = layer_time(20480, 384, 1536, 6)
-    # embedding (all N tokens, as the reference computes it) + head + targets + loss
-    pix = torch.rand(1, 320, 1, 512, 512, generator=g)
-    w_pe = (torch.randn(768, 1, 16, 16, 16, generator=g) * 0.02).requires_grad_(True)
-    b_pe = torch.zeros(768, requires_grad=True)
-    w_h = (torch.randn(4096, 384, generator=g) * 0.02).requires_grad_(True)
-    h = torch.randn(1, 13312, 384, generator=g).requires_grad_(True)
+class _FedSource:
+    """Endless (raw int16 HU volume in page-locked memory, extras) stream: 4 distinct volumes cycled, a fresh mask per step from the bit-exact
+    generator (global numpy RNG, as the reference's GenerateMask) with the token lists built on the host."""
+
+    def __init__(self, rank, gen, size, depth):
+        from smb_vision_amd.masking import split_mask_indices_host
+        self.split = split_mask_indices_host
+        rng = np.random.default_rng(1234 + rank)
+        self.raws = [torch.from_numpy(rng.integers(-1000, 1000, size=(size, size, depth), dtype=np.int16)).pin_memory() for _ in range(4)]
+        self.gen = gen
+
+    def __iter__(self):
+        i = 0
+        while True:
+            mask = self.gen().unsqueeze(0)
+            vis, msk = self.split(mask)
+            yield self.raws[i & 3], dict(mask=mask.pin_memory(), vis=vis.pin_memory(), msk=msk.pin_memory())
+            i += 1
+
+
+def trainer_ms_per_step(cfg_kw, steps=10, warm=2):
+    """The shipped harness at full size: smb_vision_amd.run_mim.build_trainer (HF Trainer + SmbTrainer), B = 1, data = pinned fp32 CPU volumes."""
+    import tempfile
+    from transformers import TrainerCallback
+    from smb_vision_amd import run_mim
+
+    class Cycling(torch.utils.data.Dataset):
+        def __init__(self, gen):
+            self.vols = [torch.rand(cfg_kw["num_frames"], 1, cfg_kw["image_size"], cfg_kw["image_size"], generator=torch.Generator().manual_seed(s)).pin_memory()
+                         for s in range(4)]
+            self.gen = gen
+
+        def __len__(self):
+            return 4 * (steps + warm)
+
+        def __getitem__(self, i):
+            return {"image": self.vols[i & 3], "mask": self.gen()}
+
+    class Clock(TrainerCallback):
+        t0 = t1 = None
+
+        def on_step_end(self, args, state, control, **kw):
+            if state.global_step == warm:
+                torch.cuda.synchronize()
+                Clock.t0 = time.perf_counter()
+            if state.global_step == warm + steps:
+                torch.cuda.synchronize()
+                Clock.t1 = time.perf_counter()
+
+    with tempfile.TemporaryDirectory() as tmp:
+        argv = ["--output_dir", tmp, "--image_size", str(cfg_kw["image_size"]), "--depth", str(cfg_kw["num_frames"]), "--patch_size", "16",
+                "--mask_patch_size", "32", "--mask_ratio", "0.65", "--max_steps", str(warm + steps), "--per_device_train_batch_size", "1",
+                "--report_to", "none", "--bf16", "true", "--learning_rate", "1.5e-4", "--weight_decay", "0.05", "--adam_beta2", "0.95", "--logging_steps", "1000",
+                "--save_strategy", "no", "--max_grad_norm", "1.0", "--dataloader_num_workers", "0", "--dataloader_pin_memory", "false", "--gradient_checkpointing", "true",
+                "--decoder_hidden_size", "384", "--decoder_num_hidden_layers", "4", "--decoder_num_attention_heads", "6", "--decoder_intermediate_size", "1536",
+                "--disable_tqdm", "true"]
+        trainer = run_mim.build_trainer(argv)
+        trainer.train_dataset = Cycling(trainer.train_dataset.gen)
+        trainer.add_callback(Clock())
+        trainer.train()
+    del trainer
+    torch.cuda.empty_cache()
+    return (Clock.t1 - Clock.t0) / steps * 1e3
+
+
+def run_vjepa(args, device, world, rank):
+    """--vjepa: BASELINE.json config 4 (ViT-base encoder + default predictor, 512x512x320, B = 1, 3 mask blocks): online forward + frozen target
+    forward + L1 + EMA + backward + fused clip / AdamW.  Diagnostic line, same barrier protocol."""
+    import torch.distributed as dist
+    from transformers import VJEPA2Config
+    from smb_vision_amd.masking import VJEPAMaskGenerator
+    from smb_vision_amd.modeling_vjepa import MomentumEncoder, SmbVJEPA2Model, make_target_encoder, vjepa_loss
+    from smb_vision_amd.optim import SmbvAdamW
+    cfg = VJEPA2Config(patch_size=16, crop_size=512, frames_per_clip=320, tubelet_size=16, in_chans=1, hidden_size=768, num_hidden_layers=12,
+                       num_attention_heads=12, mlp_ratio=4.0, pred_hidden_size=384, pred_num_hidden_layers=12, pred_num_attention_heads=12)
+    torch.manual_seed(0)
+    model = SmbVJEPA2Model(cfg).to(device).train()
+    target = make_target_encoder(model)
+    ema = MomentumEncoder(target, 0.99925)
+    opt = SmbvAdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05, max_grad_norm=1.0)
+    if world > 1:
+        from smb_vision_amd.dp import DataParallelEngine
+        DataParallelEngine(model).broadcast_parameters(model)
+    pix = torch.rand(1, 320, 1, 512, 512, generator=torch.Generator(device=device).manual_seed(1 + rank), device=device)
+    torch.manual_seed(7 + rank)
+    item = VJEPAMaskGenerator(input_size=(320, 512, 512), patch_size=(16, 16, 16), pred_mask_scale=(0.2, 0.8), aspect_ratio=(0.3, 3.0), num_blocks=3)({})
+    cm, tm = item["context_mask"][None].to(device), item["target_mask"][None].to(device)
+    inputs = {"pixel_values_videos": pix, "context_mask": [cm], "target_mask": [tm]}
+
+    def step():
+        loss, _ = vjepa_loss(model, target, ema, inputs)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    dt = timed_region(step, args.steps, world, device)
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        tf = world * VJEPA_STEP_TFLOP / (ms * 1e-3)
+        print(json.dumps({"metric": "V-JEPA train-step volumes/sec (512x512x320, ViT-base + predictor) [diagnostic: BASELINE.json config 4]", "value": world * args.steps / dt,
+                          "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": "V-JEPA ViT-base encoder (12L/768) + predictor (12L/384, 12 heads x 32), 512x512x320, B=1/GPU, 3 mask blocks: online fwd + "
+                                                 "target fwd + L1 + EMA + bwd + clip + AdamW", "tokens": model.num_patches, "context": int(cm.shape[1]), "target": int(tm.shape[1]),
+                                     "parallelism": f"dp{world}", "final_loss": float(loss.detach())},
+                          "roofline": {"bound": "mfma", "kernel": "whole step (per GPU)", "achieved": tf / world, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": tf / world / MFMA_PEAK_TFLOPS, "traffic": None, "flop_per_volume_T": VJEPA_STEP_TFLOP}}), flush=True)
+
+
+def timed_region(step, steps, world, device):
+    """EXACTLY `steps` steps between barrier + synchronize on both sides; returns the max over ranks of the elapsed seconds."""
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    emb = o.patch_embed(pix, w_pe, b_pe, cfg)
-    logits = torch.nn.functional.linear(h, w_h)
-    labels = o.labels_from_pixels(pix, cfg)[:, :13312]
-    loss = torch.nn.functional.mse_loss(logits, labels) + emb.mean()
-    loss.backward()
-    t_rest = time.perf_counter() - t0
-    est = 12 * t_enc + 4 * t_dec + t_rest
-    return dict(value=1.0 / est, unit="volumes/s", cores=threads, kind="port",
-                sample=f"oracle fp32 fwd+bwd: 1 of 12 encoder layers at S=7168 ({t_enc:.2f}s) + 1 of 4 decoder layers at S=20480 "
-                       f"({t_dec:.2f}s) + patch-embed/head/targets/loss ({t_rest:.2f}s), extrapolated to the full step ({est:.1f}s)")
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t)
 
 
 def main():
@@ -147,9 +288,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--no-feed", action="store_true", help="skip the second timed region (new volume + mask per step through the VolumeFeeder)")
+    ap.add_argument("--no-trainer", action="store_true", help="skip config.trainer_ms_per_step (the HF-Trainer harness at full size)")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward only (diagnostic; not the metric)")
     ap.add_argument("--torch-optimizer", action="store_true", help="clip_grad_norm_ + torch fused AdamW instead of the fused HIP optimizer tail")
     ap.add_argument("--tiny", action="store_true", help="64x64x32 smoke shape (diagnostic; not the metric)")
+    ap.add_argument("--vjepa", action="store_true", help="BASELINE.json config 4: the V-JEPA train step (diagnostic line; not the metric)")
     ap.add_argument("--vit-large", action="store_true", help="BASELINE.json config 5's model in bf16 (encoder 1024/24L/16H/4096; decoder 512/12L/8H/2048 - the reference "
                                                                "specifies none, SURVEY.md 8d) - diagnostic; not the metric")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse the N>1 path on one GPU)")
@@ -173,6 +317,13 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    if args.vjepa:
+        run_vjepa(args, device, world, rank)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     cfg_kw = dict(VIT_BASE)
     if args.tiny:
         cfg_kw.update(image_size=64, num_frames=32, hidden_size=128, num_attention_heads=2, num_hidden_layers=2, intermediate_size=512,
@@ -180,7 +331,8 @@ def main():
     if args.vit_large:
         cfg_kw.update(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, decoder_hidden_size=512,
                       decoder_num_hidden_layers=12, decoder_num_attention_heads=8, decoder_intermediate_size=2048)
-    model, pix, mask, n_masked = build(rank, device, cfg_kw)
+    model, pix, mask, gen = build(rank, device, cfg_kw)
+    n_masked = gen.num_masked
     params = [p for p in model.parameters()]
     opt = None
     if not args.no_optimizer:
@@ -195,8 +347,8 @@ def main():
         dp = DataParallelEngine(model)
         dp.broadcast_parameters(model)
 
-    def step():
-        out = model(pixel_values=pix, bool_masked_pos=mask, num_masked=n_masked)
+    def train(pixel_values, **mask_kw):
+        out = model(pixel_values=pixel_values, **mask_kw)
         out.loss.backward()
         if opt is not None:
             if args.torch_optimizer:
@@ -207,25 +359,35 @@ def main():
             model.zero_grad(set_to_none=True)
         return out.loss
 
+    last = {}
+
+    def step():
+        last["loss"] = train(pix, bool_masked_pos=mask, num_masked=n_masked)
+
     for _ in range(args.warmup):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t)
-    final_loss = float(loss.detach())
+        step()
+    dt = timed_region(step, args.steps, world, device)
+    final_loss = float(last["loss"].detach())
+
+    # second timed region: SURVEY.md §8(d)'s step - a NEW volume from host memory and a NEW mask every step
+    fed = None
+    if not args.no_feed and not args.tiny:
+        from smb_vision_amd.feed import VolumeFeeder
+        feeder = VolumeFeeder(_FedSource(rank, gen, cfg_kw["image_size"], cfg_kw["num_frames"]), device, cfg_kw["image_size"], cfg_kw["num_frames"])
+        it = iter(feeder)
+
+        def fed_step():
+            p, ex = next(it)
+            last["loss"] = train(p, bool_masked_pos=ex["mask"].to(device, non_blocking=True), visible_index=ex["vis"], masked_index=ex["msk"])
+
+        for _ in range(max(2, args.warmup)):
+            fed_step()
+        dt_fed = timed_region(fed_step, args.steps, world, device)
+        it.close()
+        fed = {"ms_per_step": dt_fed / args.steps * 1e3, "value": world * args.steps / dt_fed, "unit": "volumes/s", "final_loss": float(last["loss"].detach()),
+               "what": "every step: new int16 volume (167.8 MB) from pinned host memory via VolumeFeeder (copy stream, device-side scale/pad/crop/permute) + new mask, "
+                       "host-built token lists; same barrier protocol"}
+
     in_sync = None
     if world > 1:  # replicas must hold identical parameters after K averaged steps (outside the timed region)
         cs = torch.stack([p.detach().double().sum() for p in params]).sum().reshape(1)
@@ -242,29 +404,40 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "ViT-base MIM, 512x512x320 volume, patch_size=16, mask_ratio=0.65 (mask_patch 32), B=1/GPU, "
-                                   "fwd+loss+bwd+clip+AdamW" + ("" if opt is not None else " [NO OPTIMIZER: diagnostic]")
+                                   "fwd+loss+bwd+clip+AdamW, volume resident in HBM" + ("" if opt is not None else " [NO OPTIMIZER: diagnostic]")
                                    + (" [TINY: diagnostic]" if args.tiny else "") + (" [ViT-LARGE bf16: diagnostic, 64.41 TFLOP/volume]" if args.vit_large else ""),
                        "tokens": model.num_patches, "masked": n_masked, "parallelism": f"dp{world}", "final_loss": final_loss,
-                       "replicas_in_sync": in_sync},
+                       "resident_ms_per_step": ms, "replicas_in_sync": in_sync},
         }
+        if fed is not None:
+            line["fed"] = fed
         step_flop = 64.41 if args.vit_large else STEP_TFLOP
         step_tf = world * step_flop / (ms * 1e-3) if not args.tiny else None  # whole job, TFLOP/s
         if world > 1 and not args.tiny:  # multi-GPU lines carry the whole-step roofline only (the kernel figure is a 1-GPU property)
             line["roofline"] = {"bound": "mfma", "kernel": "whole step (per GPU)", "achieved": step_tf / world, "peak": MFMA_PEAK_TFLOPS,
                                 "unit": "TFLOP/s", "frac": step_tf / world / MFMA_PEAK_TFLOPS, "traffic": None}
         elif not args.no_kernel_roofline and not args.tiny:
-            kr = kernel_roofline(device)
-            dom = kr["attn_dkv_kernel"]
+            kr, unit = kernel_roofline(device)
             traffic = None
             try:  # PMC-measured fabric bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes), committed under profiles/
-                traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_attn_dkv_traffic.json")))["traffic_bytes_per_launch"]
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "attn_bwd_traffic.json")))["traffic_bytes_per_launch"]
             except Exception:
                 pass
-            line["roofline"] = {"bound": "mfma", "kernel": "attn_dkv2_kernel (decoder, S=20480, H=6, Dh=64)", "achieved": dom["tflops"],
-                                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic,
-                                "launch_ms": dom["ms"], "flop_per_launch": dom["flop"],
-                                "other": {"attn_dq_kernel": {"launch_ms": kr["attn_dq_kernel"]["ms"], "achieved": kr["attn_dq_kernel"]["tflops"]}},
+            pair_s = kr["pair"] * 1e-3
+            line["roofline"] = {"bound": "mfma", "kernel": "decoder attention backward: attn_dkv2_kernel beside attn_dq2_kernel (S=20480, H=6, Dh=64)",
+                                "achieved": 5 * unit / pair_s / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 5 * unit / pair_s / 1e12 / MFMA_PEAK_TFLOPS,
+                                "executed_frac": 7 * unit / pair_s / 1e12 / MFMA_PEAK_TFLOPS, "traffic": traffic, "launch_ms": kr["pair"],
+                                "flop_per_launch": 5 * unit, "executed_flop_per_launch": 7 * unit,
+                                "dkv": {"launch_ms": kr["dkv"], "achieved": 4 * unit / (kr["dkv"] * 1e-3) / 1e12, "frac": 4 * unit / (kr["dkv"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                                        "flop_per_launch": 4 * unit},
+                                "dq": {"launch_ms": kr["dq"], "executed": 3 * unit / (kr["dq"] * 1e-3) / 1e12},
                                 "step": {"achieved": step_tf, "flop_per_volume_T": step_flop, "frac": step_tf / MFMA_PEAK_TFLOPS}}
+        if world == 1 and not args.no_trainer and not args.tiny and not args.vit_large:
+            try:
+                line["config"]["trainer_ms_per_step"] = trainer_ms_per_step(cfg_kw)
+            except Exception as e:
+                line["config"]["trainer_ms_per_step"] = None
+                line["config"]["trainer_error"] = repr(e)
         if world == 1 and not args.no_cpu_baseline and not args.tiny:
             try:
                 line["cpu_baseline"] = cpu_baseline(cpu_threads())

@@ -14,7 +14,12 @@
  *   - pointers must be 16-byte aligned unless noted;
  *   - return value: 0 = ok, negative = SMBV_ERR_* (bad shape / alignment / argument / workspace), positive = hipError_t;
  *     smbv_last_error() returns the message of the calling thread's last failure; no C++ exception crosses the ABI;
- *   - re-entrant and stream-ordered; safe from autograd's backward thread.
+ *   - re-entrant and stream-ordered; safe from autograd's backward thread;
+ *   - state inside the library: the immutable code object; a thread-local error string; per device, ONE private non-blocking side
+ *     stream and a few events created on first use and kept for the life of the process (attention backward runs its dQ and dK/dV
+ *     kernels side by side, the block backward its weight-gradient products beside the input-gradient ones; everything forked is
+ *     joined back into `stream` before the call returns); and the kernel-selection word of smbv_debug_set_variant() below (0 unless
+ *     a tuning tool sets it).  Nothing else persists between calls.
  */
 #ifndef SMBV_H
 #define SMBV_H
@@ -37,6 +42,11 @@ typedef uint16_t smbv_bf16;
 
 int smbv_version(void);                                   /* ABI version (major*1000 + minor) */
 int smbv_last_error(char* buf, size_t len);               /* copies the thread's last error text; returns its length */
+/* Tuning / A-B hook used by tools/ and by the kernel-equivalence tests, NOT by the product path: selects alternative kernels for the same
+ * arithmetic (process-wide, not thread-safe; 0 = the shipped selection).  Bits: 32 register-staged GEMMs; 256 first-generation 128x128 NT
+ * GEMM everywhere / 131072 second-generation ring NT GEMM everywhere (default: by shape); 512 four-slot ring; 8192 attention dQ and dK/dV on
+ * one stream; 16384 weight- and input-gradient GEMMs on one stream; 32768 / 65536 TN tile selection; bits 20-23 GEMM ablation (timing only). */
+void smbv_debug_set_variant(int bits);
 
 /* ---- per-op entry points (also what the parity tests call) ------------------------------------------------------ */
 

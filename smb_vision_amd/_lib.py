@@ -94,6 +94,7 @@ class VjepaIO(C.Structure):
 _SIGS = {
     "smbv_version": (C.c_int, []),
     "smbv_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "smbv_debug_set_variant": (None, [C.c_int]),
     "smbv_gemm_nt": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GemmEpi), c_f]),
     "smbv_gemm_tn": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f, C.c_size_t, c_f]),
     "smbv_gemm_tn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

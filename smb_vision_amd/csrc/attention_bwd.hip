@@ -84,145 +84,6 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   }
 }
 
-template <int MINW, int QT>
-__global__ __launch_bounds__(256, MINW) void attn_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                       const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO,
-                                                       int ldo, const float* __restrict__ LSE, const float* __restrict__ delta,
-                                                       bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int ldd, int S, int Sq, int qoff,
-                                                       int H, float scale) {
-  // One iteration = 64 queries (two 32-row sub-tiles): half the barriers and twice the work per global-load round trip of
-  // a 32-query iteration (the kernel was parked in waits 55 % of its wave-cycles).
-  // LDS per buffer: Q [64][128 B] 8 KiB | dO 8 KiB | -lse*log2e [64] f32 | -delta [64] f32
-  constexpr int NS = QT / 32;  // 32-row sub-tiles per iteration
-  constexpr int BUF = 2 * QT * 128 + 2 * QT * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
-  const int t = threadIdx.x, l = t & 63, w = t >> 6;
-  const int r = l & 31, h2 = l >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const size_t row0 = (size_t)b * S;
-  const int key = blockIdx.x * 128 + w * 32 + r;
-  const int hoff = head * 64;
-  const float c = scale * 1.4426950408889634f;
-  const float* lse_p = LSE + ((size_t)b * H + head) * Sq;
-  const float* del_p = delta + ((size_t)b * H + head) * Sq;
-
-  bf16x8 kf[4], vf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ks++) {
-    u32x4 a = {0, 0, 0, 0}, bb = {0, 0, 0, 0};
-    if (key < S) {
-      a = *(const u32x4*)(K + (row0 + key) * ld + hoff + 16 * ks + 8 * h2);
-      bb = *(const u32x4*)(V + (row0 + key) * ld + hoff + 16 * ks + 8 * h2);
-    }
-    kf[ks] = scale_frag(a, c);  // scores leave the MFMA in the exp2 domain
-    vf[ks] = __builtin_bit_cast(bf16x8, bb);
-  }
-  f32x16 dkt[2], dvt[2];
-#pragma unroll
-  for (int i = 0; i < 16; i++) { dkt[0][i] = 0.f; dkt[1][i] = 0.f; dvt[0][i] = 0.f; dvt[1][i] = 0.f; }
-
-  u32x4 rq[NS], rdo[NS];
-  float rstat = 0.f;
-  auto gload = [&](int qt) {
-    const int q0 = qt * QT;
-#pragma unroll
-    for (int i = 0; i < NS; i++) {
-      const int id = t + 256 * i, row = id >> 3, ch = id & 7;
-      const bool ok = (q0 + row) < Sq;
-      rq[i] = ok ? *(const u32x4*)(Q + (row0 + qoff + q0 + row) * ld + hoff + ch * 8) : (u32x4){0, 0, 0, 0};
-      rdo[i] = ok ? *(const u32x4*)(dO + (row0 + qoff + q0 + row) * ldo + hoff + ch * 8) : (u32x4){0, 0, 0, 0};
-    }
-    if (t < QT) rstat = (q0 + t < Sq) ? -lse_p[q0 + t] * 1.4426950408889634f : -INFINITY;  // padded rows: p = exp2(-inf) = 0
-    else if (t < 2 * QT) rstat = (q0 + t - QT < Sq) ? -del_p[q0 + t - QT] : 0.f;
-  };
-  auto lstore = [&](int buf) {
-    unsigned char* s = smem + buf * BUF;
-#pragma unroll
-    for (int i = 0; i < NS; i++) {
-      const int id = t + 256 * i, row = id >> 3, ch = id & 7;
-      *(u32x4*)(s + swz128(row, ch)) = rq[i];
-      *(u32x4*)(s + QT * 128 + swz128(row, ch)) = rdo[i];
-    }
-    // row constants, arranged so that each lane half reads its 16 accumulator rows (8*rg + 4*h2 + e) of a 32-row sub-tile as ONE
-    // contiguous 64-byte vector: position = 32*sub + 16*h2 + 4*rg + e
-    if (t < 2 * QT) {
-      const int rr = t % QT;
-      const int pos = (rr & ~31) + 16 * ((rr >> 2) & 1) + 4 * ((rr & 31) >> 3) + (rr & 3);
-      ((float*)(s + 2 * QT * 128))[(t / QT) * QT + pos] = rstat;  // [0..QT) -lse*log2e, [QT..2QT) -delta
-    }
-  };
-
-  const int nq = (Sq + QT - 1) / QT;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  const int g1 = (l >> 4) & 1, qq = (l >> 2) & 3, pp = l & 3;
-  for (int qt = 0; qt < nq; qt++) {
-    const int buf = qt & 1;
-    if (qt + 1 < nq) gload(qt + 1);
-    const unsigned char* sq = smem + buf * BUF;
-    const unsigned char* sdo = sq + QT * 128;
-    const float* sst = (const float*)(sq + 2 * QT * 128);
-#pragma unroll
-    for (int sub = 0; sub < NS; sub++) {
-      const int rb = 32 * sub;  // first query row of this sub-tile inside the LDS images
-      // accumulators start at the row constants: S' = c*q.k - lse*log2e, dP' = dO.v - delta (rows 8*rg + 4*h2 + 0..3)
-      f32x16 s = *(const f32x16*)(sst + rb + 16 * h2);
-      f32x16 dp = *(const f32x16*)(sst + QT + rb + 16 * h2);
-#pragma unroll
-      for (int ks = 0; ks < 4; ks++) {
-        const bf16x8 qa = *(const bf16x8*)(sq + swz128(rb + r, 2 * ks + h2));
-        const bf16x8 da = *(const bf16x8*)(sdo + swz128(rb + r, 2 * ks + h2));
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);     // [q][key]
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);   // [q][key]
-      }
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const float p = fast_exp2(s[i]);
-        s[i] = p;
-        dp[i] *= p;
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; s2++) {
-        bf16x8 pf, dsf;
-#pragma unroll
-        for (int j = 0; j < 8; j++) { pf[j] = (__bf16)s[8 * s2 + j]; dsf[j] = (__bf16)dp[8 * s2 + j]; }
-        const int qb = rb + 16 * s2 + 4 * h2 + qq;
-#pragma unroll
-        for (int dt = 0; dt < 2; dt++) {
-          const int c16 = 4 * dt + 2 * g1 + (pp >> 1);
-          const int sb8 = 8 * (pp & 1);
-          typedef __attribute__((ext_vector_type(8))) short s16x8;
-          const s16x4 a0 = lds_read_tr16(sdo + swz128(qb, c16) + sb8);
-          const s16x4 a1 = lds_read_tr16(sdo + swz128(qb + 8, c16) + sb8);
-          const s16x8 aa = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-          dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aa), pf, dvt[dt], 0, 0, 0);
-          const s16x4 b0 = lds_read_tr16(sq + swz128(qb, c16) + sb8);
-          const s16x4 b1 = lds_read_tr16(sq + swz128(qb + 8, c16) + sb8);
-          const s16x8 bb = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-          dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bb), dsf, dkt[dt], 0, 0, 0);
-        }
-      }
-    }
-    if (qt + 1 < nq) lstore(buf ^ 1);
-    __syncthreads();
-  }
-
-  if (key < S) {
-    bf16_t* kp = dK + (row0 + key) * ldd + hoff;
-    bf16_t* vp = dV + (row0 + key) * ldd + hoff;
-#pragma unroll
-    for (int dt = 0; dt < 2; dt++)
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const int d0 = 32 * dt + 8 * rg + 4 * h2;
-        u32x2 pk = {pack_bf16(dkt[dt][4 * rg] * scale, dkt[dt][4 * rg + 1] * scale), pack_bf16(dkt[dt][4 * rg + 2] * scale, dkt[dt][4 * rg + 3] * scale)};
-        *(u32x2*)(kp + d0) = pk;
-        u32x2 pv = {pack_bf16(dvt[dt][4 * rg], dvt[dt][4 * rg + 1]), pack_bf16(dvt[dt][4 * rg + 2], dvt[dt][4 * rg + 3])};
-        *(u32x2*)(vp + d0) = pv;
-      }
-  }
-}
 
 // Scheduling-group masks of __builtin_amdgcn_sched_group_barrier
 #define SG_VALU 0x2
@@ -474,137 +335,6 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
   }
 }
 
-template <int MINW, int KT>
-__global__ __launch_bounds__(256, MINW) void attn_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                      const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO, int ldo,
-                                                      const float* __restrict__ LSE, const float* __restrict__ delta,
-                                                      bf16_t* __restrict__ dQ, int ldd, int S, int Sq, int qoff, int H, float scale) {
-  constexpr int NL = KT / 32;  // 16-B chunks per thread per operand per tile
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * KT * 128];  // [buf][K|V][KT keys][128 B]
-  const int t = threadIdx.x, l = t & 63, w = t >> 6;
-  const int r = l & 31, h2 = l >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const size_t row0 = (size_t)b * S;
-  const int q = blockIdx.x * 128 + w * 32 + r;
-  const int hoff = head * 64;
-  const float c = scale * 1.4426950408889634f;
-
-  bf16x8 qf[4], dof[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ks++) {
-    u32x4 a = {0, 0, 0, 0}, bb = {0, 0, 0, 0};
-    if (q < Sq) {
-      a = *(const u32x4*)(Q + (row0 + qoff + q) * ld + hoff + 16 * ks + 8 * h2);
-      bb = *(const u32x4*)(dO + (row0 + qoff + q) * ldo + hoff + 16 * ks + 8 * h2);
-    }
-    qf[ks] = scale_frag(a, c);  // scores leave the MFMA in the exp2 domain
-    dof[ks] = __builtin_bit_cast(bf16x8, bb);
-  }
-  float nlse2 = -INFINITY, ndl = 0.f;  // padded queries: p = exp2(-inf) = 0
-  if (q < Sq) {
-    nlse2 = -LSE[((size_t)b * H + head) * Sq + q] * 1.4426950408889634f;
-    ndl = -delta[((size_t)b * H + head) * Sq + q];
-  }
-  f32x16 sinit, dinit;  // persistent C inputs: S'^T = c*k.q - lse*log2e, dP'^T = v.dO - delta
-#pragma unroll
-  for (int i = 0; i < 16; i++) { sinit[i] = nlse2; dinit[i] = ndl; }
-  f32x16 dqt[2];
-#pragma unroll
-  for (int i = 0; i < 16; i++) { dqt[0][i] = 0.f; dqt[1][i] = 0.f; }
-
-  u32x4 rk[NL], rv[NL];
-  auto gload = [&](int kt) {
-    const int k0 = kt * KT;
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const int id = t + 256 * i, row = id >> 3, ch = id & 7;
-      const bool ok = (k0 + row) < S;
-      const size_t off = (row0 + k0 + row) * ld + hoff + ch * 8;
-      rk[i] = ok ? *(const u32x4*)(K + off) : (u32x4){0, 0, 0, 0};
-      rv[i] = ok ? *(const u32x4*)(V + off) : (u32x4){0, 0, 0, 0};
-    }
-  };
-  auto lstore = [&](int buf) {
-    unsigned char* sk = smem + buf * (2 * KT * 128);
-    unsigned char* sv = sk + KT * 128;
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const int id = t + 256 * i, row = id >> 3, ch = id & 7;
-      *(u32x4*)(sk + swz128(row, ch)) = rk[i];
-      *(u32x4*)(sv + swz128(row, ch)) = rv[i];
-    }
-  };
-
-  const int nt = (S + KT - 1) / KT;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  const int g1 = (l >> 4) & 1, qq = (l >> 2) & 3, pp = l & 3;
-  for (int kt = 0; kt < nt; kt++) {
-    const int buf = kt & 1;
-    if (kt + 1 < nt) gload(kt + 1);
-    const unsigned char* sk = smem + buf * (2 * KT * 128);
-    const unsigned char* sv = sk + KT * 128;
-    // Software pipeline over the 32-key sub-tiles: the S/dP MFMAs of sub-tile j+1 are issued before the exp/multiply/convert
-    // VALU work and the dQ MFMAs of sub-tile j, so one wave keeps the matrix pipe busy while it does its own softmax math
-    // (the un-pipelined loop spent 36 % of its wave-cycles stalled on instruction issue).
-    auto qk = [&](const int kt2, f32x16& s, f32x16& dp) __attribute__((always_inline)) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ks++) {
-        const bf16x8 ka = *(const bf16x8*)(sk + swz128(32 * kt2 + r, 2 * ks + h2));
-        const bf16x8 va = *(const bf16x8*)(sv + swz128(32 * kt2 + r, 2 * ks + h2));
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], ks == 0 ? sinit : s, 0, 0, 0);      // [key][q]
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], ks == 0 ? dinit : dp, 0, 0, 0);   // [key][q]
-      }
-    };
-    // keys >= S (ragged last tile) need no mask here: their K rows are staged as zeros, so whatever dS they get is multiplied by
-    // a zero K row in dQ^T += K^T dS^T.
-    auto tail = [&](const int kt2, f32x16& s, f32x16& dp) __attribute__((always_inline)) {
-#pragma unroll
-      for (int i = 0; i < 16; i++) dp[i] *= fast_exp2(s[i]);
-#pragma unroll
-      for (int s2 = 0; s2 < 2; s2++) {
-        bf16x8 dsf;
-#pragma unroll
-        for (int j = 0; j < 8; j++) dsf[j] = (__bf16)dp[8 * s2 + j];
-        const int kb = 32 * kt2 + 16 * s2 + 4 * h2 + qq;
-#pragma unroll
-        for (int dt = 0; dt < 2; dt++) {
-          const int c16 = 4 * dt + 2 * g1 + (pp >> 1);
-          const int sub = 8 * (pp & 1);
-          typedef __attribute__((ext_vector_type(8))) short s16x8;
-          const s16x4 a0 = lds_read_tr16(sk + swz128(kb, c16) + sub);
-          const s16x4 a1 = lds_read_tr16(sk + swz128(kb + 8, c16) + sub);
-          const s16x8 aa = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-          dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aa), dsf, dqt[dt], 0, 0, 0);
-        }
-      }
-    };
-    f32x16 sA, dpA, sB, dpB;
-    qk(0, sA, dpA);
-#pragma unroll
-    for (int j = 0; j < KT / 32; j += 2) {
-      qk(j + 1, sB, dpB);
-      tail(j, sA, dpA);
-      if (j + 2 < KT / 32) qk(j + 2, sA, dpA);
-      tail(j + 1, sB, dpB);
-    }
-    if (kt + 1 < nt) lstore(buf ^ 1);
-    __syncthreads();
-  }
-
-  if (q < Sq) {
-    bf16_t* qp = dQ + (row0 + qoff + q) * ldd + hoff;
-#pragma unroll
-    for (int dt = 0; dt < 2; dt++)
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const int d0 = 32 * dt + 8 * rg + 4 * h2;
-        u32x2 pk = {pack_bf16(dqt[dt][4 * rg] * scale, dqt[dt][4 * rg + 1] * scale), pack_bf16(dqt[dt][4 * rg + 2] * scale, dqt[dt][4 * rg + 3] * scale)};
-        *(u32x2*)(qp + d0) = pk;
-      }
-  }
-}
 
 // Hand-phased, rotated form of attn_dq_kernel (same arithmetic and accumulation order: bitwise identical results).  Steady state,
 // per 32-key sub-tile j, three dependent chains of 4 MFMAs, each with the other sub-tile's VALU work and the LDS reads of a LATER
@@ -828,18 +558,12 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     }
   }
   if (parts & 2) {
-#define DKV(W, QT) hipLaunchKernelGGL((attn_dkv_kernel<W, QT>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale)
-    if (g_variant & 1024) DKV(2, 128);  // previous generation, kept as the A/B reference (bitwise-identical results)
-    else hipLaunchKernelGGL((attn_dkv2_kernel<128>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale);
-#undef DKV
+    hipLaunchKernelGGL((attn_dkv2_kernel<128>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale);
     rc = check_launch("attn_dkv");
     if (rc) return rc;
   }
   if (parts & 4) {
-#define DQ(W, KT) hipLaunchKernelGGL((attn_dq_kernel<W, KT>), dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale)
-    if (g_variant & 2048) DQ(2, 128);  // previous generation (A/B reference)
-    else hipLaunchKernelGGL((attn_dq2_kernel<128>), dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale);
-#undef DQ
+    hipLaunchKernelGGL((attn_dq2_kernel<128>), dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale);
     rc = check_launch("attn_dq");
   }
   if (fj) {

@@ -38,154 +38,6 @@ __device__ __forceinline__ bf16x8 scale_bf16x8(u32x4 v, float c) {
   return __builtin_bit_cast(bf16x8, o);
 }
 
-template <int MINW>
-__global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                          const bf16_t* __restrict__ V, int ld, bf16_t* __restrict__ O, int ldo,
-                                                          float* __restrict__ LSE, int S, int Sq, int qoff, int H, float scale) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 64 * 128];  // [buf][K|V][64 keys][128 B]
-  const int t = threadIdx.x, l = t & 63, w = t >> 6;
-  const int r = l & 31, h2 = l >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const size_t row0 = (size_t)b * S;
-  const int q = blockIdx.x * 128 + w * 32 + r;
-  const int hoff = head * 64;
-  const float c = scale * 1.4426950408889634f;
-
-  bf16x8 qf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ks++) {
-    u32x4 v = {0, 0, 0, 0};
-    if (q < Sq) v = *(const u32x4*)(Q + (row0 + qoff + q) * ld + hoff + 16 * ks + 8 * h2);
-    qf[ks] = scale_bf16x8(v, c);
-  }
-
-  f32x16 ot[2], cneg;
-#pragma unroll
-  for (int i = 0; i < 16; i++) { ot[0][i] = 0.f; ot[1][i] = 0.f; cneg[i] = 0.f; }
-  float m2 = 0.f, l_i = 0.f;  // m2: reference exponent (log2 domain); cneg == -m2 in every register
-
-  u32x4 rk[2], rv[2];
-  auto gload = [&](int kt) {
-    const int k0 = kt * 64;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int id = t + 256 * i, row = id >> 3, ch = id & 7;
-      const bool ok = (k0 + row) < S;
-      const size_t off = (row0 + k0 + row) * ld + hoff + ch * 8;
-      rk[i] = ok ? *(const u32x4*)(K + off) : (u32x4){0, 0, 0, 0};
-      rv[i] = ok ? *(const u32x4*)(V + off) : (u32x4){0, 0, 0, 0};
-    }
-  };
-  auto lstore = [&](int buf) {
-    unsigned char* sk = smem + buf * (2 * 64 * 128);
-    unsigned char* sv = sk + 64 * 128;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int id = t + 256 * i, row = id >> 3, ch = id & 7;
-      *(u32x4*)(sk + swz_k64(row, ch)) = rk[i];
-      *(u32x4*)(sv + swz_v64(row, ch >> 1) + 16 * (ch & 1)) = rv[i];
-    }
-  };
-
-  const int nt = (S + 63) / 64;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  const int g1 = (l >> 4) & 1, qq = (l >> 2) & 3, pp = l & 3;
-  for (int kt = 0; kt < nt; kt++) {
-    const int buf = kt & 1;
-    if (kt + 1 < nt) gload(kt + 1);
-    const unsigned char* sk = smem + buf * (2 * 64 * 128);
-    const unsigned char* sv = sk + 64 * 128;
-
-    f32x16 s[2];
-#pragma unroll
-    for (int kt2 = 0; kt2 < 2; kt2++) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ks++) {
-        const bf16x8 kf = *(const bf16x8*)(sk + swz_k64(32 * kt2 + r, 2 * ks + h2));
-        s[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? cneg : s[kt2], 0, 0, 0);  // c*q.k - m2
-      }
-    }
-    if (kt * 64 + 64 > S) {  // ragged last tile: keys >= S get -inf
-#pragma unroll
-      for (int kt2 = 0; kt2 < 2; kt2++)
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-          const int key = kt * 64 + 32 * kt2 + (i & 3) + 8 * (i >> 2) + 4 * h2;
-          if (key >= S) s[kt2][i] = -INFINITY;
-        }
-    }
-    float mx = s[0][0];
-#pragma unroll
-    for (int i = 1; i < 16; i++) mx = fmaxf(mx, s[0][i]);
-#pragma unroll
-    for (int i = 0; i < 16; i++) mx = fmaxf(mx, s[1][i]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // finite: every tile holds at least one valid key
-    const bool rebase = (kt == 0) || (mx > ATTN_DEFER_THR);
-    if (__builtin_amdgcn_ballot_w64(rebase) != 0) {  // wave-uniform, rare after the first tiles
-      const float d = rebase ? mx : 0.f;
-      const float alpha = fast_exp2(-d);
-      m2 += d;
-      l_i *= alpha;
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        ot[0][i] *= alpha;
-        ot[1][i] *= alpha;
-        s[0][i] -= d;
-        s[1][i] -= d;
-        cneg[i] = -m2;
-      }
-    }
-    float rowsum = 0.f;
-#pragma unroll
-    for (int kt2 = 0; kt2 < 2; kt2++)
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const float p = fast_exp2(s[kt2][i]);
-        s[kt2][i] = p;
-        rowsum += p;
-      }
-    l_i += rowsum;
-
-#pragma unroll
-    for (int kt2 = 0; kt2 < 2; kt2++)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; s2++) {
-        bf16x8 pf;
-#pragma unroll
-        for (int j = 0; j < 8; j++) pf[j] = (__bf16)s[kt2][8 * s2 + j];
-        const int kb = 32 * kt2 + 16 * s2 + 4 * h2 + qq;  // this lane's address row for the tr-read
-#pragma unroll
-        for (int dt = 0; dt < 2; dt++) {
-          const int c32 = 2 * dt + g1;
-          const s16x4 v0 = lds_read_tr16(sv + swz_v64(kb, c32) + 8 * pp);
-          const s16x4 v1 = lds_read_tr16(sv + swz_v64(kb + 8, c32) + 8 * pp);
-          typedef __attribute__((ext_vector_type(8))) short s16x8;
-          const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, ot[dt], 0, 0, 0);
-        }
-      }
-    if (kt + 1 < nt) lstore(buf ^ 1);
-    __syncthreads();
-  }
-
-  const float l_tot = l_i + __shfl_xor(l_i, 32, 64);
-  const float inv = 1.0f / l_tot;
-  if (q < Sq) {
-    bf16_t* op = O + (row0 + qoff + q) * ldo + hoff;
-#pragma unroll
-    for (int dt = 0; dt < 2; dt++)
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const int d0 = 32 * dt + 8 * rg + 4 * h2;
-        u32x2 pk = {pack_bf16(ot[dt][4 * rg] * inv, ot[dt][4 * rg + 1] * inv), pack_bf16(ot[dt][4 * rg + 2] * inv, ot[dt][4 * rg + 3] * inv)};
-        *(u32x2*)(op + d0) = pk;
-      }
-    // natural-log LSE of the scaled scores: (m2 + log2(l)) / log2(e)
-    if (h2 == 0) LSE[((size_t)b * H + head) * Sq + q] = (m2 + __log2f(l_tot)) * 0.6931471805599453f;
-  }
-}
 
 #define SG_VALU 0x2
 #define SG_MFMA 0x8
@@ -437,8 +289,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
   }
 }
 
-int g_variant = 0;  // tuning / A-B hook (tools/attn_*ab.py): 32 / 1024 / 2048 previous generation of the fwd / dkv / dq kernels,
-                    // 8192 dQ and dK/dV on one stream; gemm.hip: 32 register-staged GEMMs, 64 / 128 epilogue debug
+extern int g_variant;  // debug hook, capi.hip (smbv_debug_set_variant)
 
 int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf16_t* O, int ldo, float* LSE, int B, int S, int H, int Dh,
                   float scale, int Sq, int qoff, hipStream_t st) {
@@ -448,10 +299,8 @@ int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf1
   if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 3)) { set_error("attention_fwd: bad shape B=%d S=%d H=%d ld=%d ldo=%d", B, S, H, ld, ldo); return SMBV_ERR_SHAPE; }
   if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || ((uintptr_t)O & 7)) { set_error("attention_fwd: alignment"); return SMBV_ERR_ALIGN; }
   if ((size_t)(S + 256) * ld * 2 >= (1ull << 31)) { set_error("attention_fwd: one sequence spans %zu bytes of the QKV matrix; the LDS-DMA offsets are 32-bit", (size_t)S * ld * 2); return SMBV_ERR_SHAPE; }
-  if (!(g_variant & 32)) hipLaunchKernelGGL(attn_fwd2_kernel, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale);
-  else hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale);
+  hipLaunchKernelGGL(attn_fwd2_kernel, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale);
   return check_launch("attention_fwd");
 }
 
 }  // namespace smbv
-extern "C" void smbv_set_variant(int v) { smbv::g_variant = v; }

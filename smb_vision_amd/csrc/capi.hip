@@ -40,13 +40,16 @@ static GemmEpi to_epi(const smbv_gemm_epi* s) {
   return e;
 }
 
+int g_variant = 0;  // smbv_debug_set_variant (include/smbv.h): kernel selection for A/B tools and equivalence tests; 0 on the product path
+
 }  // namespace smbv
 
 using namespace smbv;
 
 extern "C" {
 
-int smbv_version(void) { return 1000; }
+int smbv_version(void) { return 1001; }
+void smbv_debug_set_variant(int bits) { smbv::g_variant = bits; }
 
 int smbv_last_error(char* buf, size_t len) {
   const size_t n = strlen(g_err);

@@ -307,7 +307,12 @@ int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, in
       (e.dgelu_pre && ((e.ld_pre & 3) || ((uintptr_t)e.dgelu_pre & 7))) || (e.aux_pre && ((e.ld_aux & 3) || ((uintptr_t)e.aux_pre & 7)))) {
     set_error("gemm_nt: epilogue operand alignment/stride"); return SMBV_ERR_ALIGN;
   }
-  if (gemm_nt_ring_ok(lda, ldb, M, N, K, e) && !(g_variant & 256)) return gemm_nt_ring(A, lda, B, ldb, M, N, K, e, (g_variant & 512) ? 4 : 3, st, (g_variant >> 20) & 15);
+  // Kernel choice, measured per shape on MI355X (tools/gemm_ab.py, profiles/r02_gemm_ab.txt): the ring kernel (256 x 128 tiles, two K slices in
+  // flight per block, register epilogue) is 7-19 % ahead where the epilogue is heavy and K short - the GELU / dGELU products, the decoder's
+  // K = 384 projections, the head - and 5-13 % behind the 128 x 128 kernel on long-K or narrow outputs, whose smaller tiles fill the chip better.
+  const bool ring_shape = K <= 768 && N >= 1024;
+  if (gemm_nt_ring_ok(lda, ldb, M, N, K, e) && !(g_variant & 256) && (ring_shape || (g_variant & 131072)))
+    return gemm_nt_ring(A, lda, B, ldb, M, N, K, e, (g_variant & 512) ? 4 : 3, st, (g_variant >> 20) & 15);
   const int tm = cdiv(M, BM), tn = cdiv(N, BN);
   const bool dma_ok = (K % BK == 0) && (N % 8 == 0) && (!e.out_bf16 || ((e.ld_ob & 7) == 0 && ((uintptr_t)e.out_bf16 & 15) == 0)) &&
                       (!e.aux_pre || ((e.ld_aux & 7) == 0 && ((uintptr_t)e.aux_pre & 15) == 0)) &&

@@ -85,7 +85,8 @@ class SyntheticVolumeDataset(Dataset):
 
 def collate_fn(examples):
     """``src/run_mim.py:194-219``."""
-    pixel_values = torch.stack([e["image"] for e in examples])
+    # (a batch of one is a view, not a 335 MB copy: a page-locked volume stays page-locked for the upload)
+    pixel_values = examples[0]["image"].unsqueeze(0) if len(examples) == 1 else torch.stack([e["image"] for e in examples])
     mask = torch.stack([e["mask"] for e in examples])
     # extra keys for the HIP path: the two ascending token lists the reference derives with boolean indexing (spec :134-137, :811-812),
     # built here on the host from the mask that was just generated (the model otherwise sorts on the device every step)

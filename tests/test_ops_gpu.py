@@ -333,14 +333,14 @@ def test_gemm_nt_ring_kernel_matches_reference_and_first_generation(ops, M, N, K
     pre_b = rnd(M, N, seed=7).bfloat16()
     ref = A.float() @ B.float().t()
     runs = {}
-    for v in (0, 256, 512):       # ring with 3 slots (two blocks per CU), first generation, ring with 4 slots
-        raw.smbv_set_variant(v)
+    for v in (131072, 256, 131072 | 512):       # ring with 3 slots (two blocks per CU) forced, first generation forced, ring with 4 slots
+        raw.smbv_debug_set_variant(v)
         try:
             runs[v] = (ops.gemm_nt(A, B, bias=bias, rowadd=resid, out_bf16=True, out_f32=True), ops.gemm_nt(A, B, bias=bias, gelu=True, save_pre=True),
                        ops.gemm_nt(A, B, dgelu_pre=pre_b), ops.gemm_nt(A, B, out_bf16=False, out_f32=True, alpha=0.5))
         finally:
-            raw.smbv_set_variant(0)
-    r0, r1, r2, r3 = runs[0]
+            raw.smbv_debug_set_variant(0)
+    r0, r1, r2, r3 = runs[131072]
     assert rel_err(r0["f32"], ref + bias + resid) < 1e-5 * math.sqrt(K) + 1e-5
     assert rel_err(r1["pre"], ref + bias) < 6e-3
     assert rel_err(r1["bf16"], torch.nn.functional.gelu(r1["pre"].float())) < 6e-3
@@ -348,7 +348,7 @@ def test_gemm_nt_ring_kernel_matches_reference_and_first_generation(ops, M, N, K
     torch.nn.functional.gelu(x).sum().backward()
     assert rel_err(r2["bf16"], ref * x.grad) < 8e-3
     assert rel_err(r3["f32"], 0.5 * ref) < 1e-5 * math.sqrt(K) + 1e-5
-    for v in (256, 512):
-        for a, b in zip(runs[0], runs[v]):
+    for v in (256, 131072 | 512):
+        for a, b in zip(runs[131072], runs[v]):
             for k in a:
                 assert torch.equal(a[k], b[k]), (v, k)

@@ -1,4 +1,4 @@
-"""A/B the attention forward across tuning variants (smbv_set_variant masks): timing + max deviation of O / LSE from the first variant
+"""A/B the attention forward across tuning variants (smbv_debug_set_variant masks): timing + max deviation of O / LSE from the first variant
 and from a float64 torch reference on the small shape.  usage: attn_fwd_ab.py V0,V1,..."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,7 +22,7 @@ for name, S, H, Sq, qoff in (("enc", 7168, 12, 0, 0), ("dec", 20480, 6, 0, 0), (
     outs, res = {}, {v: [] for v in variants}
     for rnd in range(5):
         for v in variants:
-            raw.smbv_set_variant(v)
+            raw.smbv_debug_set_variant(v)
             O, lse = ops.attention_fwd(qkv, 1, S, H, Sq=Sq, q_off=qoff); torch.cuda.synchronize()
             outs[v] = (O.float().clone(), lse.clone())
             res[v].append(timeit(lambda: ops.attention_fwd(qkv, 1, S, H, Sq=Sq, q_off=qoff)))
@@ -38,4 +38,4 @@ for name, S, H, Sq, qoff in (("enc", 7168, 12, 0, 0), ("dec", 20480, 6, 0, 0), (
         Lr = torch.logsumexp(sc, -1)
         extra = "  vs f64: " + "  ".join(f"v{v}: dO={float((outs[v][0].double()-Or).abs().max()):.2e} dLSE={float((outs[v][1][0].double()-Lr).abs().max()):.2e}" for v in variants)
     print(f"{name:9s}: " + "  ".join(f"v{v}: {sorted(res[v])[2]*1e3:8.1f}us {fl/sorted(res[v])[2]/1e9:6.1f}TF" for v in variants) + "  " + dev + extra, flush=True)
-raw.smbv_set_variant(0)
+raw.smbv_debug_set_variant(0)

@@ -1,5 +1,5 @@
 """A/B one part of the attention backward (parts: 2 = dK/dV kernel, 4 = dQ kernel, 6 = both forked) across tuning variants.
-usage: attn_part_ab.py PARTS V0,V1[,V2...]   (variants are smbv_set_variant bit masks; outputs compared bitwise against the first)"""
+usage: attn_part_ab.py PARTS V0,V1[,V2...]   (variants are smbv_debug_set_variant bit masks; outputs compared bitwise against the first)"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -27,7 +27,7 @@ for name, S, H, Sq, qoff in (("enc", 7168, 12, 0, 0), ("dec", 20480, 6, 0, 0), (
     outs, res = {}, {v: [] for v in variants}
     for rnd in range(5):
         for v in variants:
-            raw.smbv_set_variant(v)
+            raw.smbv_debug_set_variant(v)
             out = (torch.zeros_like(qkv), delta)
             ops.attention_bwd(qkv, O, dO, lse, 1, S, H, parts=parts, out=out, Sq=Sq, q_off=qoff); torch.cuda.synchronize()
             outs[v] = out[0].clone()
@@ -35,4 +35,4 @@ for name, S, H, Sq, qoff in (("enc", 7168, 12, 0, 0), ("dec", 20480, 6, 0, 0), (
     fl = nprod * S * sq * 64 * H
     same = all(torch.equal(outs[variants[0]], outs[v]) for v in variants)
     print(f"{name:9s} parts={parts}: " + "  ".join(f"v{v}: {sorted(res[v])[2]*1e3:8.1f}us {fl/sorted(res[v])[2]/1e9:6.1f}TF" for v in variants) + f"  same={same}", flush=True)
-raw.smbv_set_variant(0)
+raw.smbv_debug_set_variant(0)

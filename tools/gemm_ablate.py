@@ -1,4 +1,4 @@
-"""Ablation timings of gemm_nt_ring_kernel (debug bits in smbv_set_variant >> 20: 1 no epilogue, 2 no in-loop copies, 4 no MFMAs, 8 no LDS reads).
+"""Ablation timings of gemm_nt_ring_kernel (debug bits in smbv_debug_set_variant >> 20: 1 no epilogue, 2 no in-loop copies, 4 no MFMAs, 8 no LDS reads).
 Outputs are preallocated: the timed region holds the GEMM launches only."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,13 +37,13 @@ def timeit(fn, iters=30):
 shapes = [(7168, 2304, 768, False), (20480, 1536, 384, True), (7168, 768, 3072, False), (7168, 768, 768, False)]
 for M, N, K, gelu in shapes:
     run, keep = make(M, N, K, gelu)
-    raw.smbv_set_variant(256)
+    raw.smbv_debug_set_variant(256)
     t_old = timeit(run)
     print(f"M{M} N{N} K{K} first-gen 128x128: {t_old:6.1f} us  {2.0*M*N*K/t_old/1e6:6.1f} TF", flush=True)
-    for base, name in ((0, "NS3"), (512, "NS4")):
+    for base, name in ((131072, "NS3"), (131072 | 512, "NS4")):
         row = []
         for dbg in (0, 1, 2, 4, 8, 2 | 1, 4 | 1, 2 | 4 | 8 | 1, 4 | 8 | 1, 2 | 8 | 1, 2 | 4 | 1):
-            raw.smbv_set_variant(base | (dbg << 20))
+            raw.smbv_debug_set_variant(base | (dbg << 20))
             row.append(f"d{dbg}:{timeit(run):6.1f}")
-        raw.smbv_set_variant(0)
+        raw.smbv_debug_set_variant(0)
         print(f"M{M} N{N} K{K} {name}: " + " ".join(row), flush=True)

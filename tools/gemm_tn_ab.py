@@ -20,7 +20,7 @@ for M, N1, N2 in shapes:
     outs, res = {}, {v: [] for v in variants}
     for rnd in range(5):
         for v in variants:
-            raw.smbv_set_variant(v)
+            raw.smbv_debug_set_variant(v)
             outs[v] = ops.gemm_tn(X, Y); torch.cuda.synchronize()
             res[v].append(timeit(lambda: ops.gemm_tn(X, Y)))
     same = all(torch.equal(outs[variants[0]], outs[v]) for v in variants)
@@ -28,4 +28,4 @@ for M, N1, N2 in shapes:
     err = "  ".join(f"v{v}:{float((outs[v] - ref).abs().max() / ref.abs().max()):.1e}" for v in variants)
     f = 2.0 * M * N1 * N2
     print(f"M{M} N1 {N1} N2 {N2}: " + "  ".join(f"v{v}: {sorted(res[v])[2]*1e3:7.1f}us {f/sorted(res[v])[2]/1e9:6.1f}TF" for v in variants) + f"  same={same}  max rel err vs fp32 {err}")
-raw.smbv_set_variant(0)
+raw.smbv_debug_set_variant(0)
