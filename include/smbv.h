@@ -70,6 +70,10 @@ int smbv_gemm_nt(const smbv_bf16* A, int lda, const smbv_bf16* B, int ldb, int M
 int smbv_gemm_tn(const smbv_bf16* X, int ldx, const smbv_bf16* Y, int ldy, int M, int N1, int N2, float* out, void* ws,
                  size_t ws_bytes, smbv_stream stream);
 size_t smbv_gemm_tn_workspace_bytes(int M, int N1, int N2);
+/* the same product plus, from the same pass over X, its column sums xsum[N1] = sum_m X[m, :] - weight and bias gradient of one nn.Linear
+ * (dW = dY^T A, db = sum over tokens of dY) in one launch; ws as above */
+int smbv_gemm_tn_bias(const smbv_bf16* X, int ldx, const smbv_bf16* Y, int ldy, int M, int N1, int N2, float* out, float* xsum, void* ws,
+                      size_t ws_bytes, smbv_stream stream);
 
 /* nn.LayerNorm over the last dim (spec :402-403, :412, :423, :676/:721); y is the bf16 GEMM operand.
  * Input rows are read at (row / grp_in) * grp_out + row % grp_in + row_off when grp_in > 0. */
@@ -126,6 +130,10 @@ typedef struct smbv_mim_cfg {
   int dd, dheads, dff, dlayers;   /* decoder_* */
   float ln_eps;                   /* config.layer_norm_eps (blocks) */
   float dec_norm_eps;             /* decoder.norm eps: torch default 1e-5 (spec :676) */
+  int recompute;                  /* 1 = gradient checkpointing (spec :459-465, torch.utils.checkpoint per layer): keep only every block's input, share
+                                     one activation set per stack and re-run a block's forward in front of its backward.  Same results bit for bit,
+                                     one extra forward of time, ~1/layers of the activation memory */
+  int attn_fp8;                   /* 1 = attention forward with OCP e4m3 operands on the block-scaled fp8 MFMA (BASELINE config 5); 0 = bf16 */
 } smbv_mim_cfg;
 
 /* fp32 tensors of one VideoMAELayer in the pinned-era (vendored) state-dict layout. */

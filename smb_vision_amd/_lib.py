@@ -27,7 +27,7 @@ class GemmEpi(C.Structure):
 class MimCfg(C.Structure):
     _fields_ = [(n, C.c_int) for n in
                 ("B", "T", "H", "W", "ps", "ts", "N", "Nvis", "Nmask", "d", "heads", "ff", "layers", "dd", "dheads", "dff", "dlayers")] + \
-               [("ln_eps", C.c_float), ("dec_norm_eps", C.c_float)]
+               [("ln_eps", C.c_float), ("dec_norm_eps", C.c_float), ("recompute", C.c_int), ("attn_fp8", C.c_int)]
 
 
 LAYER_FIELDS = ("ln1_w", "ln1_b", "q_w", "k_w", "v_w", "q_b", "v_b", "proj_w", "proj_b", "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
@@ -98,6 +98,7 @@ _SIGS = {
     "smbv_gemm_nt": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GemmEpi), c_f]),
     "smbv_gemm_tn": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f, C.c_size_t, c_f]),
     "smbv_gemm_tn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "smbv_gemm_tn_bias": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f, c_f, C.c_size_t, c_f]),
     "smbv_layernorm_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_float, C.c_long, C.c_long, C.c_long, c_f]),
     "smbv_layernorm_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, c_f, C.c_size_t, c_f]),
     "smbv_layernorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),

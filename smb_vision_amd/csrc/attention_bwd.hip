@@ -13,34 +13,12 @@
 // float atomics would be bound by the ~1.3 TB/s atomic rate at S = 20,480: see DESIGN.md).
 #include "smbv_common.h"
 #include "smbv_kernels.h"
-#include <mutex>
+#include "block.h"
 #include <type_traits>
 
 namespace smbv {
 extern int g_variant;
 
-#define HIPRC(x) do { hipError_t _e = (x); if (_e != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(_e)); return (int)_e; } } while (0)
-
-// Host-side fork/join resources: one private non-blocking stream + two events per device, created on first use and kept for
-// the life of the process (no device memory involved).  Stream order is preserved for the caller: everything forked is joined
-// back into the caller's stream before the launching function returns.
-struct ForkJoin {
-  hipStream_t side = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-};
-static ForkJoin* fork_join_for_current_device() {
-  static ForkJoin table[64];
-  static std::mutex mu;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> lk(mu);
-  ForkJoin& f = table[dev];
-  if (!f.side) {
-    if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) { f.side = nullptr; return nullptr; }
-    if (hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&f.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-  }
-  return &f;
-}
 
 // 128-byte-row LDS image usable for ds_read_b128 row reads (16 rows x same chunk) AND ds_read_b64_tr_b16 blocks
 // (4 consecutive rows x 32 B): chunk16 ^= f((row>>1)&7), f(x) = ((x&1)<<2) | (x>>1).

@@ -37,9 +37,29 @@ struct LayerWs {
 
 struct BwdScratch {  // sized for the widest block of the model
   bf16_t *d_act, *d_ln, *d_o, *d_qkv, *gath0, *gath1;
-  float *delta, *gpad;  // gpad: head-padded weight/bias gradients before un-padding (null when no block is padded)
-  void* scratch;        // gemm_tn slabs / LN-bwd partials / colsum partials
+  float *delta, *gpad, *gpad_b;  // gpad / gpad_b: head-padded weight / bias gradients before un-padding (null when no block is padded)
+  void* scratch;        // LN-bwd partials / colsum partials / gemm_tn slabs of the products that stay on the caller's stream
   size_t scratch_bytes;
+  void* wscratch;       // gemm_tn slabs + column-sum partials of the weight-gradient products that run on the side stream
+  size_t wscratch_bytes;
+};
+
+struct ForkJoin {  // streams.hip
+  hipStream_t side = nullptr, wside = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr, wfork = nullptr, wjoin = nullptr;
+  bool ready = false;
+};
+ForkJoin* fork_join_for_current_device();
+
+// The library's per-device weight-gradient side stream (streams.hip).  begin(): work enqueued on `st` afterwards
+// starts only after everything enqueued on the caller's stream so far; end(): the caller's stream waits for all side work.  With the debug
+// variant bit 16384 (or if the stream cannot be created) `st` IS the caller's stream and both calls do nothing.
+struct SideStream {
+  hipStream_t st = nullptr;
+  void* impl = nullptr;
+  bool used = false;
+  int begin(hipStream_t caller);
+  int end(hipStream_t caller);
 };
 
 struct Carver {
@@ -67,12 +87,15 @@ struct PrepList {
   void tcast(const float* src, bf16_t* dst, int R, int C, int ldd) { add(src, dst, R, C, C, ldd, 1); }
 };
 
-void carve_layer(Carver& c, LayerWs& L, const BlockDims& d);
+void carve_layer(Carver& c, LayerWs& L, const BlockDims& d, const LayerWs* share_acts = nullptr);
 size_t layer_prep_job_count(const BlockDims& d);
 // appends this block's weight-preparation jobs; for padded heads also enqueues the zero fills of the padded buffers on `st`
 int prep_layer(PrepList& pl, const BlockPtrs& p, LayerWs& L, const BlockDims& d, hipStream_t st);
-void bwd_scratch_requirements(const BlockDims& d, size_t& act_elems, size_t& w_elems, size_t& qkv_elems, size_t& gpad_elems, size_t& scratch_bytes,
-                              size_t& delta_elems);
+struct BwdNeeds {  // running maxima over the blocks of a model (elements, except scratch / wscratch: bytes)
+  size_t act = 0, we = 0, qkv = 0, gpad = 0, gpad_b = 0, delta = 0, scratch = 0, wscratch = 0;
+};
+void bwd_scratch_requirements(const BlockDims& d, BwdNeeds& n);
+void carve_bwd_scratch(Carver& cv, BwdScratch& sc, const BwdNeeds& n);  // everything of BwdScratch except gath0 / gath1
 
 // Sq > 0: only tokens qoff..qoff+Sq-1 of every sequence are needed downstream (see mim_step.hip); 0 = all tokens.
 int layer_fwd(const BlockPtrs& p, LayerWs& L, const BlockDims& d, BwdScratch& sc, const float* x_in, float* x_out, bf16_t* x_out_bf16, int Sq, int qoff,

@@ -3,8 +3,9 @@
 
 namespace smbv {
 
-void carve_layer(Carver& c, LayerWs& L, const BlockDims& d) {
+void carve_layer(Carver& c, LayerWs& L, const BlockDims& d, const LayerWs* share_acts) {
   const size_t w = d.w, wa = d.wa(), ff = d.ff, rows = d.rows;
+  if (share_acts) L = *share_acts;  // recompute mode: ONE set of activation buffers for all blocks of a stack; the weight copies stay per block
   L.wqkv = c.take<bf16_t>(3 * wa * w);
   L.wqkv_t = c.take<bf16_t>(3 * wa * w);
   L.proj = c.take<bf16_t>(w * wa);
@@ -14,6 +15,7 @@ void carve_layer(Carver& c, LayerWs& L, const BlockDims& d) {
   L.fc2 = c.take<bf16_t>(ff * w);
   L.fc2_t = c.take<bf16_t>(ff * w);
   L.bqkv = c.take<float>(3 * wa);
+  if (share_acts) return;
   L.ln1 = c.take<bf16_t>(rows * w);
   L.qkv = c.take<bf16_t>(rows * 3 * wa);
   L.attn_o = c.take<bf16_t>(rows * wa);
@@ -75,18 +77,30 @@ int prep_layer(PrepList& pl, const BlockPtrs& p, LayerWs& L, const BlockDims& d,
   return SMBV_OK;
 }
 
-void bwd_scratch_requirements(const BlockDims& d, size_t& act_elems, size_t& w_elems, size_t& qkv_elems, size_t& gpad_elems, size_t& scratch_bytes,
-                              size_t& delta_elems) {
+void bwd_scratch_requirements(const BlockDims& d, BwdNeeds& n) {
   const size_t rows = d.rows, w = d.w, wa = d.wa(), ff = d.ff;
-  act_elems = std::max(act_elems, rows * ff);
-  w_elems = std::max(w_elems, rows * std::max(w, wa));
-  qkv_elems = std::max(qkv_elems, rows * 3 * wa);
-  if (d.padded()) gpad_elems = std::max(gpad_elems, 3 * wa * w);
-  delta_elems = std::max(delta_elems, (size_t)d.B * d.H * d.S);
-  auto tn = [&](size_t M, size_t n1, size_t n2) { scratch_bytes = std::max(scratch_bytes, gemm_tn_workspace_bytes((int)M, (int)n1, (int)n2)); };
-  tn(rows, w, ff); tn(rows, ff, w); tn(rows, w, wa); tn(rows, 3 * wa, w);
-  scratch_bytes = std::max(scratch_bytes, layernorm_bwd_workspace_bytes((int)rows, (int)w));
-  scratch_bytes = std::max(scratch_bytes, colsum_workspace_bytes((int)rows, (int)std::max(ff, 3 * wa)));
+  n.act = std::max(n.act, rows * ff);
+  n.we = std::max(n.we, rows * std::max(w, wa));
+  n.qkv = std::max(n.qkv, rows * 3 * wa);
+  if (d.padded()) { n.gpad = std::max(n.gpad, 3 * wa * w); n.gpad_b = std::max(n.gpad_b, 3 * wa); }
+  n.delta = std::max(n.delta, (size_t)d.B * d.H * d.S);
+  auto tn = [&](size_t M, size_t n1, size_t n2) { n.wscratch = std::max(n.wscratch, gemm_tn_workspace_bytes((int)M, (int)n1, (int)n2)); };
+  tn(rows, w, ff); tn(rows, ff, w); tn(rows, w, wa); tn(rows, 3 * wa, w); tn(rows, w, w);
+  n.scratch = std::max(n.scratch, layernorm_bwd_workspace_bytes((int)rows, (int)w));
+}
+
+void carve_bwd_scratch(Carver& cv, BwdScratch& sc, const BwdNeeds& n) {
+  sc.d_act = cv.take<bf16_t>(n.act);
+  sc.d_ln = cv.take<bf16_t>(n.we);
+  sc.d_o = cv.take<bf16_t>(n.we);
+  sc.d_qkv = cv.take<bf16_t>(n.qkv);
+  sc.delta = cv.take<float>(n.delta);
+  sc.gpad = n.gpad ? cv.take<float>(n.gpad) : nullptr;
+  sc.gpad_b = n.gpad_b ? cv.take<float>(n.gpad_b) : nullptr;
+  sc.scratch = cv.take<char>(n.scratch);
+  sc.scratch_bytes = n.scratch;
+  sc.wscratch = cv.take<char>(n.wscratch);
+  sc.wscratch_bytes = n.wscratch;
 }
 
 int layer_fwd(const BlockPtrs& p, LayerWs& L, const BlockDims& d, BwdScratch& sc, const float* x_in, float* x_out, bf16_t* x_out_bf16, int Sq, int qoff,
@@ -138,34 +152,35 @@ int layer_fwd(const BlockPtrs& p, LayerWs& L, const BlockDims& d, BwdScratch& sc
   return SMBV_OK;
 }
 
-// colsum of a (possibly head-padded) [M, H*64] column block into a compact [H*Dh] gradient
-static int bias_grad(const bf16_t* X, int ld, int M, const BlockDims& d, float* out, BwdScratch& sc, hipStream_t st) {
-  if (!out) return SMBV_OK;
-  if (!d.padded()) return colsum_bf16(X, ld, M, d.w, out, 0, 0, 0, sc.scratch, sc.scratch_bytes, st);
-  RC(colsum_bf16(X, ld, M, d.wa(), sc.gpad, 0, 0, 0, sc.scratch, sc.scratch_bytes, st));
-  return map_copy_f32(out, sc.gpad, (size_t)d.w, d.Dh, 64, st);
-}
-
 int layer_bwd(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDims& d, BwdScratch& sc, const float* x_in, float* g, bf16_t* gb, float* g2,
               bf16_t* gb2, int Sq, int qoff, hipStream_t st) {
   const int w = d.w, ff = d.ff, wa = d.wa(), B = d.B, S = d.S, H = d.H;
   const int M = (int)d.rows;
   const bool ranged = Sq > 0;
   const int Mq = ranged ? B * Sq : M;
+  SideStream side;
   // ---- MLP (on the ranged rows only when Sq > 0: ln2 / pre / act are compact then) ----
   const bf16_t* gbc = gb;
   if (ranged) {
     gbc = gb + (size_t)qoff * w;  // contiguous for B == 1
     if (B > 1) { RC(gather_rows_bf16(gb, sc.gath0, Mq, w, Sq, S, qoff, st)); gbc = sc.gath0; }
   }
-  RC(colsum_bf16(gbc, w, Mq, w, gr.fc2_b, 0, 0, 0, sc.scratch, sc.scratch_bytes, st));
-  RC(gemm_tn(gbc, w, L.act, ff, Mq, w, ff, gr.fc2_w, sc.scratch, sc.scratch_bytes, st));
+  // weight (+ bias: the column sums ride along, gemm.hip) gradients go to the side stream; the input-gradient product they share dY with
+  // stays on `st` - the two run side by side and fill each other's tails
+  RC(side.begin(st));
+  {
+    TnColsum cs; cs.dst[0] = gr.fc2_b; cs.seg = w;
+    RC(gemm_tn(gbc, w, L.act, ff, Mq, w, ff, gr.fc2_w, sc.wscratch, sc.wscratch_bytes, side.st, &cs));
+  }
   {
     GemmEpi e; e.dgelu_pre = L.pre; e.ld_pre = ff; e.out_bf16 = sc.d_act; e.ld_ob = ff;
     RC(gemm_nt(gbc, w, L.fc2_t, w, Mq, ff, w, e, st));
   }
-  RC(colsum_bf16(sc.d_act, ff, Mq, ff, gr.fc1_b, 0, 0, 0, sc.scratch, sc.scratch_bytes, st));
-  RC(gemm_tn(sc.d_act, ff, L.ln2, w, Mq, ff, w, gr.fc1_w, sc.scratch, sc.scratch_bytes, st));
+  RC(side.begin(st));  // d_act is ready
+  {
+    TnColsum cs; cs.dst[0] = gr.fc1_b; cs.seg = ff;
+    RC(gemm_tn(sc.d_act, ff, L.ln2, w, Mq, ff, w, gr.fc1_w, sc.wscratch, sc.wscratch_bytes, side.st, &cs));
+  }
   {
     GemmEpi e; e.out_bf16 = sc.d_ln; e.ld_ob = w;
     RC(gemm_nt(sc.d_act, ff, L.fc1_t, ff, Mq, w, ff, e, st));
@@ -185,17 +200,21 @@ int layer_bwd(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDi
     g2c = gb2 + (size_t)qoff * w;
     aoc = L.attn_o + (size_t)qoff * wa;
     if (B > 1) {
+      RC(side.end(st));  // the MLP weight-gradient products read the gathered rows these two copies overwrite
       RC(gather_rows_bf16(gb2, sc.gath0, Mq, w, Sq, S, qoff, st));
       RC(gather_rows_bf16(L.attn_o, sc.gath1, Mq, wa, Sq, S, qoff, st));
       g2c = sc.gath0; aoc = sc.gath1;
     }
   }
-  RC(colsum_bf16(g2c, w, Mq, w, gr.proj_b, 0, 0, 0, sc.scratch, sc.scratch_bytes, st));
-  if (!d.padded()) {
-    RC(gemm_tn(g2c, w, aoc, wa, Mq, w, wa, gr.proj_w, sc.scratch, sc.scratch_bytes, st));
-  } else {
-    RC(gemm_tn(g2c, w, aoc, wa, Mq, w, wa, sc.gpad, sc.scratch, sc.scratch_bytes, st));   // [w, H*64] -> [w, H*Dh]
-    RC(map_copy_f32(gr.proj_w, sc.gpad, (size_t)w * w, d.Dh, 64, st));
+  RC(side.begin(st));  // gb2 (and, ranged, its gathered copy) is ready
+  {
+    TnColsum cs; cs.dst[0] = gr.proj_b; cs.seg = w;
+    if (!d.padded()) {
+      RC(gemm_tn(g2c, w, aoc, wa, Mq, w, wa, gr.proj_w, sc.wscratch, sc.wscratch_bytes, side.st, &cs));
+    } else {
+      RC(gemm_tn(g2c, w, aoc, wa, Mq, w, wa, sc.gpad, sc.wscratch, sc.wscratch_bytes, side.st, &cs));   // [w, H*64] -> [w, H*Dh]
+      RC(map_copy_f32(gr.proj_w, sc.gpad, (size_t)w * w, d.Dh, 64, side.st));
+    }
   }
   {
     GemmEpi e; e.out_bf16 = sc.d_o; e.ld_ob = wa;
@@ -208,24 +227,34 @@ int layer_bwd(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDi
                    S, H, 64, d.scale(), 7, Sq, qoff, st));
   if (d.rope_grid > 0) RC(rope3d(sc.d_qkv, 3 * wa, wa, M, S, H, 64, d.Dh, d.rope_grid, d.pos, d.rope_table, 1, st));
   // ---- QKV ----
-  RC(bias_grad(sc.d_qkv, 3 * wa, M, d, gr.q_b, sc, st));
-  RC(bias_grad(sc.d_qkv + wa, 3 * wa, M, d, gr.k_b, sc, st));
-  RC(bias_grad(sc.d_qkv + 2 * wa, 3 * wa, M, d, gr.v_b, sc, st));
+  // (the three products forked above had the whole attention backward to finish: joining them here costs nothing and makes every later
+  // write on `st` - LN1 backward rewrites g / gb - safe whatever the scheduling of the two queues)
+  RC(side.end(st));
+  RC(side.begin(st));  // d_qkv is ready
   const size_t ww = (size_t)w * w;
   const bool contiguous = gr.k_w == gr.q_w + ww && gr.v_w == gr.k_w + ww;
   if (!d.padded()) {
     if (contiguous) {
-      RC(gemm_tn(sc.d_qkv, 3 * w, L.ln1, w, M, 3 * w, w, gr.q_w, sc.scratch, sc.scratch_bytes, st));
+      TnColsum cs; cs.dst[0] = gr.q_b; cs.dst[1] = gr.k_b; cs.dst[2] = gr.v_b; cs.seg = w;   // VideoMAE has no key bias: null drops that segment
+      RC(gemm_tn(sc.d_qkv, 3 * w, L.ln1, w, M, 3 * w, w, gr.q_w, sc.wscratch, sc.wscratch_bytes, side.st, &cs));
     } else {
-      RC(gemm_tn(sc.d_qkv, 3 * w, L.ln1, w, M, w, w, gr.q_w, sc.scratch, sc.scratch_bytes, st));
-      RC(gemm_tn(sc.d_qkv + w, 3 * w, L.ln1, w, M, w, w, gr.k_w, sc.scratch, sc.scratch_bytes, st));
-      RC(gemm_tn(sc.d_qkv + 2 * w, 3 * w, L.ln1, w, M, w, w, gr.v_w, sc.scratch, sc.scratch_bytes, st));
+      float* wdst[3] = {gr.q_w, gr.k_w, gr.v_w};
+      float* bdst[3] = {gr.q_b, gr.k_b, gr.v_b};
+      for (int sec = 0; sec < 3; sec++) {
+        TnColsum cs; cs.dst[0] = bdst[sec]; cs.seg = w;
+        RC(gemm_tn(sc.d_qkv + sec * w, 3 * w, L.ln1, w, M, w, w, wdst[sec], sc.wscratch, sc.wscratch_bytes, side.st, bdst[sec] ? &cs : nullptr));
+      }
     }
   } else {
-    RC(gemm_tn(sc.d_qkv, 3 * wa, L.ln1, w, M, 3 * wa, w, sc.gpad, sc.scratch, sc.scratch_bytes, st));   // [3*H*64, w]
+    // head-padded layout (head_dim < 64): sums and products land in the padded scratch, then the real columns are compacted
+    TnColsum cs; cs.dst[0] = sc.gpad_b; cs.seg = 3 * wa;
+    RC(gemm_tn(sc.d_qkv, 3 * wa, L.ln1, w, M, 3 * wa, w, sc.gpad, sc.wscratch, sc.wscratch_bytes, side.st, &cs));   // [3*H*64, w]
     float* dst[3] = {gr.q_w, gr.k_w, gr.v_w};
-    for (int sec = 0; sec < 3; sec++)
-      RC(map_copy_f32(dst[sec], sc.gpad + (size_t)sec * wa * w, ww, (long)d.Dh * w, (long)64 * w, st));
+    float* bdst[3] = {gr.q_b, gr.k_b, gr.v_b};
+    for (int sec = 0; sec < 3; sec++) {
+      RC(map_copy_f32(dst[sec], sc.gpad + (size_t)sec * wa * w, ww, (long)d.Dh * w, (long)64 * w, side.st));
+      if (bdst[sec]) RC(map_copy_f32(bdst[sec], sc.gpad_b + (size_t)sec * wa, (size_t)w, d.Dh, 64, side.st));
+    }
   }
   {
     GemmEpi e; e.out_bf16 = sc.d_ln; e.ld_ob = w;
@@ -233,6 +262,9 @@ int layer_bwd(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDi
   }
   // ---- LN1 (+ residual) over all rows: g = g2 + LNbwd(d_ln) ----
   RC(layernorm_bwd(sc.d_ln, x_in, L.mean1, L.rstd1, p.ln1_w, g2, g, gb, gr.ln1_w, gr.ln1_b, M, w, 0, 0, 0, sc.scratch, sc.scratch_bytes, st));
+  // join: this block's parameter gradients are final on `st` (the caller records the data-parallel event next), and every buffer the side
+  // products read (gb, d_act, gb2, d_qkv, the saved activations) may be overwritten by the next block
+  RC(side.end(st));
   return SMBV_OK;
 }
 

@@ -70,6 +70,14 @@ int smbv_gemm_tn(const smbv_bf16* X, int ldx, const smbv_bf16* Y, int ldy, int M
   return gemm_tn(X, ldx, Y, ldy, M, N1, N2, out, ws, ws_bytes, (hipStream_t)stream);
 }
 size_t smbv_gemm_tn_workspace_bytes(int M, int N1, int N2) { return gemm_tn_workspace_bytes(M, N1, N2); }
+int smbv_gemm_tn_bias(const smbv_bf16* X, int ldx, const smbv_bf16* Y, int ldy, int M, int N1, int N2, float* out, float* xsum, void* ws, size_t ws_bytes,
+                      smbv_stream stream) {
+  if (!X || !Y || !out || !xsum) { set_error("smbv_gemm_tn_bias: null operand"); return SMBV_ERR_ARG; }
+  TnColsum cs;
+  cs.dst[0] = xsum;
+  cs.seg = N1;
+  return gemm_tn(X, ldx, Y, ldy, M, N1, N2, out, ws, ws_bytes, (hipStream_t)stream, &cs);
+}
 
 int smbv_layernorm_fwd(const float* x, const float* gamma, const float* beta, smbv_bf16* y, float* mean, float* rstd, int rows, int D, float eps,
                        long grp_in, long grp_out, long row_off, smbv_stream stream) {

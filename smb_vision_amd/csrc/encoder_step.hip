@@ -54,21 +54,14 @@ static void carve(const smbv_encoder_cfg& c, void* base, EncWs& w) {
     w.g1 = cv.take<float>(R * c.d);
     w.gb0 = cv.take<bf16_t>(R * c.d);
     w.gb1 = cv.take<bf16_t>(R * c.d);
-    size_t act = 0, we = 0, qkv = 0, gpad = 0, sb = 0, delta = 0;
-    bwd_scratch_requirements(de, act, we, qkv, gpad, sb, delta);
-    sb = std::max(sb, gemm_tn_workspace_bytes((int)R, c.d, K));
-    sb = std::max(sb, colsum_workspace_bytes((int)R, std::max(c.d, K)));
+    BwdNeeds nd;
+    bwd_scratch_requirements(de, nd);
+    nd.scratch = std::max(nd.scratch, gemm_tn_workspace_bytes((int)R, c.d, K));
+    nd.scratch = std::max(nd.scratch, colsum_workspace_bytes((int)R, std::max(c.d, K)));
     w.sc = BwdScratch{};
-    w.sc.d_act = cv.take<bf16_t>(act);
-    w.sc.d_ln = cv.take<bf16_t>(we);
-    w.sc.d_o = cv.take<bf16_t>(we);
-    w.sc.d_qkv = cv.take<bf16_t>(qkv);
+    carve_bwd_scratch(cv, w.sc, nd);
     w.sc.gath0 = cv.take<bf16_t>(16);
     w.sc.gath1 = cv.take<bf16_t>(16);
-    w.sc.delta = cv.take<float>(delta);
-    w.sc.gpad = nullptr;
-    w.sc.scratch = cv.take<char>(sb);
-    w.sc.scratch_bytes = sb;
     w.total = (cv.off + 255) & ~(size_t)255;
     return;
   }
@@ -179,8 +172,10 @@ static int encoder_backward(const smbv_encoder_cfg& c, const smbv_encoder_tensor
     RC(layer_bwd(blk(p, l), blk(gr, l), W.L[l], de, W.sc, W.x[l], g, gb, g2, gb2, 0, 0, st));
     // layer_bwd leaves the gradient w.r.t. its input in (g, gb) again (see block.h)
   }
-  RC(colsum_bf16(gb, c.d, (int)R, c.d, gr.pe_b, 0, 0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
-  RC(gemm_tn(gb, c.d, W.a_patch, K, (int)R, c.d, K, gr.pe_w, W.sc.scratch, W.sc.scratch_bytes, st));
+  {
+    TnColsum cs; cs.dst[0] = gr.pe_b; cs.seg = c.d;
+    RC(gemm_tn(gb, c.d, W.a_patch, K, (int)R, c.d, K, gr.pe_w, W.sc.scratch, W.sc.scratch_bytes, st, &cs));
+  }
   (void)io;
   return SMBV_OK;
 }

@@ -330,9 +330,17 @@ int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, in
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int sw_tn(int m) { return (m & 3) | (((m >> 3) & 1) << 2); }
 
+// Bias gradient from the same pass: the column sums of X over the tokens are one more product, X^T * ones.  Blocks of the first N2 tile
+// accumulate it with two extra MFMAs per wave and K-step (an all-ones A operand: every row of that accumulator tile holds the sums) on the
+// X fragments they already hold - the separate column-sum passes over dY (two launches and a full re-read per linear) are gone.
+__device__ __forceinline__ bf16x8 ones_frag() {
+  const u32x4 o = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  return __builtin_bit_cast(bf16x8, o);
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y,
                                                       int ldy, int M, int N1, int N2, float* __restrict__ out, int ldo,
-                                                      int tiles_1, int mchunk, size_t slab_stride) {
+                                                      int tiles_1, int mchunk, size_t slab_stride, float* __restrict__ xsum) {
   // LDS: [buf][X|Y][64 m][128 n] bf16 (256-B rows) = 2*2*16 KiB
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * BK * 128 * 2];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
@@ -348,6 +356,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
   for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_sum = xsum != nullptr && tile_2 == 0;
+  f32x4 accb[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 
   u32x4 rx[4], ry[4];
   auto gload = [&](int kt) {
@@ -407,11 +417,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
 #pragma unroll
         for (int j = 0; j < 4; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[j], xf[i], acc[i][j], 0, 0, 0);  // D[n2][n1]
+      if (do_sum) {
+        accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_frag(), w2 ? xf[2] : xf[0], accb[0], 0, 0, 0);
+        accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_frag(), w2 ? xf[3] : xf[1], accb[1], 0, 0, 0);
+      }
     }
     if (kt + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
   }
 
+  if (do_sum && l < 16) {  // wave (w1, w2) owns column tiles 2 w2, 2 w2 + 1 of its n1 slice
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int n1 = a0 + w1 * 64 + (2 * w2 + k) * 16 + l;
+      if (n1 < N1) xsum[(size_t)z * N1 + n1] = accb[k][0];
+    }
+  }
   float* o = out + (size_t)z * slab_stride;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -430,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
 // applied to the per-lane source address; rows beyond this split's token range read as zeros through the buffer bounds check.
 __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y, int ldy,
                                                              int M, int N1, int N2, float* __restrict__ out, int ldo, int tiles_1,
-                                                             int mchunk, size_t slab_stride) {
+                                                             int mchunk, size_t slab_stride, float* __restrict__ xsum) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * BK * 128 * 2];
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -476,6 +497,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
   for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_sum = xsum != nullptr && tile_2 == 0;
+  f32x4 accb[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 
   if (nk > 0) stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -509,11 +532,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
 #pragma unroll
         for (int j = 0; j < 4; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[j], xf[i], acc[i][j], 0, 0, 0);  // D[n2][n1]
+      if (do_sum) {
+        accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_frag(), w2 ? xf[2] : xf[0], accb[0], 0, 0, 0);
+        accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_frag(), w2 ? xf[3] : xf[1], accb[1], 0, 0, 0);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next K-step's copy had this step's MFMAs to land
     __syncthreads();
   }
 
+  if (do_sum && l < 16) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) xsum[(size_t)z * N1 + a0 + w1 * 64 + (2 * w2 + k) * 16 + l] = accb[k][0];
+  }
   float* o = out + (size_t)z * slab_stride;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -534,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
 // into slabs so that tiles x slabs fills one round of 256 blocks; slabs are summed by reduce_slabs_kernel in slab order.
 __global__ __launch_bounds__(512, 1) void gemm_tn_256_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y, int ldy,
                                                               int M, int N1, int N2, float* __restrict__ out, int ldo, int tiles_1,
-                                                              int mchunk, size_t slab_stride) {
+                                                              int mchunk, size_t slab_stride, float* __restrict__ xsum) {
   constexpr int SLICE = 2 * 32 * 512;  // X image | Y image
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * SLICE];
   const int t = threadIdx.x, l = t & 63;
@@ -574,6 +605,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_256_kernel(const bf16_t* __res
   for (int i = 0; i < 8; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_sum = xsum != nullptr && tile_2 == 0;  // wave (w1, w2) sums column tiles 2 w2, 2 w2 + 1 of its 128-wide n1 slice
+  f32x4 accb[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 
   const int g = l >> 4, q = (l >> 2) & 3, p = l & 3;
   const int mA = 8 * g + q, mB = mA + 4;
@@ -604,6 +637,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_256_kernel(const bf16_t* __res
       xf[i] = __builtin_bit_cast(bf16x8, xx);
     }
   };
+  auto bias_mfma = [&](const bf16x8* xf) __attribute__((always_inline)) {
+    // static fragment indices (a runtime-indexed register array would go to scratch): select by w2
+    const bf16x8 xa = w2 == 0 ? xf[0] : (w2 == 1 ? xf[2] : (w2 == 2 ? xf[4] : xf[6]));
+    const bf16x8 xb = w2 == 0 ? xf[1] : (w2 == 1 ? xf[3] : (w2 == 2 ? xf[5] : xf[7]));
+    accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_frag(), xa, accb[0], 0, 0, 0);
+    accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_frag(), xb, accb[1], 0, 0, 0);
+  };
   stage(0); stage(1); stage(2);
   bf16x8 xf[8], yf[4];
   if (w1 == 0) {
@@ -619,6 +659,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_256_kernel(const bf16_t* __res
       for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[j], xf[i], acc[i][j], 0, 0, 0);  // D[n2][n1]
+      if (do_sum) bias_mfma(xf);
       __builtin_amdgcn_s_setprio(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -637,11 +678,16 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_256_kernel(const bf16_t* __res
       for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[j], xf[i], acc[i][j], 0, 0, 0);
+      if (do_sum) bias_mfma(xf);
       __builtin_amdgcn_s_setprio(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 
+  if (do_sum && l < 16) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) xsum[(size_t)z * N1 + a0 + w1 * 128 + (2 * w2 + k) * 16 + l] = accb[k][0];
+  }
   float* o = out + (size_t)z * slab_stride;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -705,45 +751,58 @@ int gemm_tn_splits(int M, int N1, int N2) {
 
 size_t gemm_tn_workspace_bytes(int M, int N1, int N2) {
   const int s = std::max(gemm_tn_splits(M, N1, N2), (N1 % 256 == 0 && N2 % 256 == 0) ? gemm_tn_splits_256(M, N1, N2) : 1);
-  return s > 1 ? (size_t)s * N1 * N2 * sizeof(float) : 0;
+  // slabs (when the token range is split) + the per-slab column sums of X (bias gradient), 256-B aligned behind them
+  return (s > 1 ? (((size_t)s * N1 * N2 * sizeof(float) + 255) & ~(size_t)255) : 0) + (size_t)s * N1 * sizeof(float);
 }
 
-int gemm_tn(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int M, int N1, int N2, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
+// bias gradient: out segment k (seg columns each, up to 3 destinations, null = dropped) = sum over slabs of the column sums
+__global__ void reduce_xsum_kernel(const float* __restrict__ part, int nslab, int N1, TnColsum dst) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N1) return;
+  float s = 0.f;
+  for (int z = 0; z < nslab; z++) s += part[(size_t)z * N1 + n];  // slab order: reproducible
+  float* d = dst.dst[n / dst.seg];
+  if (d) d[n % dst.seg] = s;
+}
+
+int gemm_tn(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int M, int N1, int N2, float* out, void* ws, size_t ws_bytes, hipStream_t st,
+            const TnColsum* colsum) {
   if (M <= 0 || N1 <= 0 || N2 <= 0) { set_error("gemm_tn: empty problem"); return SMBV_ERR_SHAPE; }
   if ((N1 & 7) || (N2 & 7) || (ldx & 7) || (ldy & 7)) { set_error("gemm_tn: N1,N2,ldx,ldy must be multiples of 8 (N1=%d N2=%d ldx=%d ldy=%d)", N1, N2, ldx, ldy); return SMBV_ERR_SHAPE; }
   if (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)out) & 15) { set_error("gemm_tn: operands must be 16-byte aligned"); return SMBV_ERR_ALIGN; }
-  if (gemm_tn_use_256(M, N1, N2) && ((size_t)M * ldx * 2 < (1ull << 31)) && ((size_t)M * ldy * 2 < (1ull << 31))) {
-    const int s2 = gemm_tn_splits_256(M, N1, N2);
-    const int mchunk2 = cdiv(cdiv(M, s2), 32) * 32;
-    const size_t need2 = (size_t)s2 * N1 * N2 * sizeof(float);
-    if (s2 > 1 && (!ws || ws_bytes < need2 || ((uintptr_t)ws & 15))) { set_error("gemm_tn: workspace too small (%zu < %zu)", ws_bytes, need2); return SMBV_ERR_WORKSPACE; }
-    hipLaunchKernelGGL(gemm_tn_256_kernel, dim3((N1 / 256) * (N2 / 256), s2), dim3(512), 0, st, X, ldx, Y, ldy, M, N1, N2, s2 > 1 ? (float*)ws : out, N2, N1 / 256,
-                       mchunk2, s2 > 1 ? (size_t)N1 * N2 : (size_t)0);
-    int rc2 = check_launch("gemm_tn_256");
-    if (rc2 || s2 == 1) return rc2;
-    const size_t n4b = (size_t)N1 * N2 / 4;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)std::min<size_t>(2048, (n4b + 255) / 256)), dim3(256), 0, st, out, (const float*)ws, s2, n4b, n4b);
-    return check_launch("reduce_slabs");
+  if (colsum && (colsum->seg <= 0 || N1 % colsum->seg || N1 / colsum->seg > 3)) { set_error("gemm_tn: column-sum segments %d do not tile N1=%d", colsum->seg, N1); return SMBV_ERR_ARG; }
+  const bool small32 = ((size_t)M * ldx * 2 < (1ull << 31)) && ((size_t)M * ldy * 2 < (1ull << 31));
+  const bool big = gemm_tn_use_256(M, N1, N2) && small32;
+  const int s = big ? gemm_tn_splits_256(M, N1, N2) : gemm_tn_splits(M, N1, N2);
+  const size_t slab_bytes = s > 1 ? (((size_t)s * N1 * N2 * sizeof(float) + 255) & ~(size_t)255) : 0;
+  const size_t need = slab_bytes + (colsum ? (size_t)s * N1 * sizeof(float) : 0);
+  if (need && (!ws || ws_bytes < need || ((uintptr_t)ws & 15))) { set_error("gemm_tn: workspace too small (%zu < %zu)", ws_bytes, need); return SMBV_ERR_WORKSPACE; }
+  float* slabs = s > 1 ? (float*)ws : out;
+  float* xs = colsum ? (float*)((char*)ws + slab_bytes) : nullptr;
+  const size_t stride = s > 1 ? (size_t)N1 * N2 : (size_t)0;
+  if (big) {
+    const int mchunk = cdiv(cdiv(M, s), 32) * 32;
+    hipLaunchKernelGGL(gemm_tn_256_kernel, dim3((N1 / 256) * (N2 / 256), s), dim3(512), 0, st, X, ldx, Y, ldy, M, N1, N2, slabs, N2, N1 / 256, mchunk, stride, xs);
+  } else {
+    const int t1 = cdiv(N1, 128), t2 = cdiv(N2, 128);
+    const bool dma = (N1 % 128 == 0) && (N2 % 128 == 0) && small32 && !(g_variant & 32);
+    const int mchunk = cdiv(cdiv(M, s), 64) * 64;
+    if (dma) hipLaunchKernelGGL(gemm_tn_dma_kernel, dim3(t1 * t2, s), dim3(256), 0, st, X, ldx, Y, ldy, M, N1, N2, slabs, N2, t1, mchunk, stride, xs);
+    else hipLaunchKernelGGL(gemm_tn_kernel, dim3(t1 * t2, s), dim3(256), 0, st, X, ldx, Y, ldy, M, N1, N2, slabs, N2, t1, mchunk, stride, xs);
   }
-  const int s = gemm_tn_splits(M, N1, N2);
-  const int t1 = cdiv(N1, 128), t2 = cdiv(N2, 128);
-  const bool dma = (N1 % 128 == 0) && (N2 % 128 == 0) && ((size_t)M * ldx * 2 < (1ull << 31)) && ((size_t)M * ldy * 2 < (1ull << 31)) && !(g_variant & 32);
-  if (s == 1) {
-    if (dma) hipLaunchKernelGGL(gemm_tn_dma_kernel, dim3(t1 * t2, 1), dim3(256), 0, st, X, ldx, Y, ldy, M, N1, N2, out, N2, t1, ((M + 63) / 64) * 64, (size_t)0);
-    else hipLaunchKernelGGL(gemm_tn_kernel, dim3(t1 * t2, 1), dim3(256), 0, st, X, ldx, Y, ldy, M, N1, N2, out, N2, t1, ((M + 63) / 64) * 64, (size_t)0);
-    return check_launch("gemm_tn");
-  }
-  const size_t need = (size_t)s * N1 * N2 * sizeof(float);
-  if (!ws || ws_bytes < need || ((uintptr_t)ws & 15)) { set_error("gemm_tn: workspace too small (%zu < %zu)", ws_bytes, need); return SMBV_ERR_WORKSPACE; }
-  int mchunk = cdiv(cdiv(M, s), 64) * 64;
-  if (dma) hipLaunchKernelGGL(gemm_tn_dma_kernel, dim3(t1 * t2, s), dim3(256), 0, st, X, ldx, Y, ldy, M, N1, N2, (float*)ws, N2, t1, mchunk, (size_t)N1 * N2);
-  else hipLaunchKernelGGL(gemm_tn_kernel, dim3(t1 * t2, s), dim3(256), 0, st, X, ldx, Y, ldy, M, N1, N2, (float*)ws, N2, t1, mchunk, (size_t)N1 * N2);
   int rc = check_launch("gemm_tn");
   if (rc) return rc;
-  const size_t n4 = (size_t)N1 * N2 / 4;
-  const int grid = (int)std::min<size_t>(2048, (n4 + 255) / 256);
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, st, out, (const float*)ws, s, n4, n4);
-  return check_launch("reduce_slabs");
+  if (s > 1) {
+    const size_t n4 = (size_t)N1 * N2 / 4;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)std::min<size_t>(2048, (n4 + 255) / 256)), dim3(256), 0, st, out, (const float*)ws, s, n4, n4);
+    rc = check_launch("reduce_slabs");
+    if (rc) return rc;
+  }
+  if (colsum) {
+    hipLaunchKernelGGL(reduce_xsum_kernel, dim3(cdiv(N1, 256)), dim3(256), 0, st, (const float*)xs, s, N1, *colsum);
+    rc = check_launch("reduce_xsum");
+  }
+  return rc;
 }
 
 }  // namespace smbv

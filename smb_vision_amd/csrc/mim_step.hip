@@ -60,8 +60,9 @@ static void carve(const smbv_mim_cfg& c, void* base, MimWs& w) {
   w.e2d_t = cv.take<bf16_t>((size_t)c.dd * c.d);
   w.head = cv.take<bf16_t>((size_t)K * c.dd);
   w.head_t = cv.take<bf16_t>((size_t)K * c.dd);
-  for (int l = 0; l < c.layers; l++) carve_layer(cv, w.enc[l], de);
-  for (int l = 0; l < c.dlayers; l++) carve_layer(cv, w.dec[l], dd);
+  // recompute (gradient checkpointing, spec :459-465): the blocks of a stack share one activation set; only their inputs x[l] are kept
+  for (int l = 0; l < c.layers; l++) carve_layer(cv, w.enc[l], de, (c.recompute && l > 0) ? &w.enc[0] : nullptr);
+  for (int l = 0; l < c.dlayers; l++) carve_layer(cv, w.dec[l], dd, (c.recompute && l > 0) ? &w.dec[0] : nullptr);
   w.a_patch = cv.take<bf16_t>(R * K);
   for (int l = 0; l <= c.layers; l++) w.x[l] = cv.take<float>(R * c.d);
   for (int l = 0; l <= c.dlayers; l++) w.xd[l] = cv.take<float>(Rd * c.dd);
@@ -80,23 +81,16 @@ static void carve(const smbv_mim_cfg& c, void* base, MimWs& w) {
   w.gb1 = cv.take<bf16_t>(gw);
   w.dlogits = cv.take<bf16_t>(Rm * K);
   w.d_vis = cv.take<bf16_t>(R * c.dd);
-  size_t act = 0, we = 0, qkv = 0, gpad = 0, sb = 0, delta = 0;
-  bwd_scratch_requirements(de, act, we, qkv, gpad, sb, delta);
-  bwd_scratch_requirements(dd, act, we, qkv, gpad, sb, delta);
-  auto tn = [&](size_t M, int n1, int n2) { sb = std::max(sb, gemm_tn_workspace_bytes((int)M, n1, n2)); };
+  BwdNeeds nd;
+  bwd_scratch_requirements(de, nd);
+  bwd_scratch_requirements(dd, nd);
+  auto tn = [&](size_t M, int n1, int n2) { nd.scratch = std::max(nd.scratch, gemm_tn_workspace_bytes((int)M, n1, n2)); };
   tn(R, c.d, K); tn(R, c.dd, c.d); tn(Rm, K, c.dd);
-  sb = std::max(sb, layernorm_bwd_workspace_bytes((int)Rm, c.dd));
-  sb = std::max(sb, colsum_workspace_bytes((int)std::max(R, Rd), std::max(std::max(c.d, c.dd), K)));
-  w.sc.d_act = cv.take<bf16_t>(act);
-  w.sc.d_ln = cv.take<bf16_t>(we);
-  w.sc.d_o = cv.take<bf16_t>(we);
-  w.sc.d_qkv = cv.take<bf16_t>(qkv);
+  nd.scratch = std::max(nd.scratch, layernorm_bwd_workspace_bytes((int)Rm, c.dd));
+  nd.scratch = std::max(nd.scratch, colsum_workspace_bytes((int)std::max(R, Rd), std::max(std::max(c.d, c.dd), K)));
+  carve_bwd_scratch(cv, w.sc, nd);
   w.sc.gath0 = cv.take<bf16_t>(Rm * c.dd);
   w.sc.gath1 = cv.take<bf16_t>(Rm * c.dd);
-  w.sc.delta = cv.take<float>(delta);
-  w.sc.gpad = gpad ? cv.take<float>(gpad) : nullptr;
-  w.sc.scratch = cv.take<char>(sb);
-  w.sc.scratch_bytes = sb;
   w.total = (cv.off + 255) & ~(size_t)255;
 }
 
@@ -173,8 +167,10 @@ static int mim_backward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const 
 
   RC(mse_bwd(io.pixel_values, io.mask_idx, (int)Rm, c.Nmask, W.bmean, W.brinv, io.logits, W.dlogits, io.grad_scale, c.T, c.H, c.W, c.ts, c.ps, st));
   // head
-  RC(colsum_bf16(W.dlogits, K, (int)Rm, K, gr.head_b, 0, 0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
-  RC(gemm_tn(W.dlogits, K, W.lnf, c.dd, (int)Rm, K, c.dd, gr.head_w, W.sc.scratch, W.sc.scratch_bytes, st));
+  {
+    TnColsum cs; cs.dst[0] = gr.head_b; cs.seg = K;   // bias gradient = column sums of dlogits, from the same pass
+    RC(gemm_tn(W.dlogits, K, W.lnf, c.dd, (int)Rm, K, c.dd, gr.head_w, W.sc.scratch, W.sc.scratch_bytes, st, &cs));
+  }
   {
     GemmEpi e; e.out_bf16 = W.sc.d_ln; e.ld_ob = c.dd;
     RC(gemm_nt(W.dlogits, K, W.head_t, K, (int)Rm, c.dd, K, e, st));
@@ -187,6 +183,8 @@ static int mim_backward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const 
   RC(mark());
   for (int l = c.dlayers - 1; l >= 0; l--) {
     const bool last = l == c.dlayers - 1;  // its forward only produced the masked tokens (see mim_forward)
+    // recompute: rebuild this block's activations from its saved input (the last block's are still in the shared set)
+    if (c.recompute && !last) RC(layer_fwd(to_block(p.dec[l]), W.dec[l], dd, W.sc, W.xd[l], W.xd[l + 1], nullptr, 0, 0, st));
     RC(layer_bwd(to_block(p.dec[l]), to_block(gr.dec[l]), W.dec[l], dd, W.sc, W.xd[l], W.g0, W.gb0, W.g1, W.gb1, last ? c.Nmask : 0, last ? c.Nvis : 0, st));
     RC(mark());
   }
@@ -200,12 +198,16 @@ static int mim_backward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const 
   }
   RC(mark());
   for (int l = c.layers - 1; l >= 0; l--) {
+    // recompute: the decoder ran after the encoder and does not touch the encoder's shared set, so the last encoder block's activations survive
+    if (c.recompute && l != c.layers - 1) RC(layer_fwd(to_block(p.enc[l]), W.enc[l], de, W.sc, W.x[l], W.x[l + 1], nullptr, 0, 0, st));
     RC(layer_bwd(to_block(p.enc[l]), to_block(gr.enc[l]), W.enc[l], de, W.sc, W.x[l], W.g1, W.gb1, W.g0, W.gb0, 0, 0, st));
     RC(mark());
   }
   // patch embedding (the volume needs no gradient)
-  RC(colsum_bf16(W.gb1, c.d, (int)R, c.d, gr.pe_b, 0, 0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
-  RC(gemm_tn(W.gb1, c.d, W.a_patch, K, (int)R, c.d, K, gr.pe_w, W.sc.scratch, W.sc.scratch_bytes, st));
+  {
+    TnColsum cs; cs.dst[0] = gr.pe_b; cs.seg = c.d;
+    RC(gemm_tn(W.gb1, c.d, W.a_patch, K, (int)R, c.d, K, gr.pe_w, W.sc.scratch, W.sc.scratch_bytes, st, &cs));
+  }
   RC(mark());
   return SMBV_OK;
 }

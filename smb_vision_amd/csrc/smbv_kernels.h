@@ -31,7 +31,14 @@ int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, in
 // second-generation NT kernel (gemm_nt_ring.hip): 256 x 128 tiles, LDS ring of K slices, register epilogue; gemm_nt dispatches to it
 bool gemm_nt_ring_ok(int lda, int ldb, int M, int N, int K, const GemmEpi& e);
 int gemm_nt_ring(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, int slots, hipStream_t st, int dbg = 0);
-int gemm_tn(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int M, int N1, int N2, float* out, void* ws, size_t ws_bytes, hipStream_t st);
+// optional by-product of gemm_tn: the column sums of X over the M rows (the bias gradient of the linear whose weight gradient this is),
+// written as up to three segments of `seg` columns (fused q | k | v: three bias tensors; a null destination drops its segment)
+struct TnColsum {
+  float* dst[3] = {nullptr, nullptr, nullptr};
+  int seg = 0;
+};
+int gemm_tn(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int M, int N1, int N2, float* out, void* ws, size_t ws_bytes, hipStream_t st,
+            const TnColsum* colsum = nullptr);
 size_t gemm_tn_workspace_bytes(int M, int N1, int N2);
 
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd, int rows, int D, float eps,

@@ -1,0 +1,54 @@
+// Host-side fork/join resources of the library: per device, two private non-blocking streams and their events, created on first use and
+// kept for the life of the process (no device memory involved; declared in include/smbv.h's conventions).
+//   side  : attention backward runs its dQ kernel here beside dK/dV (attention_bwd.hip)
+//   wside : the block backward runs its weight-gradient products here beside the input-gradient ones (block.hip, SideStream)
+// Stream order is preserved for the caller: everything forked is joined back into the caller's stream before the forking function returns
+// (attention) / before the block's gradients are declared final (block backward).
+#include "block.h"
+#include <mutex>
+
+namespace smbv {
+extern int g_variant;
+
+ForkJoin* fork_join_for_current_device() {
+  static ForkJoin table[64];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  ForkJoin& f = table[dev];
+  if (!f.ready) {
+    if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipStreamCreateWithFlags(&f.wside, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    hipEvent_t* ev[4] = {&f.fork, &f.join, &f.wfork, &f.wjoin};
+    for (auto e : ev)
+      if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    f.ready = true;
+  }
+  return &f;
+}
+
+int SideStream::begin(hipStream_t caller) {
+  if (!impl) {
+    ForkJoin* fj = (g_variant & 16384) ? nullptr : fork_join_for_current_device();
+    impl = fj;
+    st = fj ? fj->wside : caller;
+  }
+  ForkJoin* fj = (ForkJoin*)impl;
+  if (!fj) { st = caller; return SMBV_OK; }
+  HIPRC(hipEventRecord(fj->wfork, caller));
+  HIPRC(hipStreamWaitEvent(fj->wside, fj->wfork, 0));
+  used = true;
+  return SMBV_OK;
+}
+
+int SideStream::end(hipStream_t caller) {
+  ForkJoin* fj = (ForkJoin*)impl;
+  if (!fj || !used) return SMBV_OK;
+  HIPRC(hipEventRecord(fj->wjoin, fj->wside));
+  HIPRC(hipStreamWaitEvent(caller, fj->wjoin, 0));
+  used = false;
+  return SMBV_OK;
+}
+
+}  // namespace smbv

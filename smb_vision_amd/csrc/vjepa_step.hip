@@ -95,22 +95,15 @@ static void vcarve(const smbv_vjepa_cfg& c, void* base, VjepaWs& w) {
   w.d_lnfull = cv.take<bf16_t>(gw);
   w.d_ctx = cv.take<bf16_t>(Rc * c.pd);
   w.d_encctx = cv.take<bf16_t>(Rc * c.d);
-  size_t act = 0, we = 0, qkv = 0, gpad = 0, sb = 0, delta = 0;
-  bwd_scratch_requirements(de, act, we, qkv, gpad, sb, delta);
-  bwd_scratch_requirements(dp, act, we, qkv, gpad, sb, delta);
-  auto tn = [&](size_t M, int n1, int n2) { sb = std::max(sb, gemm_tn_workspace_bytes((int)M, n1, n2)); };
+  BwdNeeds nd;
+  bwd_scratch_requirements(de, nd);
+  bwd_scratch_requirements(dp, nd);
+  auto tn = [&](size_t M, int n1, int n2) { nd.scratch = std::max(nd.scratch, gemm_tn_workspace_bytes((int)M, n1, n2)); };
   tn(Re, c.d, K); tn(Rc, c.pd, c.d); tn(Rt, c.d, c.pd);
-  sb = std::max(sb, colsum_workspace_bytes((int)std::max(Re, Rp), std::max(std::max(c.d, c.pd), K)));
-  w.sc.d_act = cv.take<bf16_t>(act);
-  w.sc.d_ln = cv.take<bf16_t>(we);
-  w.sc.d_o = cv.take<bf16_t>(we);
-  w.sc.d_qkv = cv.take<bf16_t>(qkv);
+  nd.scratch = std::max(nd.scratch, colsum_workspace_bytes((int)std::max(Re, Rp), std::max(std::max(c.d, c.pd), K)));
+  carve_bwd_scratch(cv, w.sc, nd);
   w.sc.gath0 = nullptr;
   w.sc.gath1 = nullptr;
-  w.sc.delta = cv.take<float>(delta);
-  w.sc.gpad = gpad ? cv.take<float>(gpad) : nullptr;
-  w.sc.scratch = cv.take<char>(sb);
-  w.sc.scratch_bytes = sb;
   w.total = (cv.off + 255) & ~(size_t)255;
 }
 
@@ -188,8 +181,10 @@ static int vjepa_backward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, 
   const int Sp = c.Nctx + c.Ntgt;
   // predictor.proj
   RC(cast_f32_bf16(io.d_pred, W.dpred_bf, Rt * c.d, st));
-  RC(colsum_bf16(W.dpred_bf, c.d, (int)Rt, c.d, gr.pproj_b, 0, 0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
-  RC(gemm_tn(W.dpred_bf, c.d, W.tgt_bf, c.pd, (int)Rt, c.d, c.pd, gr.pproj_w, W.sc.scratch, W.sc.scratch_bytes, st));
+  {
+    TnColsum cs; cs.dst[0] = gr.pproj_b; cs.seg = c.d;
+    RC(gemm_tn(W.dpred_bf, c.d, W.tgt_bf, c.pd, (int)Rt, c.d, c.pd, gr.pproj_w, W.sc.scratch, W.sc.scratch_bytes, st, &cs));
+  }
   {
     GemmEpi e; e.out_bf16 = W.d_tgt; e.ld_ob = c.pd;
     RC(gemm_nt(W.dpred_bf, c.d, W.pproj_t, c.d, (int)Rt, c.pd, c.d, e, st));
@@ -208,8 +203,10 @@ static int vjepa_backward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, 
   RC(gather_rows_idx_f32(W.g0, W.gtmp, io.tgt_slot, (long)Rt, c.Ntgt, Sp, c.pd, st));
   RC(colsum_f32(W.gtmp, c.pd, (int)Rt, c.pd, gr.mask_token, 0, 0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
   RC(gather_rows_idx_bf16(W.gb0, W.d_ctx, io.ctx_slot, (long)Rc, c.Nctx, Sp, c.pd, st));
-  RC(colsum_bf16(W.d_ctx, c.pd, (int)Rc, c.pd, gr.pemb_b, 0, 0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
-  RC(gemm_tn(W.d_ctx, c.pd, W.ctx_bf, c.d, (int)Rc, c.pd, c.d, gr.pemb_w, W.sc.scratch, W.sc.scratch_bytes, st));
+  {
+    TnColsum cs; cs.dst[0] = gr.pemb_b; cs.seg = c.pd;
+    RC(gemm_tn(W.d_ctx, c.pd, W.ctx_bf, c.d, (int)Rc, c.pd, c.d, gr.pemb_w, W.sc.scratch, W.sc.scratch_bytes, st, &cs));
+  }
   {
     GemmEpi e; e.out_bf16 = W.d_encctx; e.ld_ob = c.d;
     RC(gemm_nt(W.d_ctx, c.pd, W.pemb_t, c.pd, (int)Rc, c.d, c.pd, e, st));
@@ -232,8 +229,10 @@ static int vjepa_backward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, 
     RC(mark());  // [players+3 ..] encoder layers, last first
   }
   // patch embedding
-  RC(colsum_bf16(W.gb0, c.d, (int)Re, c.d, gr.pe_b, 0, 0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
-  RC(gemm_tn(W.gb0, c.d, W.a_patch, K, (int)Re, c.d, K, gr.pe_w, W.sc.scratch, W.sc.scratch_bytes, st));
+  {
+    TnColsum cs; cs.dst[0] = gr.pe_b; cs.seg = c.d;
+    RC(gemm_tn(W.gb0, c.d, W.a_patch, K, (int)Re, c.d, K, gr.pe_w, W.sc.scratch, W.sc.scratch_bytes, st, &cs));
+  }
   RC(mark());  // [last] patch embedding
   return SMBV_OK;
 }

@@ -169,7 +169,7 @@ class SmbVideoMAEForPreTraining(PreTrainedModel):
         self.tubelet_size = int(config.tubelet_size)
         self.num_patches = (self.image_size[1] // self.patch_size[1]) * (self.image_size[0] // self.patch_size[0]) * (
             config.num_frames // self.tubelet_size)
-        self.gradient_checkpointing = False  # accepted for API compatibility; activations stay resident (288 GB HBM)
+        self.gradient_checkpointing = False  # see _use_recompute
         # non-persistent, device-resident state
         self._pos = None          # (pos_enc, pos_dec) on the parameter device
         self._gflat = None        # flat fp32 gradient arena; param.grad are views into it
@@ -226,8 +226,7 @@ class SmbVideoMAEForPreTraining(PreTrainedModel):
         self.gradient_checkpointing = enable
 
     def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None):
-        # HF Trainer calls this with --gradient_checkpointing (trainer.py:1401).  Accepted and recorded; the HIP path keeps all
-        # activations of the step resident in HBM (~5 GB at ViT-base, 512x512x320), so nothing is recomputed.
+        # HF Trainer calls this with --gradient_checkpointing (trainer.py:1401); see _use_recompute for what it switches on.
         self.gradient_checkpointing = True
 
     def gradient_checkpointing_disable(self):
@@ -264,7 +263,30 @@ class SmbVideoMAEForPreTraining(PreTrainedModel):
                                             c.decoder_num_hidden_layers)
         s.ln_eps = c.layer_norm_eps
         s.dec_norm_eps = 1e-5
+        s.recompute = int(self._use_recompute(s))
+        s.attn_fp8 = int(bool(getattr(c, "smbv_attention_fp8", False)))
         return s
+
+    def _use_recompute(self, cfg) -> bool:
+        """``gradient_checkpointing_enable()`` (HF Trainer ``--gradient_checkpointing``, which the reference's scripts always pass) asks for the
+        per-layer recompute of spec :459-465.  Results are bit-identical either way; recomputing costs one more forward.  Policy
+        ``config.smbv_recompute``: "always" / "never" / "auto" (default): recompute only when keeping every block's activations would take more
+        than 60 % of the device's memory - on a 288 GB MI355X ViT-base / ViT-large at batch 1-4 stay resident."""
+        if not self.gradient_checkpointing:
+            return False
+        policy = getattr(self.config, "smbv_recompute", "auto")
+        if policy in ("always", True):
+            return True
+        if policy in ("never", False):
+            return False
+        key = (cfg.B, cfg.Nmask)
+        cache = self.__dict__.setdefault("_recompute_auto", {})
+        if key not in cache:
+            cfg.recompute = 0
+            need = _lib.load().smbv_mim_workspace_bytes(C.byref(cfg))
+            total = torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory if torch.cuda.is_available() else 0
+            cache[key] = bool(total and need > 0.6 * total)
+        return cache[key]
 
     def _ordered_params(self):
         sd = dict(self.named_parameters())
@@ -363,7 +385,7 @@ class SmbVideoMAEForPreTraining(PreTrainedModel):
         need = lib.smbv_mim_workspace_bytes(C.byref(cfg))
         if need == 0:
             raise ValueError("smbv_mim_workspace_bytes: " + _lib.last_error())
-        key = (B, n_masked, dev)
+        key = (B, n_masked, dev, cfg.recompute, cfg.attn_fp8)
         if self._ws is None or self._ws_key != key or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)

@@ -71,6 +71,19 @@ def gemm_tn(X, Y):
     return out
 
 
+def gemm_tn_bias(X, Y):
+    """(X^T @ Y fp32 [N1,N2], column sums of X fp32 [N1]): weight and bias gradient of a linear in one launch."""
+    _need_gpu(X, Y)
+    lib = _lib.load()
+    M, N1 = X.shape
+    N2 = Y.shape[1]
+    out = torch.empty(N1, N2, dtype=torch.float32, device=X.device)
+    xs = torch.empty(N1, dtype=torch.float32, device=X.device)
+    ws = _ws(lib.smbv_gemm_tn_workspace_bytes(M, N1, N2), X.device)
+    check(lib.smbv_gemm_tn_bias(_p(X), X.stride(0), _p(Y), Y.stride(0), M, N1, N2, _p(out), _p(xs), _p(ws), ws.numel(), _stream()), "smbv_gemm_tn_bias")
+    return out, xs
+
+
 def layernorm_fwd(x, gamma, beta, eps, rows=None, grp=(0, 0, 0)):
     _need_gpu(x, gamma, beta)
     lib = _lib.load()

@@ -100,6 +100,11 @@ def test_step_matches_oracle_mid_size_and_is_deterministic():
     # tighter: against the oracle with the same bf16 rounding points
     e_loss, e_logits, e_grads = mim_step(params, cfg, pix, mask, emulate_bf16=True)
     assert abs(float(loss) - float(e_loss)) <= 1e-3 * float(e_loss)
+    d = logits - e_logits
+    e_rms = float(d.pow(2).mean().sqrt()) / float(e_logits.pow(2).mean().sqrt())
+    worst_e = check_against(loss, logits, grads, e_loss, e_logits, e_grads, tl=1e-3, tg=1.5e-2)   # same rounding points: tighter than vs fp32
+    print("vs bf16-emulating oracle: logits rms", e_rms, "worst grad", worst_e)
+    assert e_rms <= 5e-3
     # bitwise reproducible (no float atomics anywhere in the step)
     loss2, logits2, grads2 = run_step(model, pix, mask)
     assert torch.equal(loss, loss2) and torch.equal(logits, logits2)
@@ -161,3 +166,30 @@ def test_hf_trainer_runs_the_drop_in(tmp_path):
     from smb_vision_amd.modeling_videomae import SmbVideoMAEForPreTraining
     m = SmbVideoMAEForPreTraining.from_pretrained(str(tmp_path))
     assert m.config.num_frames == 32
+
+
+def test_gradient_checkpointing_recompute_is_bitwise_identical_and_smaller():
+    """config.smbv_recompute = "always" + gradient_checkpointing_enable(): per-layer recompute (reference spec :459-465, torch.utils.checkpoint per
+    VideoMAELayer) - the blocks of a stack share one activation set and each block's forward re-runs in front of its backward.  Same kernels on
+    the same inputs: loss, logits and every gradient bit for bit; the workspace shrinks."""
+    c = dict(image_size=128, num_frames=64, patch_size=16, tubelet_size=16, hidden_size=128, num_hidden_layers=4, num_attention_heads=2,
+             intermediate_size=512, decoder_hidden_size=64, decoder_num_hidden_layers=3, decoder_num_attention_heads=1, decoder_intermediate_size=256)
+    cfg = MIMConfig(**c)
+    params = init_params(cfg, seed=9, nonzero_small=True)
+    from smb_vision_amd.masking import MaskGenerator
+    np.random.seed(4)
+    gen = MaskGenerator(128, 64, 16, 16, 0.6)
+    mask = torch.stack([gen(), gen()])
+    pix = torch.rand(2, 64, 1, 128, 128, generator=torch.Generator().manual_seed(6))
+    res, sizes = [], []
+    for policy in ("never", "always", "auto"):
+        model = build_model(c, params)
+        model.config.smbv_recompute = policy
+        model.gradient_checkpointing_enable()
+        res.append(run_step(model, pix, mask))
+        sizes.append(model._ws.numel())
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1])
+        for k in res[0][2]:
+            assert torch.equal(res[0][2][k], other[2][k]), k
+    assert sizes[1] < 0.75 * sizes[0] and sizes[2] == sizes[0]     # "auto" keeps activations resident when they fit (they do here)

@@ -352,3 +352,18 @@ def test_gemm_nt_ring_kernel_matches_reference_and_first_generation(ops, M, N, K
         for a, b in zip(runs[131072], runs[v]):
             for k in a:
                 assert torch.equal(a[k], b[k]), (v, k)
+
+
+@pytest.mark.parametrize("M,N1,N2", [(300, 136, 72), (4096, 128, 128), (7168, 768, 3072), (4100, 3072, 768), (2000, 2304, 768), (26, 64, 4096)])
+def test_gemm_tn_bias_column_sums_ride_along(ops, M, N1, N2):
+    """smbv_gemm_tn_bias: weight gradient AND bias gradient (column sums of dY) of a linear from ONE pass - the sums are an extra X^T * ones MFMA
+    product inside the blocks of the first N2 tile (register-staged, LDS-DMA and 256 x 256 kernels, with and without token slabs)."""
+    X = rnd(M, N1, seed=11).bfloat16()
+    Y = rnd(M, N2, seed=12).bfloat16()
+    out, xs = ops.gemm_tn_bias(X, Y)
+    assert torch.equal(out, ops.gemm_tn(X, Y))
+    ref = X.float().sum(0)
+    assert float((xs - ref).abs().max()) <= 2e-6 * M * float(X.float().abs().max()) + 1e-6
+    assert rel_err(xs, ref) < 1e-5 * math.sqrt(M) + 1e-6 or float(ref.abs().max()) < 1.0
+    out2, xs2 = ops.gemm_tn_bias(X, Y)
+    assert torch.equal(xs, xs2) and torch.equal(out, out2)
