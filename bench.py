@@ -296,6 +296,8 @@ def main():
     ap.add_argument("--vjepa", action="store_true", help="BASELINE.json config 4: the V-JEPA train step (diagnostic line; not the metric)")
     ap.add_argument("--vit-large", action="store_true", help="BASELINE.json config 5's model in bf16 (encoder 1024/24L/16H/4096; decoder 512/12L/8H/2048 - the reference "
                                                                "specifies none, SURVEY.md 8d) - diagnostic; not the metric")
+    ap.add_argument("--fp8", action="store_true", help="attention forward on the block-scaled fp8 MFMA (config.smbv_attention_fp8; BASELINE config 5 with --vit-large) - diagnostic")
+    ap.add_argument("--recompute", action="store_true", help="gradient checkpointing: per-layer recompute (config.smbv_recompute = always) - diagnostic")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse the N>1 path on one GPU)")
     args = ap.parse_args()
 
@@ -331,7 +333,13 @@ def main():
     if args.vit_large:
         cfg_kw.update(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, decoder_hidden_size=512,
                       decoder_num_hidden_layers=12, decoder_num_attention_heads=8, decoder_intermediate_size=2048)
+    if args.fp8:
+        cfg_kw["smbv_attention_fp8"] = True
+    if args.recompute:
+        cfg_kw["smbv_recompute"] = "always"
     model, pix, mask, gen = build(rank, device, cfg_kw)
+    if args.recompute:
+        model.gradient_checkpointing_enable()
     n_masked = gen.num_masked
     params = [p for p in model.parameters()]
     opt = None
@@ -402,10 +410,11 @@ def main():
         line = {
             "metric": "MIM train-step volumes/sec (512x512x320, ViT-base)", "value": value, "unit": "volumes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if not args.fp8 else "bf16 (attention forward fp8 e4m3)", "data": "synthetic",
             "config": {"workload": "ViT-base MIM, 512x512x320 volume, patch_size=16, mask_ratio=0.65 (mask_patch 32), B=1/GPU, "
                                    "fwd+loss+bwd+clip+AdamW, volume resident in HBM" + ("" if opt is not None else " [NO OPTIMIZER: diagnostic]")
-                                   + (" [TINY: diagnostic]" if args.tiny else "") + (" [ViT-LARGE bf16: diagnostic, 64.41 TFLOP/volume]" if args.vit_large else ""),
+                                   + (" [TINY: diagnostic]" if args.tiny else "") + (" [ViT-LARGE: diagnostic, 64.41 TFLOP/volume]" if args.vit_large else "")
+                                   + (" [fp8 e4m3 attention forward: diagnostic]" if args.fp8 else "") + (" [per-layer recompute]" if args.recompute else ""),
                        "tokens": model.num_patches, "masked": n_masked, "parallelism": f"dp{world}", "final_loss": final_loss,
                        "resident_ms_per_step": ms, "replicas_in_sync": in_sync},
         }
@@ -432,7 +441,7 @@ def main():
                                         "flop_per_launch": 4 * unit},
                                 "dq": {"launch_ms": kr["dq"], "executed": 3 * unit / (kr["dq"] * 1e-3) / 1e12},
                                 "step": {"achieved": step_tf, "flop_per_volume_T": step_flop, "frac": step_tf / MFMA_PEAK_TFLOPS}}
-        if world == 1 and not args.no_trainer and not args.tiny and not args.vit_large:
+        if world == 1 and not args.no_trainer and not args.tiny and not args.vit_large and not args.fp8 and not args.recompute:
             try:
                 line["config"]["trainer_ms_per_step"] = trainer_ms_per_step(cfg_kw)
             except Exception as e:

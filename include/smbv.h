@@ -90,6 +90,12 @@ size_t smbv_layernorm_bwd_workspace_bytes(int rows, int D);
  * (The last decoder block only needs its masked tokens' outputs: spec :717-718 keeps hidden_states[:, -return_token_num:].) */
 int smbv_attention_fwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, smbv_bf16* O, int ldo, float* LSE,
                        int B, int S, int H, int Dh, float scale, int Sq, int q_off, smbv_stream stream);
+/* The same forward with OCP e4m3 operands on the block-scaled fp8 MFMA (BASELINE.json config 5: "fp8 MFMA QK^T / PV"): Q (pre-scaled), K per
+ * (token, head, 32 channels) and V per (channel, 32 keys) under power-of-two E8M0 scales, P in e4m3 under a fixed 2^-7 scale; fp32 softmax and
+ * accumulation.  ws: smbv_attention_fp8_workspace_bytes(B, S, H) bytes, 256-B aligned (the quantised operands).  Feeds the bf16 backward above. */
+size_t smbv_attention_fp8_workspace_bytes(int B, int S, int H);
+int smbv_attention_fwd_fp8(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, smbv_bf16* O, int ldo, float* LSE, int B, int S, int H,
+                           int Dh, float scale, int Sq, int q_off, void* ws, size_t ws_bytes, smbv_stream stream);
 int smbv_attention_bwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* dO,
                        int ldo, const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S,
                        int H, int Dh, float scale, int parts /* bit0 delta, bit1 dK/dV, bit2 dQ; 7 = all */, int Sq, int q_off, smbv_stream stream);

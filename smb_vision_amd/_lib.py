@@ -103,6 +103,8 @@ _SIGS = {
     "smbv_layernorm_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, c_f, C.c_size_t, c_f]),
     "smbv_layernorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "smbv_attention_fwd": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, c_f]),
+    "smbv_attention_fp8_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "smbv_attention_fwd_fp8": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, c_f, C.c_size_t, c_f]),
     "smbv_attention_bwd": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, c_f]),
     "smbv_prepare_volume": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, c_f]),
     "smbv_gather_bricks": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),

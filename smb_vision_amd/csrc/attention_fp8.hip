@@ -1,0 +1,279 @@
+// Attention forward with OCP e4m3 operands on the block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, 2x the bf16 matrix rate):
+// BASELINE.json config 5 ("ViT-large MIM, fp8 MFMA QK^T / PV").  Same function as attention_fwd.hip - softmax(Q K^T * scale) V per head,
+// head_dim 64, fp32 online softmax, LSE out (reference src/models/videomae/modeling_videomae.py:196-223) - with Q, K, V and P rounded to
+// e4m3 under power-of-two (E8M0) block scales, MX style:
+//   * quant_qk_fp8_kernel: Q (pre-multiplied by scale * log2 e, so scores leave the MFMA in the exp2 domain) and K, one scale per
+//     (token, head, 32 channels) - the 32 contraction elements one lane feeds the MFMA;
+//   * quant_vt_fp8_kernel: V transposed to [batch, head, channel][key] with one scale per (channel, 32 keys), the keys of every 64-key
+//     group stored in the order the P operand holds them (below), so both operands of P V are plain 32-byte row reads;
+//   * attn_fwd_fp8_kernel: 4 waves x 32 queries, 64-key tiles.  S^T = K Q^T is ONE MFMA per 32 keys (K = 64 channels = the two lane halves
+//     x 32 bytes), query on the lane: row max / sum are lane-local plus one v_permlane32_swap; the exponentiated accumulator, scaled by 2^7
+//     and converted to e4m3 in register order, IS the B operand of O^T += V^T P^T (its E8M0 scale 2^-7 undoes the factor) - lane half h of the
+//     two S^T tiles holds keys 32 t + 8 g + 4 h + e (t tile, g = 0..3, e = 0..3) in bytes 16 t + 4 g + e, and V^T is stored in that key order.
+// The operand maps were pinned on hardware by tools/probe/fp8_probe.hip: lane (r = l & 31, h = l >> 5) feeds row / column r and 32 of the
+// 64 contraction elements; byte j of half h meets byte j of the other operand's half h; one E8M0 scale byte per lane per operand.
+// The backward stays on the bf16 kernels (attention_bwd.hip) with this forward's LSE.  Stated tolerance: tests/test_fp8_gpu.py.
+#include "smbv_common.h"
+#include "smbv_kernels.h"
+
+namespace smbv {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ int e8m0_for(float amax) {
+  // smallest power of two 2^e with amax / 2^e <= 448 (e4m3 max); stored biased by 127
+  if (!(amax > 0.f)) return 127;
+  const int e = (int)ceilf(__log2f(amax * (1.0f / 448.0f)));
+  return min(max(e, -126), 127) + 127;
+}
+__device__ __forceinline__ float e8m0_inv(int byte) { return __uint_as_float((unsigned)(254 - byte) << 23); }  // 2^-(byte-127)
+
+// bf16 [rows, ld] column block `col0 .. col0 + w` -> e4m3 [rows, w] + E8M0 scales [rows, w / 32]; premul folded in before rounding
+__global__ __launch_bounds__(256) void quant_qk_fp8_kernel(const bf16_t* __restrict__ X, int ld, long rows, int w, float premul,
+                                                           unsigned char* __restrict__ X8, unsigned char* __restrict__ sX) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const int per_row = w >> 3;
+  const long row = gid / per_row;
+  const int c8 = (int)(gid % per_row);
+  float v[8];
+  float amax = 0.f;
+  if (row < rows) {
+    const u32x4 raw = *(const u32x4*)(X + row * ld + c8 * 8);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { v[2 * i] = bf_lo(raw[i]) * premul; v[2 * i + 1] = bf_hi(raw[i]) * premul; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) amax = fmaxf(amax, fabsf(v[i]));
+  }
+  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));  // 4 threads = 32 channels = one scale block
+  amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+  if (row >= rows) return;
+  const int sb = e8m0_for(amax);
+  const float inv = e8m0_inv(sb);
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
+  *(u32x2*)(X8 + row * w + c8 * 8) = (u32x2){(unsigned)lo, (unsigned)hi};
+  if ((c8 & 3) == 0) sX[row * (w >> 5) + (c8 >> 2)] = (unsigned char)sb;
+}
+
+// V bf16 [B*S, ld] (head h at columns 64 h ..) -> V8T e4m3 [B, H, 64 channels][Spad keys, permuted inside 64-key groups] + scales
+// sV [B, H, 64][Spad / 64][2].  One block = one (64-key group, head, batch); thread (d = t >> 1, half = t & 1) owns one scale block.
+__global__ __launch_bounds__(128) void quant_vt_fp8_kernel(const bf16_t* __restrict__ V, int ld, int S, int Spad, int H,
+                                                           unsigned char* __restrict__ V8T, unsigned char* __restrict__ sV) {
+  __shared__ unsigned short tile[64][66];
+  const int t = threadIdx.x, grp = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  for (int i = t; i < 64 * 8; i += 128) {  // 64 keys x 8 chunks of 8 channels
+    const int key = i >> 3, c = i & 7;
+    const int gk = grp * 64 + key;
+    u32x4 raw = {0, 0, 0, 0};
+    if (gk < S) raw = *(const u32x4*)(V + ((size_t)b * S + gk) * ld + head * 64 + c * 8);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { tile[key][c * 8 + 2 * j] = (unsigned short)(raw[j] & 0xffff); tile[key][c * 8 + 2 * j + 1] = (unsigned short)(raw[j] >> 16); }
+  }
+  __syncthreads();
+  const int d = t >> 1, h = t & 1;
+  float v[32];
+  float amax = 0.f;
+#pragma unroll
+  for (int p = 0; p < 32; p++) {  // byte p = 16 tt + 4 g + e  <->  key 32 tt + 8 g + 4 h + e
+    const int key = 32 * (p >> 4) + 8 * ((p >> 2) & 3) + 4 * h + (p & 3);
+    v[p] = bf2f(tile[key][d]);
+    amax = fmaxf(amax, fabsf(v[p]));
+  }
+  const int sb = e8m0_for(amax);
+  const float inv = e8m0_inv(sb);
+  unsigned out[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    int wv = 0;
+    wv = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * q] * inv, v[4 * q + 1] * inv, wv, false);
+    wv = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * q + 2] * inv, v[4 * q + 3] * inv, wv, true);
+    out[q] = (unsigned)wv;
+  }
+  unsigned char* dst = V8T + (((size_t)b * H + head) * 64 + d) * Spad + (size_t)grp * 64 + 32 * h;
+  *(u32x4*)dst = (u32x4){out[0], out[1], out[2], out[3]};
+  *(u32x4*)(dst + 16) = (u32x4){out[4], out[5], out[6], out[7]};
+  sV[((((size_t)b * H + head) * 64 + d) * (Spad >> 6) + grp) * 2 + h] = (unsigned char)sb;
+}
+
+__device__ __forceinline__ int fp8_swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned char* __restrict__ Q8, const unsigned char* __restrict__ sQ,
+                                                              const unsigned char* __restrict__ K8, const unsigned char* __restrict__ sK,
+                                                              const unsigned char* __restrict__ V8T, const unsigned char* __restrict__ sV, int w,
+                                                              bf16_t* __restrict__ O, int ldo, float* __restrict__ LSE, int S, int Spad, int Sq, int qoff,
+                                                              int H) {
+  // per buffer: K tile [64 keys][64 B] | V^T tile [64 channels][64 B] | K scales [64] u16 | V scales [64] u16
+  constexpr int BUF = 4096 + 4096 + 128 + 128;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+  const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+  const int r = l & 31, h = l >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q = blockIdx.x * 128 + wv * 32 + r;            // index inside the query range
+  const bool qok = q < Sq;
+  const size_t qrow = (size_t)b * S + qoff + (qok ? q : 0);
+  const int nsc = w >> 5;                                   // scale bytes per token row
+  v8i qf = {0, 0, 0, 0, 0, 0, 0, 0};
+  int qs = 127;
+  if (qok) {
+    const u32x4 a = *(const u32x4*)(Q8 + qrow * w + head * 64 + 32 * h);
+    const u32x4 c = *(const u32x4*)(Q8 + qrow * w + head * 64 + 32 * h + 16);
+    qf = (v8i){(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
+    qs = sQ[qrow * nsc + head * 2 + h];
+  }
+  // staging: thread -> (row t >> 2, 16-byte chunk t & 3) of both tiles
+  const int srow = t >> 2, sch = t & 3;
+  const unsigned char* kbase = K8 + (size_t)b * S * w + head * 64 + sch * 16;
+  const unsigned char* vbase = V8T + (((size_t)b * H + head) * 64 + srow) * Spad + sch * 16;
+  const unsigned char* skbase = sK + (size_t)b * S * nsc + head * 2;
+  const unsigned char* svbase = sV + (((size_t)b * H + head) * 64) * (size_t)(Spad >> 6) * 2;
+  u32x4 kreg, vreg;
+  unsigned short sreg = 0;
+  auto gload = [&](int kt) {
+    const int key = kt * 64 + srow;
+    kreg = key < S ? *(const u32x4*)(kbase + (size_t)key * w) : (u32x4){0, 0, 0, 0};
+    vreg = *(const u32x4*)(vbase + (size_t)kt * 64);
+    if (t < 64) {
+      const int k2 = kt * 64 + t;
+      sreg = k2 < S ? *(const unsigned short*)(skbase + (size_t)k2 * nsc) : (unsigned short)0x7f7f;
+    } else if (t < 128) {
+      sreg = *(const unsigned short*)(svbase + ((size_t)(t - 64) * (Spad >> 6) + kt) * 2);
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* sb = smem + buf * BUF;
+    *(u32x4*)(sb + fp8_swz(srow, sch)) = kreg;
+    *(u32x4*)(sb + 4096 + fp8_swz(srow, sch)) = vreg;
+    if (t < 128) ((unsigned short*)(sb + 8192))[t] = sreg;
+  };
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int i = 0; i < 16; i++) { o0[i] = 0.f; o1[i] = 0.f; }
+  float m = -INFINITY, lsum = 0.f;
+  const int nt = (S + 63) >> 6;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nt; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nt) gload(kt + 1);
+    const unsigned char* sb = smem + buf * BUF;
+    const unsigned short* sks = (const unsigned short*)(sb + 8192);
+    const unsigned short* svs = sks + 64;
+    f32x16 s[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) {
+      const int row = 32 * tt + r;
+      const u32x4 a = *(const u32x4*)(sb + fp8_swz(row, 2 * h));
+      const u32x4 c = *(const u32x4*)(sb + fp8_swz(row, 2 * h + 1));
+      const v8i kf = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
+      const int ks = (sks[row] >> (8 * h)) & 0xff;
+      f32x16 z;
+#pragma unroll
+      for (int i = 0; i < 16; i++) z[i] = 0.f;
+      s[tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf, z, 0, 0, 0, ks, 0, qs);   // S^T[key][q], exp2 domain
+    }
+    if (kt == nt - 1 && (S & 63)) {  // keys past the end of the sequence
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const int key = kt * 64 + 32 * tt + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (key >= S) s[tt][i] = -INFINITY;
+        }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) mx = fmaxf(mx, s[0][i]);
+#pragma unroll
+    for (int i = 0; i < 16; i++) mx = fmaxf(mx, s[1][i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // the other lane half holds the other 32 keys of this query
+    const float mn = fmaxf(m, mx);
+    const float alpha = fast_exp2(m - mn);    // first tile: exp2(-inf) = 0
+    m = mn;
+    float ps = 0.f;
+    int pw[8];
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const float p0 = fast_exp2(s[tt][4 * g] - mn), p1 = fast_exp2(s[tt][4 * g + 1] - mn), p2 = fast_exp2(s[tt][4 * g + 2] - mn),
+                    p3 = fast_exp2(s[tt][4 * g + 3] - mn);
+        ps += (p0 + p1) + (p2 + p3);
+        int wd = 0;
+        wd = __builtin_amdgcn_cvt_pk_fp8_f32(p0 * 128.f, p1 * 128.f, wd, false);   // P in [0, 1] -> [0, 128]: 7 more binades above the e4m3 floor
+        wd = __builtin_amdgcn_cvt_pk_fp8_f32(p2 * 128.f, p3 * 128.f, wd, true);
+        pw[4 * tt + g] = wd;
+      }
+    lsum = lsum * alpha + ps;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }
+    const v8i pf = {pw[0], pw[1], pw[2], pw[3], pw[4], pw[5], pw[6], pw[7]};
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++) {
+      const int row = 32 * dt + r;  // channel
+      const u32x4 a = *(const u32x4*)(sb + 4096 + fp8_swz(row, 2 * h));
+      const u32x4 c = *(const u32x4*)(sb + 4096 + fp8_swz(row, 2 * h + 1));
+      const v8i vf = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
+      const int vs = (svs[row] >> (8 * h)) & 0xff;
+      if (dt == 0) o0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf, o0, 0, 0, 0, vs, 0, 120);   // O^T[channel][q]; 120 = 2^-7
+      else o1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf, o1, 0, 0, 0, vs, 0, 120);
+    }
+    if (kt + 1 < nt) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  if (!qok) return;
+  const float inv = 1.0f / ltot;
+  bf16_t* op = O + qrow * ldo + head * 64;
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const int d0 = 8 * g + 4 * h;
+    const u32x2 a = {pack_bf16(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack_bf16(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv)};
+    const u32x2 c = {pack_bf16(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack_bf16(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv)};
+    *(u32x2*)(op + d0) = a;
+    *(u32x2*)(op + 32 + d0) = c;
+  }
+  if (h == 0) LSE[((size_t)b * H + head) * Sq + q] = (m + __log2f(ltot)) * 0.6931471805599453f;
+}
+
+size_t attention_fp8_workspace_bytes(int B, int S, int H) {
+  const size_t rows = (size_t)B * S, w = (size_t)H * 64, Spad = ((size_t)S + 63) & ~(size_t)63;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  return al(rows * w) * 2 + al(rows * (w >> 5)) * 2 + al((size_t)B * H * 64 * Spad) + al((size_t)B * H * 64 * (Spad >> 6) * 2);
+}
+
+int attention_fwd_fp8(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf16_t* O, int ldo, float* LSE, int B, int S, int H, int Dh, float scale,
+                      int Sq, int qoff, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (Sq <= 0) { Sq = S; qoff = 0; }
+  if (qoff < 0 || qoff + Sq > S) { set_error("attention_fwd_fp8: query range outside the sequence"); return SMBV_ERR_SHAPE; }
+  if (Dh != 64) { set_error("attention_fwd_fp8: head_dim %d not supported (only 64)", Dh); return SMBV_ERR_SHAPE; }
+  if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 3)) { set_error("attention_fwd_fp8: bad shape"); return SMBV_ERR_SHAPE; }
+  if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || ((uintptr_t)O & 7)) { set_error("attention_fwd_fp8: alignment"); return SMBV_ERR_ALIGN; }
+  const size_t need = attention_fp8_workspace_bytes(B, S, H);
+  if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) { set_error("attention_fwd_fp8: workspace too small or misaligned (%zu < %zu)", ws_bytes, need); return SMBV_ERR_WORKSPACE; }
+  const long rows = (long)B * S;
+  const int w = H * 64, Spad = (S + 63) & ~63;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  unsigned char* p = (unsigned char*)ws;
+  unsigned char* Q8 = p; p += al((size_t)rows * w);
+  unsigned char* K8 = p; p += al((size_t)rows * w);
+  unsigned char* sQ = p; p += al((size_t)rows * (w >> 5));
+  unsigned char* sK = p; p += al((size_t)rows * (w >> 5));
+  unsigned char* V8T = p; p += al((size_t)B * H * 64 * Spad);
+  unsigned char* sV = p;
+  const int qblocks = cdiv(rows * (w >> 3), 256);
+  hipLaunchKernelGGL(quant_qk_fp8_kernel, dim3(qblocks), dim3(256), 0, st, Q, ld, rows, w, scale * 1.4426950408889634f, Q8, sQ);
+  hipLaunchKernelGGL(quant_qk_fp8_kernel, dim3(qblocks), dim3(256), 0, st, K, ld, rows, w, 1.0f, K8, sK);
+  hipLaunchKernelGGL(quant_vt_fp8_kernel, dim3(Spad / 64, H, B), dim3(128), 0, st, V, ld, S, Spad, H, V8T, sV);
+  int rc = check_launch("quant_fp8");
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_fwd_fp8_kernel, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, (const unsigned char*)Q8, (const unsigned char*)sQ, (const unsigned char*)K8,
+                     (const unsigned char*)sK, (const unsigned char*)V8T, (const unsigned char*)sV, w, O, ldo, LSE, S, Spad, Sq, qoff, H);
+  return check_launch("attention_fwd_fp8");
+}
+
+}  // namespace smbv

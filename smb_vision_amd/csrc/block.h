@@ -23,6 +23,7 @@ struct BlockDims {
   int rope_grid = 0;              // > 0: 3-axis RoPE on q and k with this grid size (tokens per row; tokens per frame = grid^2)
   const int* pos = nullptr;       // token position ids for RoPE (null = index within the sequence)
   const float* rope_table = nullptr;
+  int attn_fp8 = 0;               // 1: attention forward on the block-scaled fp8 MFMA (attention_fp8.hip); the backward stays bf16
   int wa() const { return H * 64; }
   bool padded() const { return Dh != 64; }
   float scale() const { return 1.0f / std::sqrt((float)Dh); }
@@ -40,6 +41,8 @@ struct BwdScratch {  // sized for the widest block of the model
   float *delta, *gpad, *gpad_b;  // gpad / gpad_b: head-padded weight / bias gradients before un-padding (null when no block is padded)
   void* scratch;        // LN-bwd partials / colsum partials / gemm_tn slabs of the products that stay on the caller's stream
   size_t scratch_bytes;
+  void* f8ws = nullptr; // quantised operands of the fp8 attention forward (null unless a block asks for it)
+  size_t f8ws_bytes = 0;
   void* wscratch;       // gemm_tn slabs + column-sum partials of the weight-gradient products that run on the side stream
   size_t wscratch_bytes;
 };
@@ -92,7 +95,7 @@ size_t layer_prep_job_count(const BlockDims& d);
 // appends this block's weight-preparation jobs; for padded heads also enqueues the zero fills of the padded buffers on `st`
 int prep_layer(PrepList& pl, const BlockPtrs& p, LayerWs& L, const BlockDims& d, hipStream_t st);
 struct BwdNeeds {  // running maxima over the blocks of a model (elements, except scratch / wscratch: bytes)
-  size_t act = 0, we = 0, qkv = 0, gpad = 0, gpad_b = 0, delta = 0, scratch = 0, wscratch = 0;
+  size_t act = 0, we = 0, qkv = 0, gpad = 0, gpad_b = 0, delta = 0, scratch = 0, wscratch = 0, f8 = 0;
 };
 void bwd_scratch_requirements(const BlockDims& d, BwdNeeds& n);
 void carve_bwd_scratch(Carver& cv, BwdScratch& sc, const BwdNeeds& n);  // everything of BwdScratch except gath0 / gath1

@@ -87,6 +87,7 @@ void bwd_scratch_requirements(const BlockDims& d, BwdNeeds& n) {
   auto tn = [&](size_t M, size_t n1, size_t n2) { n.wscratch = std::max(n.wscratch, gemm_tn_workspace_bytes((int)M, (int)n1, (int)n2)); };
   tn(rows, w, ff); tn(rows, ff, w); tn(rows, w, wa); tn(rows, 3 * wa, w); tn(rows, w, w);
   n.scratch = std::max(n.scratch, layernorm_bwd_workspace_bytes((int)rows, (int)w));
+  if (d.attn_fp8) n.f8 = std::max(n.f8, attention_fp8_workspace_bytes(d.B, d.S, d.H));
 }
 
 void carve_bwd_scratch(Carver& cv, BwdScratch& sc, const BwdNeeds& n) {
@@ -101,6 +102,8 @@ void carve_bwd_scratch(Carver& cv, BwdScratch& sc, const BwdNeeds& n) {
   sc.scratch_bytes = n.scratch;
   sc.wscratch = cv.take<char>(n.wscratch);
   sc.wscratch_bytes = n.wscratch;
+  sc.f8ws = n.f8 ? cv.take<char>(n.f8) : nullptr;
+  sc.f8ws_bytes = n.f8;
 }
 
 int layer_fwd(const BlockPtrs& p, LayerWs& L, const BlockDims& d, BwdScratch& sc, const float* x_in, float* x_out, bf16_t* x_out_bf16, int Sq, int qoff,
@@ -113,7 +116,8 @@ int layer_fwd(const BlockPtrs& p, LayerWs& L, const BlockDims& d, BwdScratch& sc
     RC(gemm_nt(L.ln1, w, L.wqkv, w, M, 3 * wa, w, e, st));
   }
   if (d.rope_grid > 0) RC(rope3d(L.qkv, 3 * wa, wa, M, S, H, 64, d.Dh, d.rope_grid, d.pos, d.rope_table, 0, st));
-  RC(attention_fwd(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, wa, L.lse, B, S, H, 64, d.scale(), Sq, qoff, st));
+  if (d.attn_fp8) RC(attention_fwd_fp8(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, wa, L.lse, B, S, H, 64, d.scale(), Sq, qoff, sc.f8ws, sc.f8ws_bytes, st));
+  else RC(attention_fwd(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, wa, L.lse, B, S, H, 64, d.scale(), Sq, qoff, st));
   if (Sq > 0) {
     // ranged tail: projection + MLP on the Sq tokens only; x_mid / x_out keep the full [B*S, w] layout, ln2 / pre / act are compact
     const int Mq = B * Sq;

@@ -97,6 +97,12 @@ int smbv_attention_fwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* 
   if (!Q || !K || !V || !O || !LSE) { set_error("smbv_attention_fwd: null operand"); return SMBV_ERR_ARG; }
   return attention_fwd(Q, K, V, ld, O, ldo, LSE, B, S, H, Dh, scale, Sq, q_off, (hipStream_t)stream);
 }
+size_t smbv_attention_fp8_workspace_bytes(int B, int S, int H) { return attention_fp8_workspace_bytes(B, S, H); }
+int smbv_attention_fwd_fp8(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, smbv_bf16* O, int ldo, float* LSE, int B, int S, int H, int Dh,
+                           float scale, int Sq, int q_off, void* ws, size_t ws_bytes, smbv_stream stream) {
+  if (!Q || !K || !V || !O || !LSE) { set_error("smbv_attention_fwd_fp8: null operand"); return SMBV_ERR_ARG; }
+  return attention_fwd_fp8(Q, K, V, ld, O, ldo, LSE, B, S, H, Dh, scale, Sq, q_off, ws, ws_bytes, (hipStream_t)stream);
+}
 int smbv_attention_bwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* dO, int ldo,
                        const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S, int H, int Dh, float scale,
                        int parts, int Sq, int q_off, smbv_stream stream) {

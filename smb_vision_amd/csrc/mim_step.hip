@@ -26,11 +26,11 @@ struct MimWs {
 };
 
 static BlockDims enc_dims(const smbv_mim_cfg& c) {
-  BlockDims d; d.rows = (size_t)c.B * c.Nvis; d.w = c.d; d.ff = c.ff; d.B = c.B; d.S = c.Nvis; d.H = c.heads; d.Dh = 64; d.eps = c.ln_eps;
+  BlockDims d; d.rows = (size_t)c.B * c.Nvis; d.w = c.d; d.ff = c.ff; d.B = c.B; d.S = c.Nvis; d.H = c.heads; d.Dh = 64; d.eps = c.ln_eps; d.attn_fp8 = c.attn_fp8;
   return d;
 }
 static BlockDims dec_dims(const smbv_mim_cfg& c) {
-  BlockDims d; d.rows = (size_t)c.B * c.N; d.w = c.dd; d.ff = c.dff; d.B = c.B; d.S = c.N; d.H = c.dheads; d.Dh = 64; d.eps = c.ln_eps;
+  BlockDims d; d.rows = (size_t)c.B * c.N; d.w = c.dd; d.ff = c.dff; d.B = c.B; d.S = c.N; d.H = c.dheads; d.Dh = 64; d.eps = c.ln_eps; d.attn_fp8 = c.attn_fp8;
   return d;
 }
 static BlockPtrs to_block(const smbv_layer_ptrs& p) {

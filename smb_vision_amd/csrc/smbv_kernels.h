@@ -53,6 +53,11 @@ int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf1
 int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
                   float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st);
 
+// fp8 (OCP e4m3, block-scaled MFMA) forward: same contract as attention_fwd plus a caller-owned workspace for the quantised operands
+size_t attention_fp8_workspace_bytes(int B, int S, int H);
+int attention_fwd_fp8(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf16_t* O, int ldo, float* LSE, int B, int S, int H, int Dh, float scale,
+                      int Sq, int qoff, void* ws, size_t ws_bytes, hipStream_t st);
+
 int prepare_volume(const void* src, int src_dtype, float* dst, int B, int H0, int W0, int D0, int H, int W, int D, float a_min, float a_max,
                    float b_min, float b_max, int clip, hipStream_t st);
 int gather_bricks(const float* pix, const int* idx, int rows, int per_batch, bf16_t* out, int T, int H, int W, int ts, int ps, hipStream_t st);

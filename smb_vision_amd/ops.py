@@ -124,6 +124,21 @@ def attention_fwd(qkv, B, S, H, scale=None, Sq=0, q_off=0):
     return O, lse
 
 
+def attention_fwd_fp8(qkv, B, S, H, scale=None, Sq=0, q_off=0):
+    """As attention_fwd, on the block-scaled fp8 (OCP e4m3) MFMA path (smbv_attention_fwd_fp8)."""
+    _need_gpu(qkv)
+    lib = _lib.load()
+    w = H * 64
+    scale = scale if scale is not None else 64 ** -0.5
+    O = torch.zeros(B * S, w, dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty(B, H, Sq if Sq > 0 else S, dtype=torch.float32, device=qkv.device)
+    ws = _ws(lib.smbv_attention_fp8_workspace_bytes(B, S, H), qkv.device)
+    base = qkv.data_ptr()
+    check(lib.smbv_attention_fwd_fp8(base, base + 2 * w, base + 4 * w, qkv.stride(0), _p(O), w, _p(lse), B, S, H, 64, scale, Sq, q_off, _p(ws), ws.numel(),
+                                     _stream()), "smbv_attention_fwd_fp8")
+    return O, lse
+
+
 def attention_bwd(qkv, O, dO, lse, B, S, H, scale=None, parts=7, out=None, Sq=0, q_off=0):
     _need_gpu(qkv, O, dO, lse)
     lib = _lib.load()

@@ -1,0 +1,108 @@
+"""BASELINE.json config 5 on the GPU: attention forward on the block-scaled fp8 (OCP e4m3) MFMA, and the MIM step that uses it.
+
+Stated tolerances.  The fp8 path rounds Q (after the softmax scale), K, V and the probabilities P to e4m3 (3 mantissa bits: 2^-4 relative per
+element) under power-of-two block scales; sums over 64 channels / thousands of keys average the rounding down.  Against fp32:
+  attention kernel : O    max |d| <= 6e-2 max|O|, rms(d) <= 2.5e-2 rms(O);  LSE |d| <= 3e-2
+                     and, against a reference that applies the SAME operand rounding to Q / K / V (exact P), rms(d) <= 1.5e-2 rms(O)
+  MIM step         : loss |d| <= 1e-2 |loss|, logits rms(d) <= 5e-2 rms(logits), every gradient ||d|| <= 1.5e-1 ||g|| and cosine >= 0.99
+(the bf16 path's bounds for the same checks are 5e-3 / 1e-2 / 6e-2 / 0.998: tests/test_mim_step_gpu.py)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def mx_round(x, axis_block):
+    """Reference MX rounding: power-of-two scale per 32-element block along the last axis (amax / 2^e <= 448), e4m3 round-to-nearest."""
+    shp = x.shape
+    xb = x.reshape(-1, 32) if axis_block == "last" else x
+    amax = xb.abs().amax(dim=-1, keepdim=True)
+    e = torch.ceil(torch.log2(torch.clamp(amax, min=1e-30) / 448.0))
+    sc = torch.pow(2.0, e)
+    q = (xb / sc).to(torch.float8_e4m3fn).to(torch.float32) * sc
+    return q.reshape(shp)
+
+
+@pytest.mark.parametrize("B,S,H,Sq,qoff", [(1, 256, 2, 0, 0), (2, 1000, 3, 0, 0), (1, 2048, 4, 700, 1348), (1, 200, 1, 0, 0)])
+def test_attention_fwd_fp8_matches_fp32_within_the_stated_tolerance(B, S, H, Sq, qoff):
+    from smb_vision_amd import ops
+    w = H * 64
+    g = torch.Generator().manual_seed(S + H)
+    qkv = (torch.randn(B * S, 3 * w, generator=g) * 1.5).bfloat16()
+    O, lse = ops.attention_fwd_fp8(qkv.cuda(), B, S, H, Sq=Sq, q_off=qoff)
+    O_b, lse_b = ops.attention_fwd(qkv.cuda(), B, S, H, Sq=Sq, q_off=qoff)
+    f = qkv.float().view(B, S, 3, H, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = f[0], f[1], f[2]
+    sl = slice(qoff, qoff + Sq) if Sq else slice(None)
+
+    def attn(q, k, v):
+        s = torch.matmul(q[:, :, sl], k.transpose(-1, -2)) * 0.125
+        return torch.matmul(torch.softmax(s, -1), v), torch.logsumexp(s, -1)
+
+    ref, ref_lse = attn(q, k, v)
+    got = O.float().cpu().view(B, S, H, 64).permute(0, 2, 1, 3)[:, :, sl]
+    d = got - ref
+    assert float(d.abs().max()) <= 6e-2 * float(ref.abs().max())
+    rms = float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    assert rms <= 2.5e-2, rms
+    assert float((lse.cpu() - ref_lse).abs().max()) <= 3e-2
+    # same operand rounding in the reference (Q with the scale * log2 e folded in, K per 32 channels, V per 32 keys of the kernel's key order)
+    c = 0.125 * math.log2(math.e)
+    q8 = mx_round(q * c, "last") / c
+    k8 = mx_round(k, "last")
+    Sp = (S + 63) // 64 * 64
+    vp = torch.zeros(B, H, Sp, 64)
+    vp[:, :, :S] = v
+    key = torch.arange(64)
+    order = torch.stack([32 * (p >> 4) + 8 * ((p >> 2) & 3) + 4 * h + (p & 3) for h in range(2) for p in range(32)])     # [64]: half-major
+    vt = vp.view(B, H, Sp // 64, 64, 64)[:, :, :, order]                         # keys in the kernel's order: [.., grp, 64 keys', ch]
+    vt8 = mx_round(vt.permute(0, 1, 2, 4, 3).contiguous(), "last")              # [.., grp, ch, 64 keys'] blocks of 32 keys'
+    inv = torch.argsort(order)
+    v8 = vt8.permute(0, 1, 2, 4, 3)[:, :, :, inv].reshape(B, H, Sp, 64)[:, :, :S]
+    ref8, _ = attn(q8, k8, v8)
+    rms8 = float((got - ref8).pow(2).mean().sqrt() / ref8.pow(2).mean().sqrt())
+    assert rms8 <= 1.5e-2, rms8
+    rms_b = float((O_b.float().cpu().view(B, S, H, 64).permute(0, 2, 1, 3)[:, :, sl] - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    print(f"fp8 attention S={S}: rms vs fp32 {rms:.2e} (bf16 kernel {rms_b:.2e}), vs same-rounding reference {rms8:.2e}")
+
+
+def test_mim_step_with_fp8_attention_and_recompute():
+    """config.smbv_attention_fp8 = True (+ per-layer recompute): the whole step against the fp32 oracle, tolerances in the module docstring."""
+    from transformers import VideoMAEConfig
+    from oracle.mim_oracle import MIMConfig, init_params, mim_step
+    from smb_vision_amd.masking import MaskGenerator
+    from smb_vision_amd.modeling_videomae import SmbVideoMAEForPreTraining
+    c = dict(image_size=128, num_frames=64, patch_size=16, tubelet_size=16, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+             intermediate_size=512, decoder_hidden_size=64, decoder_num_hidden_layers=2, decoder_num_attention_heads=1, decoder_intermediate_size=256)
+    cfg = MIMConfig(**c)
+    params = init_params(cfg, seed=7, nonzero_small=True)
+    np.random.seed(3)
+    gen = MaskGenerator(128, 64, 16, 16, 0.59)
+    mask = torch.stack([gen(), gen()])
+    pix = torch.rand(2, 64, 1, 128, 128, generator=torch.Generator().manual_seed(5))
+    ref_loss, ref_logits, ref_grads = mim_step(params, cfg, pix, mask)
+    model = SmbVideoMAEForPreTraining(VideoMAEConfig(num_channels=1, smbv_attention_fp8=True, smbv_recompute="always", **c))
+    model.load_state_dict(params)
+    model = model.cuda().train()
+    model.gradient_checkpointing_enable()
+    out = model(pixel_values=pix.cuda(), bool_masked_pos=mask.cuda())
+    out.loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(out.loss) - float(ref_loss)) <= 1e-2 * float(ref_loss)
+    d = out.logits.float().cpu() - ref_logits
+    assert float(d.pow(2).mean().sqrt()) <= 5e-2 * float(ref_logits.pow(2).mean().sqrt())
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        r = ref_grads[k]
+        n = float(r.norm())
+        if n < 1e-10:
+            continue
+        g = p.grad.cpu()
+        e = float((g - r).norm()) / n
+        cos = float((g * r).sum() / (g.norm() * r.norm()))
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        assert e <= 1.5e-1 and cos >= 0.99, (k, e, cos)
+    print("fp8 MIM step: loss", float(out.loss), "oracle", float(ref_loss), "worst grad", worst)
