@@ -4,14 +4,16 @@
 // e4m3 under power-of-two (E8M0) block scales, MX style:
 //   * quant_qk_fp8_kernel: Q (pre-multiplied by scale * log2 e, so scores leave the MFMA in the exp2 domain) and K, one scale per
 //     (token, head, 32 channels) - the 32 contraction elements one lane feeds the MFMA;
-//   * quant_vt_fp8_kernel: V transposed to [batch, head, channel][key] with one scale per (channel, 32 keys), the keys of every 64-key
-//     group stored in the order the P operand holds them (below), so both operands of P V are plain 32-byte row reads;
+//   * quant_vt_fp8_kernel: V transposed to [batch, head, channel][key] with one scale per (channel, 32 consecutive keys), the keys of every
+//     64-key group stored in the order the P operand holds them (below), so both operands of P V are plain 32-byte row reads;
 //   * attn_fwd_fp8_kernel: 4 waves x 32 queries, 64-key tiles.  S^T = K Q^T is ONE MFMA per 32 keys (K = 64 channels = the two lane halves
 //     x 32 bytes), query on the lane: row max / sum are lane-local plus one v_permlane32_swap; the exponentiated accumulator, scaled by 2^7
 //     and converted to e4m3 in register order, IS the B operand of O^T += V^T P^T (its E8M0 scale 2^-7 undoes the factor) - lane half h of the
 //     two S^T tiles holds keys 32 t + 8 g + 4 h + e (t tile, g = 0..3, e = 0..3) in bytes 16 t + 4 g + e, and V^T is stored in that key order.
 // The operand maps were pinned on hardware by tools/probe/fp8_probe.hip: lane (r = l & 31, h = l >> 5) feeds row / column r and 32 of the
-// 64 contraction elements; byte j of half h meets byte j of the other operand's half h; one E8M0 scale byte per lane per operand.
+// 64 contraction elements; byte j of half h meets byte j of the other operand's half h; the E8M0 scale in lane (r, h) acts on scale block h of
+// row r, and scale block b is bytes 16 b .. 16 b + 15 of BOTH lane halves.  So lane half h carries channels 16 h .. +15 (block 0) and
+// 32 + 16 h .. +15 (block 1) of a Q / K row, and for P V block t is simply the keys of S^T tile t.
 // The backward stays on the bf16 kernels (attention_bwd.hip) with this forward's LSE.  Stated tolerance: tests/test_fp8_gpu.py.
 #include "smbv_common.h"
 #include "smbv_kernels.h"
@@ -73,29 +75,31 @@ __global__ __launch_bounds__(128) void quant_vt_fp8_kernel(const bf16_t* __restr
     for (int j = 0; j < 4; j++) { tile[key][c * 8 + 2 * j] = (unsigned short)(raw[j] & 0xffff); tile[key][c * 8 + 2 * j + 1] = (unsigned short)(raw[j] >> 16); }
   }
   __syncthreads();
-  const int d = t >> 1, h = t & 1;
+  const int d = t >> 1, tt = t & 1;  // channel, 32-key scale block (= S^T tile) of the group
   float v[32];
   float amax = 0.f;
 #pragma unroll
-  for (int p = 0; p < 32; p++) {  // byte p = 16 tt + 4 g + e  <->  key 32 tt + 8 g + 4 h + e
-    const int key = 32 * (p >> 4) + 8 * ((p >> 2) & 3) + 4 * h + (p & 3);
-    v[p] = bf2f(tile[key][d]);
-    amax = fmaxf(amax, fabsf(v[p]));
+  for (int kk = 0; kk < 32; kk++) {
+    v[kk] = bf2f(tile[32 * tt + kk][d]);
+    amax = fmaxf(amax, fabsf(v[kk]));
   }
   const int sb = e8m0_for(amax);
   const float inv = e8m0_inv(sb);
-  unsigned out[8];
+  // lane half h of the P operand holds keys 32 tt + 8 g + 4 h + e in bytes 16 tt + 4 g + e: four dwords per (block, half)
+  unsigned char* dst = V8T + (((size_t)b * H + head) * 64 + d) * Spad + (size_t)grp * 64 + 16 * tt;
 #pragma unroll
-  for (int q = 0; q < 8; q++) {
-    int wv = 0;
-    wv = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * q] * inv, v[4 * q + 1] * inv, wv, false);
-    wv = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * q + 2] * inv, v[4 * q + 3] * inv, wv, true);
-    out[q] = (unsigned)wv;
+  for (int h = 0; h < 2; h++) {
+    unsigned out[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      int wv = 0;
+      wv = __builtin_amdgcn_cvt_pk_fp8_f32(v[8 * g + 4 * h] * inv, v[8 * g + 4 * h + 1] * inv, wv, false);
+      wv = __builtin_amdgcn_cvt_pk_fp8_f32(v[8 * g + 4 * h + 2] * inv, v[8 * g + 4 * h + 3] * inv, wv, true);
+      out[g] = (unsigned)wv;
+    }
+    *(u32x4*)(dst + 32 * h) = (u32x4){out[0], out[1], out[2], out[3]};
   }
-  unsigned char* dst = V8T + (((size_t)b * H + head) * 64 + d) * Spad + (size_t)grp * 64 + 32 * h;
-  *(u32x4*)dst = (u32x4){out[0], out[1], out[2], out[3]};
-  *(u32x4*)(dst + 16) = (u32x4){out[4], out[5], out[6], out[7]};
-  sV[((((size_t)b * H + head) * 64 + d) * (Spad >> 6) + grp) * 2 + h] = (unsigned char)sb;
+  sV[((((size_t)b * H + head) * 64 + d) * (Spad >> 6) + grp) * 2 + tt] = (unsigned char)sb;
 }
 
 __device__ __forceinline__ int fp8_swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
@@ -118,8 +122,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
   v8i qf = {0, 0, 0, 0, 0, 0, 0, 0};
   int qs = 127;
   if (qok) {
-    const u32x4 a = *(const u32x4*)(Q8 + qrow * w + head * 64 + 32 * h);
-    const u32x4 c = *(const u32x4*)(Q8 + qrow * w + head * 64 + 32 * h + 16);
+    const u32x4 a = *(const u32x4*)(Q8 + qrow * w + head * 64 + 16 * h);        // channels 16 h .. (scale block 0)
+    const u32x4 c = *(const u32x4*)(Q8 + qrow * w + head * 64 + 32 + 16 * h);   // channels 32 + 16 h .. (scale block 1)
     qf = (v8i){(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
     qs = sQ[qrow * nsc + head * 2 + h];
   }
@@ -167,8 +171,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
 #pragma unroll
     for (int tt = 0; tt < 2; tt++) {
       const int row = 32 * tt + r;
-      const u32x4 a = *(const u32x4*)(sb + fp8_swz(row, 2 * h));
-      const u32x4 c = *(const u32x4*)(sb + fp8_swz(row, 2 * h + 1));
+      const u32x4 a = *(const u32x4*)(sb + fp8_swz(row, h));
+      const u32x4 c = *(const u32x4*)(sb + fp8_swz(row, 2 + h));
       const v8i kf = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
       const int ks = (sks[row] >> (8 * h)) & 0xff;
       f32x16 z;

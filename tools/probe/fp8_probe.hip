@@ -26,6 +26,16 @@ static unsigned char enc_e4m3(float f) {
   return s | (unsigned char)(E << 3) | (unsigned char)M;
 }
 
+// per-lane scales: lane (r, h) supplies the scale of row / column r, contraction block h
+__global__ void k_scaled_lane(const unsigned char* abytes, const unsigned char* bbytes, float* C, const int* sa, const int* sb) {
+  const int l = threadIdx.x;
+  v8i a = *(const v8i*)(abytes + l * 32);
+  v8i b = *(const v8i*)(bbytes + l * 32);
+  v16f c = {};
+  c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa[l], 0, sb[l]);
+  for (int r = 0; r < 16; r++) C[((r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 32 + (l & 31)] = c[r];
+}
+
 __global__ void k_scaled(const unsigned char* abytes, const unsigned char* bbytes, float* C, int sa, int sb) {
   const int l = threadIdx.x;
   v8i a = *(const v8i*)(abytes + l * 32);
@@ -98,6 +108,71 @@ int main() {
     int bad = 0;
     for (int i = 0; i < M * N; i++) bad += hc[i] != ref[i] * cs.f;
     printf("scale_a 0x%x scale_b 0x%x expect x%g: %d mismatches\n", cs.sa, cs.sb, cs.f, bad);
+  }
+  {  // per-lane scales with candidate map 0 (k = 32 h + b): reference applies 2^(sa[row][h] - 127) * 2^(sb[col][h] - 127) per 32-k block
+    std::vector<int> hsa(64), hsb(64);
+    for (int l = 0; l < 64; l++) { hsa[l] = 124 + (l * 7) % 6; hsb[l] = 125 + (l * 5) % 5; }
+    int *dsa, *dsb;
+    CK(hipMalloc(&dsa, 256)); CK(hipMalloc(&dsb, 256));
+    CK(hipMemcpy(dsa, hsa.data(), 256, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dsb, hsb.data(), 256, hipMemcpyHostToDevice));
+    for (int l = 0; l < 64; l++)
+      for (int b = 0; b < 32; b++) {
+        const int k = 32 * (l >> 5) + b;
+        ha[l * 32 + b] = enc_e4m3(A[(l & 31) * K + k]);
+        hb[l * 32 + b] = enc_e4m3(B[k * N + (l & 31)]);
+      }
+    CK(hipMemcpy(da, ha.data(), ha.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, hb.data(), hb.size(), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_scaled_lane, dim3(1), dim3(64), 0, 0, da, db, dc, dsa, dsb);
+    CK(hipMemcpy(hc.data(), dc, M * N * 4, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int i = 0; i < M; i++)
+      for (int j = 0; j < N; j++) {
+        float s = 0;
+        for (int h = 0; h < 2; h++) {
+          float part = 0;
+          for (int k = 32 * h; k < 32 * h + 32; k++) part += A[i * K + k] * B[k * N + j];
+          s += part * ldexpf(1.f, hsa[i + 32 * h] - 127) * ldexpf(1.f, hsb[j + 32 * h] - 127);
+        }
+        bad += hc[i * N + j] != s;
+      }
+    printf("per-lane scales (lane (r,h) -> row r, block h): %d mismatches\n", bad);
+  }
+  {  // which (row, 32-k block) does lane L's A-scale byte act on?  (data placed with map 0; B scales all 2^0)
+    std::vector<int> hsa(64), hsb(64, 127);
+    int *dsa, *dsb;
+    CK(hipMalloc(&dsa, 256)); CK(hipMalloc(&dsb, 256));
+    CK(hipMemcpy(dsb, hsb.data(), 256, hipMemcpyHostToDevice));
+    const int probes[] = {0, 1, 5, 31, 32, 33, 37, 63};
+    for (int which = 0; which < 2; which++)       // 0: vary A scales, 1: vary B scales
+      for (int L : probes) {
+        for (int l = 0; l < 64; l++) hsa[l] = 127;
+        hsa[L] = 128;
+        CK(hipMemcpy(which ? dsb : dsa, hsa.data(), 256, hipMemcpyHostToDevice));
+        for (int l = 0; l < 64; l++) hsa[l] = 127;
+        CK(hipMemcpy(which ? dsa : dsb, hsa.data(), 256, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_scaled_lane, dim3(1), dim3(64), 0, 0, da, db, dc, dsa, dsb);
+        CK(hipMemcpy(hc.data(), dc, M * N * 4, hipMemcpyDeviceToHost));
+        printf("%c scale of lane %2d doubled ->", which ? 'B' : 'A', L);
+        const int x = L & 31;
+        // partial sums per 8-byte group of the contraction as the data was placed (map 0: k = 8 q8 + e; half = q8 >> 2)
+        int subset = -1, nmatch = 0;
+        for (int sub = 1; sub < 256; sub++) {
+          bool ok = true;
+          for (int y = 0; y < 32 && ok; y++) {
+            const int i = which ? y : x, j = which ? x : y;
+            float want = hc[i * N + j] - ref[i * N + j], got = 0;
+            for (int q8 = 0; q8 < 8; q8++)
+              if (sub >> q8 & 1)
+                for (int k = 8 * q8; k < 8 * q8 + 8; k++) got += A[i * K + k] * B[k * N + j];
+            ok = got == want;
+          }
+          if (ok) { subset = sub; nmatch++; }
+        }
+        printf(" %s %d: groups of 8 k (bit q = k 8q..8q+7) 0x%02x (%d subsets fit)", which ? "col" : "row", x, subset, nmatch);
+        printf("\n");
+      }
   }
   printf("RESULT kmap=%d\n", found);
   return 0;
