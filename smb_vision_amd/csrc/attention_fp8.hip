@@ -102,6 +102,17 @@ __global__ __launch_bounds__(128) void quant_vt_fp8_kernel(const bf16_t* __restr
   sV[((((size_t)b * H + head) * 64 + d) * (Spad >> 6) + grp) * 2 + tt] = (unsigned char)sb;
 }
 
+// value of the partner lane (l ^ 32) combined with this lane's: one v_permlane32_swap instead of an LDS-routed shuffle
+__device__ __forceinline__ void other_half(float v, float& own, float& other) {
+  typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+  const unsigned a = __builtin_bit_cast(unsigned, v);
+  const u32x2v sw = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+  unsigned lo = sw[0], hi = sw[1];
+  asm volatile("" : "+v"(lo), "+v"(hi));  // (hipcc -O3 otherwise folds a symmetric use of sw[0], sw[1] to sw[0]: attention_fwd.hip)
+  own = __builtin_bit_cast(float, lo);
+  other = __builtin_bit_cast(float, hi);
+}
+
 __device__ __forceinline__ int fp8_swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
 __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned char* __restrict__ Q8, const unsigned char* __restrict__ sQ,
@@ -194,7 +205,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
     for (int i = 1; i < 16; i++) mx = fmaxf(mx, s[0][i]);
 #pragma unroll
     for (int i = 0; i < 16; i++) mx = fmaxf(mx, s[1][i]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // the other lane half holds the other 32 keys of this query
+    {  // the other lane half holds the other 32 keys of this query
+      float a, c2;
+      other_half(mx, a, c2);
+      mx = fmaxf(a, c2);
+    }
     const float mn = fmaxf(m, mx);
     const float alpha = fast_exp2(m - mn);    // first tile: exp2(-inf) = 0
     m = mn;
@@ -229,7 +244,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
     if (kt + 1 < nt) lstore(buf ^ 1);
     __syncthreads();
   }
-  const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  float la, lb;
+  other_half(lsum, la, lb);
+  const float ltot = la + lb;
   if (!qok) return;
   const float inv = 1.0f / ltot;
   bf16_t* op = O + qrow * ldo + head * 64;
