@@ -197,7 +197,8 @@ def trainer_ms_per_step(cfg_kw, steps=10, warm=2):
                 torch.cuda.synchronize()
                 Clock.t1 = time.perf_counter()
 
-    with tempfile.TemporaryDirectory() as tmp:
+    import contextlib
+    with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(sys.stderr):  # stdout carries the ONE JSON line only
         argv = ["--output_dir", tmp, "--image_size", str(cfg_kw["image_size"]), "--depth", str(cfg_kw["num_frames"]), "--patch_size", "16",
                 "--mask_patch_size", "32", "--mask_ratio", "0.65", "--max_steps", str(warm + steps), "--per_device_train_batch_size", "1",
                 "--report_to", "none", "--bf16", "true", "--learning_rate", "1.5e-4", "--weight_decay", "0.05", "--adam_beta2", "0.95", "--logging_steps", "1000",

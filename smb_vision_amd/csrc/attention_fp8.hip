@@ -167,7 +167,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
   f32x16 o0, o1;
 #pragma unroll
   for (int i = 0; i < 16; i++) { o0[i] = 0.f; o1[i] = 0.f; }
-  float m = -INFINITY, lsum = 0.f;
+  // VALU diet (the loop is bound by vector issue, not by the matrix pipe, at 64 channels per head): scores leave the MFMA already relative to a
+  // running per-query reference `mref` and shifted by +7 (the reference sits in the accumulator input), so p' = 128 exp2(s - mref) is ONE
+  // v_exp_f32 per score with no subtract and no multiply, and feeds the e4m3 conversion directly; the reference only moves when a score would
+  // push p' past 256 (or on the first tile) - the rescale of O and of the row sum then runs under a wave-uniform branch, rarely.
+  float mref = 0.f, lsum = 0.f;
   const int nt = (S + 63) >> 6;
   gload(0);
   lstore(0);
@@ -179,6 +183,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
     const unsigned short* sks = (const unsigned short*)(sb + 8192);
     const unsigned short* svs = sks + 64;
     f32x16 s[2];
+    const float zin = 7.0f - mref;
 #pragma unroll
     for (int tt = 0; tt < 2; tt++) {
       const int row = 32 * tt + r;
@@ -188,8 +193,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
       const int ks = (sks[row] >> (8 * h)) & 0xff;
       f32x16 z;
 #pragma unroll
-      for (int i = 0; i < 16; i++) z[i] = 0.f;
-      s[tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf, z, 0, 0, 0, ks, 0, qs);   // S^T[key][q], exp2 domain
+      for (int i = 0; i < 16; i++) z[i] = zin;
+      s[tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf, z, 0, 0, 0, ks, 0, qs);   // S^T[key][q] - mref + 7, exp2 domain
     }
     if (kt == nt - 1 && (S & 63)) {  // keys past the end of the sequence
 #pragma unroll
@@ -200,36 +205,37 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
           if (key >= S) s[tt][i] = -INFINITY;
         }
     }
-    float mx = s[0][0];
+    float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
-    for (int i = 1; i < 16; i++) mx = fmaxf(mx, s[0][i]);
-#pragma unroll
-    for (int i = 0; i < 16; i++) mx = fmaxf(mx, s[1][i]);
+    for (int i = 1; i < 16; i++) mx = fmaxf(fmaxf(mx, s[0][i]), s[1][i]);  // v_max3_f32
     {  // the other lane half holds the other 32 keys of this query
       float a, c2;
       other_half(mx, a, c2);
       mx = fmaxf(a, c2);
     }
-    const float mn = fmaxf(m, mx);
-    const float alpha = fast_exp2(m - mn);    // first tile: exp2(-inf) = 0
-    m = mn;
+    const bool rebase = kt == 0 || mx > 8.0f;
+    if (__builtin_amdgcn_ballot_w64(rebase) != 0) {
+      const float d = rebase ? mx - 7.0f : 0.f;  // bring this query's maximum back to 2^7
+      const float alpha = fast_exp2(-d);
+      mref += d;
+      lsum *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; s[0][i] -= d; s[1][i] -= d; }
+    }
     float ps = 0.f;
     int pw[8];
 #pragma unroll
     for (int tt = 0; tt < 2; tt++)
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        const float p0 = fast_exp2(s[tt][4 * g] - mn), p1 = fast_exp2(s[tt][4 * g + 1] - mn), p2 = fast_exp2(s[tt][4 * g + 2] - mn),
-                    p3 = fast_exp2(s[tt][4 * g + 3] - mn);
+        const float p0 = fast_exp2(s[tt][4 * g]), p1 = fast_exp2(s[tt][4 * g + 1]), p2 = fast_exp2(s[tt][4 * g + 2]), p3 = fast_exp2(s[tt][4 * g + 3]);
         ps += (p0 + p1) + (p2 + p3);
         int wd = 0;
-        wd = __builtin_amdgcn_cvt_pk_fp8_f32(p0 * 128.f, p1 * 128.f, wd, false);   // P in [0, 1] -> [0, 128]: 7 more binades above the e4m3 floor
-        wd = __builtin_amdgcn_cvt_pk_fp8_f32(p2 * 128.f, p3 * 128.f, wd, true);
+        wd = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, wd, false);   // p' in [0, 256]: 7-8 binades above where P in [0, 1] would sit in e4m3
+        wd = __builtin_amdgcn_cvt_pk_fp8_f32(p2, p3, wd, true);
         pw[4 * tt + g] = wd;
       }
-    lsum = lsum * alpha + ps;
-#pragma unroll
-    for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }
+    lsum += ps;
     const v8i pf = {pw[0], pw[1], pw[2], pw[3], pw[4], pw[5], pw[6], pw[7]};
 #pragma unroll
     for (int dt = 0; dt < 2; dt++) {
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
       const u32x4 c = *(const u32x4*)(sb + 4096 + fp8_swz(row, 2 * h + 1));
       const v8i vf = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
       const int vs = (svs[row] >> (8 * h)) & 0xff;
-      if (dt == 0) o0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf, o0, 0, 0, 0, vs, 0, 120);   // O^T[channel][q]; 120 = 2^-7
+      if (dt == 0) o0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf, o0, 0, 0, 0, vs, 0, 120);   // O^T[channel][q]; 120 = 2^-7 undoes the 128
       else o1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf, o1, 0, 0, 0, vs, 0, 120);
     }
     if (kt + 1 < nt) lstore(buf ^ 1);
@@ -246,9 +252,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
   }
   float la, lb;
   other_half(lsum, la, lb);
-  const float ltot = la + lb;
+  const float ltot = la + lb;   // = 128 * sum exp2(s - mref)
   if (!qok) return;
-  const float inv = 1.0f / ltot;
+  const float inv = 128.0f / ltot;
   bf16_t* op = O + qrow * ldo + head * 64;
 #pragma unroll
   for (int g = 0; g < 4; g++) {
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
     *(u32x2*)(op + d0) = a;
     *(u32x2*)(op + 32 + d0) = c;
   }
-  if (h == 0) LSE[((size_t)b * H + head) * Sq + q] = (m + __log2f(ltot)) * 0.6931471805599453f;
+  if (h == 0) LSE[((size_t)b * H + head) * Sq + q] = (mref + __log2f(ltot) - 7.0f) * 0.6931471805599453f;
 }
 
 size_t attention_fp8_workspace_bytes(int B, int S, int H) {

@@ -98,6 +98,7 @@ def main(argv=None):
     logging.basicConfig(level=logging.INFO, handlers=[logging.StreamHandler(sys.stdout)])
     set_seed(targs.seed)
     targs.remove_unused_columns = False
+    targs.logging_nan_inf_filter = False  # no per-step host read of the loss (see run_mim.py)
     # run_vjepa.py:221-233: in_chans=1, frames_per_clip=depth, tubelet_size=patch_size, crop_size=image_size
     config = VJEPA2Config(patch_size=dargs.patch_size, crop_size=dargs.image_size, frames_per_clip=dargs.depth, tubelet_size=dargs.patch_size, in_chans=1,
                           hidden_size=margs.hidden_size, num_hidden_layers=margs.num_hidden_layers, num_attention_heads=margs.num_attention_heads,
