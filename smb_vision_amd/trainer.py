@@ -124,10 +124,18 @@ class SmbTrainer(Trainer):
         return out
 
     def get_train_dataloader(self):
-        loader = super().get_train_dataloader()
-        if getattr(self.args, "smbv_prefetch_to_device", True) and _is_native(self.model) and next(self.model.parameters()).is_cuda:
-            return DevicePrefetcher(loader, next(self.model.parameters()).device)
-        return loader
+        prefetch = getattr(self.args, "smbv_prefetch_to_device", True) and _is_native(self.model) and next(self.model.parameters()).is_cuda
+        if not prefetch:
+            return super().get_train_dataloader()
+        # accelerate's prepared loader would itself move every batch to the device with a BLOCKING copy on the compute stream
+        # (DataLoaderShard.send_to_device): leave the batches on the host and let the prefetcher upload them on its copy stream
+        placement = self.accelerator.device_placement
+        self.accelerator.device_placement = False
+        try:
+            loader = super().get_train_dataloader()
+        finally:
+            self.accelerator.device_placement = placement
+        return DevicePrefetcher(loader, next(self.model.parameters()).device)
 
     # -- fused optimizer tail -------------------------------------------------------------------------------------------------------------
     def create_optimizer(self, model=None):
