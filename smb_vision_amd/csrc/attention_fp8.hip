@@ -31,8 +31,9 @@ __device__ __forceinline__ int e8m0_for(float amax) {
 __device__ __forceinline__ float e8m0_inv(int byte) { return __uint_as_float((unsigned)(254 - byte) << 23); }  // 2^-(byte-127)
 
 // bf16 [rows, ld] column block `col0 .. col0 + w` -> e4m3 [rows, w] + E8M0 scales [rows, w / 32]; premul folded in before rounding
+// scale layout: head_major_S == 0 -> [rows, w / 32]; > 0 (= S) -> [batch, head][S][2], contiguous per head (what the K tiles are staged from)
 __global__ __launch_bounds__(256) void quant_qk_fp8_kernel(const bf16_t* __restrict__ X, int ld, long rows, int w, float premul,
-                                                           unsigned char* __restrict__ X8, unsigned char* __restrict__ sX) {
+                                                           unsigned char* __restrict__ X8, unsigned char* __restrict__ sX, int head_major_S) {
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   const int per_row = w >> 3;
   const long row = gid / per_row;
@@ -57,11 +58,19 @@ __global__ __launch_bounds__(256) void quant_qk_fp8_kernel(const bf16_t* __restr
   hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, hi, false);
   hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
   *(u32x2*)(X8 + row * w + c8 * 8) = (u32x2){(unsigned)lo, (unsigned)hi};
-  if ((c8 & 3) == 0) sX[row * (w >> 5) + (c8 >> 2)] = (unsigned char)sb;
+  if ((c8 & 3) == 0) {
+    if (head_major_S > 0) {
+      const long bb = row / head_major_S, ss = row % head_major_S;
+      const int H = w >> 6, head = c8 >> 3, half = (c8 >> 2) & 1;
+      sX[((bb * H + head) * head_major_S + ss) * 2 + half] = (unsigned char)sb;
+    } else {
+      sX[row * (w >> 5) + (c8 >> 2)] = (unsigned char)sb;
+    }
+  }
 }
 
 // V bf16 [B*S, ld] (head h at columns 64 h ..) -> V8T e4m3 [B, H, 64 channels][Spad keys, permuted inside 64-key groups] + scales
-// sV [B, H, 64][Spad / 64][2].  One block = one (64-key group, head, batch); thread (d = t >> 1, half = t & 1) owns one scale block.
+// sV [B, H][Spad / 64][64][2] (contiguous per 64-key group).  One block = one (64-key group, head, batch); thread (d = t >> 1, half = t & 1) owns one scale block.
 __global__ __launch_bounds__(128) void quant_vt_fp8_kernel(const bf16_t* __restrict__ V, int ld, int S, int Spad, int H,
                                                            unsigned char* __restrict__ V8T, unsigned char* __restrict__ sV) {
   __shared__ unsigned short tile[64][66];
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(128) void quant_vt_fp8_kernel(const bf16_t* __restr
     }
     *(u32x4*)(dst + 32 * h) = (u32x4){out[0], out[1], out[2], out[3]};
   }
-  sV[((((size_t)b * H + head) * 64 + d) * (Spad >> 6) + grp) * 2 + tt] = (unsigned char)sb;
+  sV[((((size_t)b * H + head) * (Spad >> 6) + grp) * 64 + d) * 2 + tt] = (unsigned char)sb;
 }
 
 // value of the partner lane (l ^ 32) combined with this lane's: one v_permlane32_swap instead of an LDS-routed shuffle
@@ -115,53 +124,48 @@ __device__ __forceinline__ void other_half(float v, float& own, float& other) {
 
 __device__ __forceinline__ int fp8_swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned char* __restrict__ Q8, const unsigned char* __restrict__ sQ,
-                                                              const unsigned char* __restrict__ K8, const unsigned char* __restrict__ sK,
-                                                              const unsigned char* __restrict__ V8T, const unsigned char* __restrict__ sV, int w,
-                                                              bf16_t* __restrict__ O, int ldo, float* __restrict__ LSE, int S, int Spad, int Sq, int qoff,
-                                                              int H) {
-  // per buffer: K tile [64 keys][64 B] | V^T tile [64 channels][64 B] | K scales [64] u16 | V scales [64] u16
-  constexpr int BUF = 4096 + 4096 + 128 + 128;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
-  const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+__global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned char* __restrict__ wsb, unsigned ws_bytes, unsigned offK, unsigned offSQ,
+                                                              unsigned offSK, unsigned offV, unsigned offSV, int w, bf16_t* __restrict__ O, int ldo,
+                                                              float* __restrict__ LSE, int S, int Spad, int Sq, int qoff, int H) {
+  // K / V^T / scale tiles go global -> LDS by LDS-DMA (hidden from hipcc's wait insertion, smbv_common.h) into a ring of three slots, two tiles
+  // in flight; one counted vmcnt + one barrier per tile.  Slot: K tile [64 keys][64 B] | V^T tile [64 channels][64 B] | per 16 rows
+  // [K scales 32 B | V scales 32 B] x 4.  (A one-tile register prefetch left every tile waiting for its L2 round trip.)
+  constexpr int SLOT = 4096 + 4096 + 256;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * SLOT];
+  const int t = threadIdx.x, l = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int r = l & 31, h = l >> 5;
   const int head = blockIdx.y, b = blockIdx.z;
   const int q = blockIdx.x * 128 + wv * 32 + r;            // index inside the query range
   const bool qok = q < Sq;
   const size_t qrow = (size_t)b * S + qoff + (qok ? q : 0);
-  const int nsc = w >> 5;                                   // scale bytes per token row
+  const int nsc = w >> 5;                                   // Q scale bytes per token row
+  const unsigned char* Q8 = wsb;
   v8i qf = {0, 0, 0, 0, 0, 0, 0, 0};
   int qs = 127;
   if (qok) {
     const u32x4 a = *(const u32x4*)(Q8 + qrow * w + head * 64 + 16 * h);        // channels 16 h .. (scale block 0)
     const u32x4 c = *(const u32x4*)(Q8 + qrow * w + head * 64 + 32 + 16 * h);   // channels 32 + 16 h .. (scale block 1)
     qf = (v8i){(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
-    qs = sQ[qrow * nsc + head * 2 + h];
+    qs = (wsb + offSQ)[qrow * nsc + head * 2 + h];
   }
-  // staging: thread -> (row t >> 2, 16-byte chunk t & 3) of both tiles
-  const int srow = t >> 2, sch = t & 3;
-  const unsigned char* kbase = K8 + (size_t)b * S * w + head * 64 + sch * 16;
-  const unsigned char* vbase = V8T + (((size_t)b * H + head) * 64 + srow) * Spad + sch * 16;
-  const unsigned char* skbase = sK + (size_t)b * S * nsc + head * 2;
-  const unsigned char* svbase = sV + (((size_t)b * H + head) * 64) * (size_t)(Spad >> 6) * 2;
-  u32x4 kreg, vreg;
-  unsigned short sreg = 0;
-  auto gload = [&](int kt) {
-    const int key = kt * 64 + srow;
-    kreg = key < S ? *(const u32x4*)(kbase + (size_t)key * w) : (u32x4){0, 0, 0, 0};
-    vreg = *(const u32x4*)(vbase + (size_t)kt * 64);
-    if (t < 64) {
-      const int k2 = kt * 64 + t;
-      sreg = k2 < S ? *(const unsigned short*)(skbase + (size_t)k2 * nsc) : (unsigned short)0x7f7f;
-    } else if (t < 128) {
-      sreg = *(const unsigned short*)(svbase + ((size_t)(t - 64) * (Spad >> 6) + kt) * 2);
-    }
-  };
-  auto lstore = [&](int buf) {
-    unsigned char* sb = smem + buf * BUF;
-    *(u32x4*)(sb + fp8_swz(srow, sch)) = kreg;
-    *(u32x4*)(sb + 4096 + fp8_swz(srow, sch)) = vreg;
-    if (t < 128) ((unsigned short*)(sb + 8192))[t] = sreg;
+  asm volatile("" : "+v"(qf), "+v"(qs));  // consumed here: hipcc waits for these loads now, not with a vmcnt(0) inside the tile loop
+  // copy side: wave wv stages rows 16 wv .. + 15 of both tiles (one 1-KiB piece each: lane -> row l >> 2, physical chunk l & 3 holding logical
+  // chunk (l & 3) ^ ((row >> 2) & 3)) and, with its first 16 lanes, the 64 scale bytes of those rows
+  const i32x4 rs = dma_rsrc(wsb, ws_bytes);
+  const int prow = 16 * wv + (l >> 2), csrc = (l & 3) ^ ((l >> 4) & 3);
+  const int ok0 = (int)offK + (int)(((size_t)b * S + prow) * w) + head * 64 + 16 * csrc;
+  const int ov0 = (int)offV + (int)((((size_t)b * H + head) * 64 + prow) * Spad) + 16 * csrc;
+  const int j8 = l & 7;
+  const int os0 = l < 8 ? (int)offSK + (int)((((size_t)b * H + head) * S + 16 * wv) * 2) + 4 * j8
+                        : (int)offSV + (int)((((size_t)b * H + head) * (Spad >> 6) * 64 + 16 * wv) * 2) + 4 * j8;
+  const int os_step = l < 8 ? 128 : 128;  // both scale arrays advance 64 rows x 2 B per tile
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((int)lds_addr_of(smem));
+  auto stage = [&](int kt) __attribute__((always_inline)) {
+    const unsigned sl = lds0 + (unsigned)(kt % 3) * SLOT;
+    dma16_hidden(rs, sl + (unsigned)wv * 1024, ok0 + kt * 64 * w);
+    dma16_hidden(rs, sl + 4096 + (unsigned)wv * 1024, ov0 + kt * 64);
+    if (l < 16) dma4_hidden(rs, sl + 8192 + (unsigned)wv * 64, os0 + kt * os_step);
   };
 
   f32x16 o0, o1;
@@ -173,15 +177,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
   // push p' past 256 (or on the first tile) - the rescale of O and of the row sum then runs under a wave-uniform branch, rarely.
   float mref = 0.f, lsum = 0.f;
   const int nt = (S + 63) >> 6;
-  gload(0);
-  lstore(0);
-  __syncthreads();
+  stage(0);
+  stage(1);
   for (int kt = 0; kt < nt; kt++) {
-    const int buf = kt & 1;
-    if (kt + 1 < nt) gload(kt + 1);
-    const unsigned char* sb = smem + buf * BUF;
-    const unsigned short* sks = (const unsigned short*)(sb + 8192);
-    const unsigned short* svs = sks + 64;
+    // this wave's pieces of tile kt have landed (tile kt + 1 may still fly: three copies a tile, the wave with lanes >= 16 idle in the third
+    // still counts it); the barrier publishes the tile and retires everybody's reads of tile kt - 1, whose slot tile kt + 2 now takes
+    // (past the end the copies read unused bytes of the workspace: never consumed)
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    stage(kt + 2);
+    const unsigned char* sb = smem + (kt % 3) * SLOT;
+    const unsigned char* scb = sb + 8192;
     f32x16 s[2];
     const float zin = 7.0f - mref;
 #pragma unroll
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
       const u32x4 a = *(const u32x4*)(sb + fp8_swz(row, h));
       const u32x4 c = *(const u32x4*)(sb + fp8_swz(row, 2 + h));
       const v8i kf = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
-      const int ks = (sks[row] >> (8 * h)) & 0xff;
+      const int ks = scb[(row >> 4) * 64 + (row & 15) * 2 + h];
       f32x16 z;
 #pragma unroll
       for (int i = 0; i < 16; i++) z[i] = zin;
@@ -243,13 +249,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
       const u32x4 a = *(const u32x4*)(sb + 4096 + fp8_swz(row, 2 * h));
       const u32x4 c = *(const u32x4*)(sb + 4096 + fp8_swz(row, 2 * h + 1));
       const v8i vf = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
-      const int vs = (svs[row] >> (8 * h)) & 0xff;
+      const int vs = scb[(row >> 4) * 64 + 32 + (row & 15) * 2 + h];
       if (dt == 0) o0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf, o0, 0, 0, 0, vs, 0, 120);   // O^T[channel][q]; 120 = 2^-7 undoes the 128
       else o1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf, o1, 0, 0, 0, vs, 0, 120);
     }
-    if (kt + 1 < nt) lstore(buf ^ 1);
-    __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead copies still target this block's LDS
   float la, lb;
   other_half(lsum, la, lb);
   const float ltot = la + lb;   // = 128 * sum exp2(s - mref)
@@ -293,13 +298,15 @@ int attention_fwd_fp8(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld,
   unsigned char* V8T = p; p += al((size_t)B * H * 64 * Spad);
   unsigned char* sV = p;
   const int qblocks = cdiv(rows * (w >> 3), 256);
-  hipLaunchKernelGGL(quant_qk_fp8_kernel, dim3(qblocks), dim3(256), 0, st, Q, ld, rows, w, scale * 1.4426950408889634f, Q8, sQ);
-  hipLaunchKernelGGL(quant_qk_fp8_kernel, dim3(qblocks), dim3(256), 0, st, K, ld, rows, w, 1.0f, K8, sK);
+  if (need >= ((size_t)1 << 31)) { set_error("attention_fwd_fp8: workspace of %zu bytes exceeds the 32-bit copy offsets", need); return SMBV_ERR_SHAPE; }
+  hipLaunchKernelGGL(quant_qk_fp8_kernel, dim3(qblocks), dim3(256), 0, st, Q, ld, rows, w, scale * 1.4426950408889634f, Q8, sQ, 0);
+  hipLaunchKernelGGL(quant_qk_fp8_kernel, dim3(qblocks), dim3(256), 0, st, K, ld, rows, w, 1.0f, K8, sK, S);
   hipLaunchKernelGGL(quant_vt_fp8_kernel, dim3(Spad / 64, H, B), dim3(128), 0, st, V, ld, S, Spad, H, V8T, sV);
   int rc = check_launch("quant_fp8");
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_fwd_fp8_kernel, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, (const unsigned char*)Q8, (const unsigned char*)sQ, (const unsigned char*)K8,
-                     (const unsigned char*)sK, (const unsigned char*)V8T, (const unsigned char*)sV, w, O, ldo, LSE, S, Spad, Sq, qoff, H);
+  const unsigned char* base = (const unsigned char*)ws;
+  hipLaunchKernelGGL(attn_fwd_fp8_kernel, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, base, (unsigned)need, (unsigned)(K8 - base), (unsigned)(sQ - base),
+                     (unsigned)(sK - base), (unsigned)(V8T - base), (unsigned)(sV - base), w, O, ldo, LSE, S, Spad, Sq, qoff, H);
   return check_launch("attention_fwd_fp8");
 }
 

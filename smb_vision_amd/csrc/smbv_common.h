@@ -71,6 +71,15 @@ __device__ __forceinline__ void dma16_hidden(i32x4 rsrc, unsigned lds_uniform, i
                : "memory");
 }
 
+// the same with 4 bytes per lane (256 B per wave-instruction; honours the EXEC mask: lane i of the active lanes writes lds_uniform + 4*i)
+__device__ __forceinline__ void dma4_hidden(i32x4 rsrc, unsigned lds_uniform, int voff) {
+  unsigned keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_uniform), "v"(voff), "s"(rsrc)
+               : "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -39,6 +39,8 @@ def mxq(x):  # x [..., 32] -> (bytes uint8, scale byte)
 
 for name, x, got8, gots in (("Q", q * c, Q8, sQ), ("K", k, K8, sK)):
     b8, sc = mxq(x.reshape(rows, w // 32, 32))
+    if name == "K":  # K scales are stored [batch, head][S][2]
+        sc = sc.view(B, S, H, 2).permute(0, 2, 1, 3).contiguous()
     nb = int((b8.reshape(-1) != got8).sum()); ns = int((sc.reshape(-1) != gots).sum())
     print(f"{name}: {nb} / {b8.numel()} byte mismatches, {ns} / {sc.numel()} scale mismatches")
     if nb:
@@ -50,16 +52,17 @@ vch = vv.permute(0, 2, 3, 1).reshape(B, H, 64, Sp // 64, 2, 32)                 
 b8n, sc = mxq(vch)                                                               # natural key order
 order = torch.tensor([32 * t + 8 * g + 4 * h + e for h in range(2) for t in range(2) for g in range(4) for e in range(4)])
 b8 = b8n.reshape(B, H, 64, Sp // 64, 64)[..., order]
-nb = int((b8.reshape(-1) != V8T).sum()); ns = int((sc.reshape(-1) != sV).sum())
+scv = sc.permute(0, 1, 3, 2, 4).contiguous()   # stored [B,H][grp][ch][2]
+nb = int((b8.reshape(-1) != V8T).sum()); ns = int((scv.reshape(-1) != sV).sum())
 print(f"V: {nb} / {b8.numel()} byte mismatches, {ns} / {sc.numel()} scale mismatches")
 # attention from the dequantised operands
 def deq(b8, sc):
     return b8.view(torch.float8_e4m3fn).float() * torch.pow(2.0, sc.float() - 127).unsqueeze(-1)
 qd = deq(Q8.view(rows, w // 32, 32), sQ.view(rows, w // 32)).view(B, S, H, 64).permute(0, 2, 1, 3)
-kd = deq(K8.view(rows, w // 32, 32), sK.view(rows, w // 32)).view(B, S, H, 64).permute(0, 2, 1, 3)
+kd = deq(K8.view(rows, w // 32, 32), sK.view(B, H, S, 2).permute(0, 2, 1, 3).reshape(rows, w // 32)).view(B, S, H, 64).permute(0, 2, 1, 3)
 inv = torch.argsort(order)
 vnat = V8T.view(B, H, 64, Sp // 64, 64)[..., inv].reshape(B, H, 64, Sp // 64, 2, 32)
-vd = deq(vnat, sV.view(B, H, 64, Sp // 64, 2)).reshape(B, H, 64, Sp)[..., :S].permute(0, 1, 3, 2)
+vd = deq(vnat, sV.view(B, H, Sp // 64, 64, 2).permute(0, 1, 3, 2, 4)).reshape(B, H, 64, Sp)[..., :S].permute(0, 1, 3, 2)
 s2 = torch.matmul(qd, kd.transpose(-1, -2))          # exp2 domain
 p = torch.softmax(s2 * math.log(2.0), -1)
 ref = torch.matmul(p, vd)
