@@ -369,9 +369,12 @@ def main():
         return out.loss
 
     last = {}
+    from smb_vision_amd.masking import split_mask_indices_host
+    vis_h, msk_h = split_mask_indices_host(mask.cpu())      # what run_mim.collate_fn hands over next to the mask (no per-step device sort)
+    vis_d, msk_d = vis_h.to(device), msk_h.to(device)
 
     def step():
-        last["loss"] = train(pix, bool_masked_pos=mask, num_masked=n_masked)
+        last["loss"] = train(pix, bool_masked_pos=mask, visible_index=vis_d, masked_index=msk_d)
 
     for _ in range(args.warmup):
         step()
