@@ -175,7 +175,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
   // running per-query reference `mref` and shifted by +7 (the reference sits in the accumulator input), so p' = 128 exp2(s - mref) is ONE
   // v_exp_f32 per score with no subtract and no multiply, and feeds the e4m3 conversion directly; the reference only moves when a score would
   // push p' past 256 (or on the first tile) - the rescale of O and of the row sum then runs under a wave-uniform branch, rarely.
-  float mref = 0.f, lsum = 0.f;
+  // (the loop is vector-issue bound - SQ_ACTIVE_INST_VALU x 3 waves per SIMD = 0.9 - so two more things leave the vector pipe: the reference
+  // lives in a persistent accumulator-input block `cin` instead of being splatted per tile, and the row sum is ONE more MFMA, ones^T P^T, on the
+  // e4m3 P the numerator uses, instead of 32 adds)
+  float mref = 0.f;
+  f32x16 cin, ol;
+#pragma unroll
+  for (int i = 0; i < 16; i++) { cin[i] = 7.0f; ol[i] = 0.f; }
+  const v8i ones = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};  // e4m3 1.0
   const int nt = (S + 63) >> 6;
   stage(0);
   stage(1);
@@ -189,7 +196,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
     const unsigned char* sb = smem + (kt % 3) * SLOT;
     const unsigned char* scb = sb + 8192;
     f32x16 s[2];
-    const float zin = 7.0f - mref;
 #pragma unroll
     for (int tt = 0; tt < 2; tt++) {
       const int row = 32 * tt + r;
@@ -197,10 +203,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
       const u32x4 c = *(const u32x4*)(sb + fp8_swz(row, 2 + h));
       const v8i kf = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
       const int ks = scb[(row >> 4) * 64 + (row & 15) * 2 + h];
-      f32x16 z;
-#pragma unroll
-      for (int i = 0; i < 16; i++) z[i] = zin;
-      s[tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf, z, 0, 0, 0, ks, 0, qs);   // S^T[key][q] - mref + 7, exp2 domain
+      s[tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf, cin, 0, 0, 0, ks, 0, qs);   // S^T[key][q] - mref + 7, exp2 domain
     }
     if (kt == nt - 1 && (S & 63)) {  // keys past the end of the sequence
 #pragma unroll
@@ -224,25 +227,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
       const float d = rebase ? mx - 7.0f : 0.f;  // bring this query's maximum back to 2^7
       const float alpha = fast_exp2(-d);
       mref += d;
-      lsum *= alpha;
 #pragma unroll
-      for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; s[0][i] -= d; s[1][i] -= d; }
+      for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; ol[i] *= alpha; s[0][i] -= d; s[1][i] -= d; cin[i] -= d; }
     }
-    float ps = 0.f;
     int pw[8];
 #pragma unroll
     for (int tt = 0; tt < 2; tt++)
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const float p0 = fast_exp2(s[tt][4 * g]), p1 = fast_exp2(s[tt][4 * g + 1]), p2 = fast_exp2(s[tt][4 * g + 2]), p3 = fast_exp2(s[tt][4 * g + 3]);
-        ps += (p0 + p1) + (p2 + p3);
         int wd = 0;
         wd = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, wd, false);   // p' in [0, 256]: 7-8 binades above where P in [0, 1] would sit in e4m3
         wd = __builtin_amdgcn_cvt_pk_fp8_f32(p2, p3, wd, true);
         pw[4 * tt + g] = wd;
       }
-    lsum += ps;
     const v8i pf = {pw[0], pw[1], pw[2], pw[3], pw[4], pw[5], pw[6], pw[7]};
+    ol = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones, pf, ol, 0, 0, 0, 127, 0, 127);   // every row: sum over the tile's 64 keys of p' (as rounded)
 #pragma unroll
     for (int dt = 0; dt < 2; dt++) {
       const int row = 32 * dt + r;  // channel
@@ -255,9 +255,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead copies still target this block's LDS
-  float la, lb;
-  other_half(lsum, la, lb);
-  const float ltot = la + lb;   // = 128 * sum exp2(s - mref)
+  const float ltot = ol[0];   // = 128 * sum exp2(s - mref) over ALL keys (the MFMA contracts both lane halves)
   if (!qok) return;
   const float inv = 128.0f / ltot;
   bf16_t* op = O + qrow * ldo + head * 64;
