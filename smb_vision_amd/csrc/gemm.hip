@@ -312,7 +312,7 @@ int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, in
   // K = 384 projections, the head - and 5-13 % behind the 128 x 128 kernel on long-K or narrow outputs, whose smaller tiles fill the chip better.
   const bool ring_shape = K <= 768 && N >= 1024;
   if (gemm_nt_ring_ok(lda, ldb, M, N, K, e) && !(g_variant & 256) && (ring_shape || (g_variant & 131072)))
-    return gemm_nt_ring(A, lda, B, ldb, M, N, K, e, (g_variant & 512) ? 4 : 3, st, (g_variant >> 20) & 15);
+    return gemm_nt_ring(A, lda, B, ldb, M, N, K, e, (g_variant & 262144) ? 64 : ((g_variant & 512) ? 4 : 3), st, (g_variant >> 20) & 15);
   const int tm = cdiv(M, BM), tn = cdiv(N, BN);
   const bool dma_ok = (K % BK == 0) && (N % 8 == 0) && (!e.out_bf16 || ((e.ld_ob & 7) == 0 && ((uintptr_t)e.out_bf16 & 15) == 0)) &&
                       (!e.aux_pre || ((e.ld_aux & 7) == 0 && ((uintptr_t)e.aux_pre & 15) == 0)) &&

@@ -97,6 +97,25 @@ __device__ __forceinline__ void epi_rows4(const GemmEpi& e, const int (&m)[4], c
   }
 }
 
+// epilogue shared by the ring kernels: register r of acc[i][j] is row 64 wm + 16 i + 4 (l >> 4) + r, column 64 wn + 4 (l & 15) + j
+template <int EPI>
+__device__ __forceinline__ void ring_epilogue(const f32x4 (&acc)[4][4], const GemmEpi& e_in, int m0, int n0, int wm, int wn, int l, int M) {
+  const GemmEpi e = e_in;
+  const int n = n0 + 64 * wn + 4 * (l & 15);
+  const int mb = m0 + 64 * wm + 4 * (l >> 4);
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (e.bias) bias = *(const f32x4*)(e.bias + n);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int m[4] = {mb + 16 * i, mb + 16 * i + 1, mb + 16 * i + 2, mb + 16 * i + 3};
+    f32x4 v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = (f32x4){acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+    epi_rows4<EPI>(e, m, M, n, v, bias);
+    __builtin_amdgcn_sched_barrier(0);  // keep the next row group's loads from being hoisted up here (register budget of the 2-blocks-per-CU build)
+  }
+}
+
 template <int NS, int EPI>
 __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_nt_ring_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
                                                                           int M, int N, int K, int tiles_m, int tiles_n, GemmEpi e_in, int dbg) {
@@ -183,21 +202,88 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_nt_ring_kernel(cons
     if (acc[0][0][0] == 1234.5f) e_in.out_f32[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3];
     return;
   }
-  // epilogue: register r of acc[i][j] is row 64 wm + 16 i + 4 (l >> 4) + r, column 64 wn + 4 (l & 15) + j
-  const GemmEpi e = e_in;
-  const int n = n0 + 64 * wn + 4 * (l & 15);
-  const int mb = m0 + 64 * wm + 4 * (l >> 4);
-  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-  if (e.bias) bias = *(const f32x4*)(e.bias + n);
+  ring_epilogue<EPI>(acc, e_in, m0, n0, wm, wn, l, M);
+}
+
+// The same tile with 64-deep K slices: rows of 128 B, so every copy request is a whole cache line (the 32-deep slices above ask L2 for 64-B
+// halves: 4.9 M requests per QKV product against 2.3 M here, profiles/r02_gemm_pmc.txt); 3 slots of 48 KiB = one block per CU, two slices in
+// flight, two MFMA K-steps per barrier.  Image swizzle as gemm.hip's swz_nt (16-B chunk c of row r at chunk c ^ ((r >> 1) & 7)).
+__device__ __forceinline__ int ring64_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_ring64_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N, int K,
+                                                                int tiles_m, int tiles_n, GemmEpi e_in) {
+  constexpr int SLOT = (RBM + RBN) * 128;  // 48 KiB
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * SLOT];
+  const int t = threadIdx.x, l = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int nwg = tiles_m * tiles_n, bid = blockIdx.x;
+  const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
+  const int tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+  const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+  const int m0 = tile_m * RBM, n0 = tile_n * RBN;
+  const int nks = K / 64;
+
+  const i32x4 ra = dma_rsrc(A, (unsigned)(((size_t)(M - 1) * lda + K) * 2));
+  const i32x4 rb = dma_rsrc(B, (unsigned)(((size_t)(N - 1) * ldb + K) * 2));
+  // copy side: piece = 8 LDS rows x 128 B; lane -> (row l >> 3, physical chunk l & 7); pieces at even / odd multiples of 8 rows see
+  // (row >> 1) & 7 = (l >> 4) / 4 + (l >> 4): two source-chunk permutations per lane
+  const int rin = l >> 3, cpos = l & 7;
+  const int cs_e = cpos ^ ((rin >> 1) & 7), cs_o = cpos ^ ((4 + (rin >> 1)) & 7);
+  const int oa_e = ((m0 + 32 * w + rin) * lda + cs_e * 8) * 2, oa_o = ((m0 + 32 * w + 8 + rin) * lda + cs_o * 8) * 2;   // A rows 32 w + {0, 8} + rin; +16 rows for pieces 2, 3
+  // LDS B row p = 16 w + 8 i + rin (i = 0, 1) <- weight row 64 (w >> 2) + 4 (8 i + rin) + (w & 3)
+  const int ob_e = ((n0 + 64 * (w >> 2) + 4 * rin + (w & 3)) * ldb + cs_e * 8) * 2;
+  const int ob_o = ((n0 + 64 * (w >> 2) + 4 * (8 + rin) + (w & 3)) * ldb + cs_o * 8) * 2;
+  const int a16 = 16 * lda * 2;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((int)lds_addr_of(smem));
+  const unsigned la = lds0 + (unsigned)w * 4096, lb = lds0 + RBM * 128 + (unsigned)w * 2048;
+  auto stage = [&](int s) __attribute__((always_inline)) {
+    const unsigned so = (unsigned)(s % 3) * SLOT;
+    const int kb = s * 128;
+    dma16_hidden(ra, la + so, oa_e + kb);
+    dma16_hidden(ra, la + so + 1024, oa_o + kb);
+    dma16_hidden(ra, la + so + 2048, oa_e + a16 + kb);
+    dma16_hidden(ra, la + so + 3072, oa_o + a16 + kb);
+    dma16_hidden(rb, lb + so, ob_e + kb);
+    dma16_hidden(rb, lb + so + 1024, ob_o + kb);
+  };
+
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int m[4] = {mb + 16 * i, mb + 16 * i + 1, mb + 16 * i + 2, mb + 16 * i + 3};
-    f32x4 v[4];
+  for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) v[r] = (f32x4){acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
-    epi_rows4<EPI>(e, m, M, n, v, bias);
-    __builtin_amdgcn_sched_barrier(0);  // keep the next row group's loads from being hoisted up here (register budget of the 2-blocks-per-CU build)
+    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  stage(0);
+  stage(1);
+  for (int s = 0; s < nks; s++) {
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // own pieces of slice s (slice s + 1 may still fly)
+    __builtin_amdgcn_s_barrier();
+    stage(s + 2);  // into the slot of slice s - 1 (beyond K: zeros, never read)
+    const unsigned char* sa = smem + (s % 3) * SLOT;
+    const unsigned char* sb = sa + RBM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      bf16x8 af[4], bfr[4];
+      const int ch = (l >> 4) + 4 * ks;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        af[i] = *(const bf16x8*)(sa + ring64_swz(64 * wm + 16 * i + (l & 15), ch));
+        bfr[i] = *(const bf16x8*)(sb + ring64_swz(64 * wn + 16 * i + (l & 15), ch));
+      }
+      if (ks == 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of this slice are retired before this wave can reach the next barrier
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ring_epilogue<EPI>(acc, e_in, m0, n0, wm, wn, l, M);
 }
 
 bool gemm_nt_ring_ok(int lda, int ldb, int M, int N, int K, const GemmEpi& e) {
@@ -224,6 +310,14 @@ static void launch_ring(const bf16_t* A, int lda, const bf16_t* B, int ldb, int 
 
 int gemm_nt_ring(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, int slots, hipStream_t st, int dbg) {
   if (e.act_gelu && e.dgelu_pre) { set_error("gemm_nt_ring: GELU and dGELU epilogues are exclusive"); return SMBV_ERR_ARG; }
+  if (slots == 64 && (K % 64) == 0) {
+    const int tm = cdiv(M, RBM), tn = N / RBN;
+    const dim3 grid(tm * tn), block(512);
+    if (e.act_gelu) hipLaunchKernelGGL((gemm_nt_ring64_kernel<1>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e);
+    else if (e.dgelu_pre) hipLaunchKernelGGL((gemm_nt_ring64_kernel<2>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e);
+    else hipLaunchKernelGGL((gemm_nt_ring64_kernel<0>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e);
+    return check_launch("gemm_nt_ring64");
+  }
   if (slots == 4) launch_ring<4>(A, lda, B, ldb, M, N, K, e, dbg, st);
   else launch_ring<3>(A, lda, B, ldb, M, N, K, e, dbg, st);
   return check_launch("gemm_nt_ring");

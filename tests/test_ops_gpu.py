@@ -333,7 +333,7 @@ def test_gemm_nt_ring_kernel_matches_reference_and_first_generation(ops, M, N, K
     pre_b = rnd(M, N, seed=7).bfloat16()
     ref = A.float() @ B.float().t()
     runs = {}
-    for v in (131072, 256, 131072 | 512):       # ring with 3 slots (two blocks per CU) forced, first generation forced, ring with 4 slots
+    for v in (131072, 256, 131072 | 512, 131072 | 262144):   # ring (3 slots, two blocks per CU) forced, first generation forced, ring with 4 slots, ring with 64-deep slices
         raw.smbv_debug_set_variant(v)
         try:
             runs[v] = (ops.gemm_nt(A, B, bias=bias, rowadd=resid, out_bf16=True, out_f32=True), ops.gemm_nt(A, B, bias=bias, gelu=True, save_pre=True),
@@ -348,7 +348,7 @@ def test_gemm_nt_ring_kernel_matches_reference_and_first_generation(ops, M, N, K
     torch.nn.functional.gelu(x).sum().backward()
     assert rel_err(r2["bf16"], ref * x.grad) < 8e-3
     assert rel_err(r3["f32"], 0.5 * ref) < 1e-5 * math.sqrt(K) + 1e-5
-    for v in (256, 131072 | 512):
+    for v in (256, 131072 | 512, 131072 | 262144):
         for a, b in zip(runs[131072], runs[v]):
             for k in a:
                 assert torch.equal(a[k], b[k]), (v, k)
