@@ -170,3 +170,54 @@ def test_vjepa_vit_base_512x512x320_matches_oracle():
     kb, _ = _cmp_grads(grads, ref_grads, 2e-1, 0.97, only=lambda k: k.endswith("attention.key.bias"))
     assert n >= 12 * 14 + 4
     print(f"full-size V-JEPA: loss {loss:.6f} (oracle {float(ref_loss):.6f}), enc rms {e_rms:.2e}, pred rms {p_rms:.2e}, worst grad {worst}, key.bias {kb}, {n} tensors")
+
+
+def test_vit_large_512x512x320_fp8_attention_and_recompute_match_oracle_forward():
+    """BASELINE.json config 5 at full size (one GPU; DP is the driver's): ViT-large (encoder 1024/24L/16H/4096, decoder 512/12L/8H/2048 as SURVEY.md 8d
+    assumes), 512x512x320, with the fp8 attention forward and per-layer recompute - loss and logits against the oracle's fp32 forward (~30 s of CPU),
+    next to the bf16 path on the same weights; the recompute step's backward must also reproduce the resident step's gradients bit for bit.
+    Stated tolerances: bf16 loss 5e-3 / logits rms 1e-2; fp8 attention loss 1e-2 / logits rms 5e-2 (tests/test_fp8_gpu.py)."""
+    from transformers import VideoMAEConfig
+    from smb_vision_amd.masking import MaskGenerator
+    from smb_vision_amd.modeling_videomae import SmbVideoMAEForPreTraining
+
+    large = dict(VIT_BASE, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, decoder_hidden_size=512,
+                 decoder_num_hidden_layers=12, decoder_num_attention_heads=8, decoder_intermediate_size=2048)
+    cfg = mo.MIMConfig(**large)
+    params = mo.init_params(cfg, seed=21, nonzero_small=True)
+    np.random.seed(7)
+    mask = MaskGenerator(512, 320, 32, 16, 0.65)().unsqueeze(0)
+    pix = torch.rand(1, 320, 1, 512, 512, generator=torch.Generator().manual_seed(77))
+
+    def run(**extra):
+        model = SmbVideoMAEForPreTraining(VideoMAEConfig(num_channels=1, **large, **extra))
+        model.load_state_dict(params, strict=True)
+        model = model.cuda().train()
+        if extra.get("smbv_recompute") == "always":
+            model.gradient_checkpointing_enable()
+        out = model(pixel_values=pix.cuda(), bool_masked_pos=mask.cuda())
+        out.loss.backward()
+        torch.cuda.synchronize()
+        res = (float(out.loss), out.logits.detach().float().cpu(), {k: p.grad.detach().cpu().clone() for k, p in list(model.named_parameters())[:40]},
+               model._ws.numel())
+        del model, out
+        torch.cuda.empty_cache()
+        return res
+
+    l_bf, g_bf, gr_bf, ws_bf = run()
+    l_f8, g_f8, gr_f8, ws_f8 = run(smbv_attention_fp8=True, smbv_recompute="always")
+    l_rc, g_rc, gr_rc, ws_rc = run(smbv_recompute="always")
+    assert l_rc == l_bf and torch.equal(g_rc, g_bf) and all(torch.equal(gr_rc[k], gr_bf[k]) for k in gr_bf)   # recompute: identical
+    assert ws_rc < 0.5 * ws_bf
+    mo.SDPA = True
+    try:
+        torch.set_num_threads(max(1, min(64, len(__import__("os").sched_getaffinity(0)))))
+        with torch.no_grad():
+            ref_loss, ref_logits = mo.mim_forward(params, cfg, pix, mask)
+    finally:
+        mo.SDPA = False
+    rms = lambda a: float((a - ref_logits).pow(2).mean().sqrt() / ref_logits.pow(2).mean().sqrt())
+    print(f"ViT-large full size: oracle loss {float(ref_loss):.6f}; bf16 {l_bf:.6f} (logits rms {rms(g_bf):.2e}); fp8 attention + recompute {l_f8:.6f} "
+          f"(logits rms {rms(g_f8):.2e}); workspace {ws_bf / 2**30:.1f} GiB resident, {ws_rc / 2**30:.1f} GiB with recompute")
+    assert abs(l_bf - float(ref_loss)) <= 5e-3 * float(ref_loss) and rms(g_bf) <= 1e-2
+    assert abs(l_f8 - float(ref_loss)) <= 1e-2 * float(ref_loss) and rms(g_f8) <= 5e-2
