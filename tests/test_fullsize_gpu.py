@@ -1,5 +1,5 @@
 """Full-size parity: the HIP train steps at the BENCHMARKED shapes (BASELINE.json configs 2 and 4: ViT-base, 512x512x320 volume,
-N = 20,480 tokens) against the CPU oracle on the same seeded inputs.  These are the launches bench.py times — S = 7,168 / 20,480
+N = 20,480 tokens; config 5: ViT-large with the fp8 attention forward and per-layer recompute) against the CPU oracle on the same seeded inputs.  These are the launches bench.py times — S = 7,168 / 20,480
 attention grids, the 256x256 weight-gradient tiles and their token slabs at M = 20,480, the ranged (Sq = 13,312, q_off = 7,168) last
 decoder block, the 5.3 GB workspace — which the small-shape tests cannot reach.
 
