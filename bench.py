@@ -299,6 +299,7 @@ def main():
                                                                "specifies none, SURVEY.md 8d) - diagnostic; not the metric")
     ap.add_argument("--fp8", action="store_true", help="attention forward on the block-scaled fp8 MFMA (config.smbv_attention_fp8; BASELINE config 5 with --vit-large) - diagnostic")
     ap.add_argument("--recompute", action="store_true", help="gradient checkpointing: per-layer recompute (config.smbv_recompute = always) - diagnostic")
+    ap.add_argument("--debug-variant", type=int, default=0, help="smbv_debug_set_variant bits (kernel A/B; diagnostic, not the metric)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse the N>1 path on one GPU)")
     args = ap.parse_args()
 
@@ -313,6 +314,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the MIM hot path has no CPU fallback")
     device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
+    if args.debug_variant:
+        from smb_vision_amd import _lib
+        _lib.load().smbv_debug_set_variant(args.debug_variant)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":

@@ -480,17 +480,22 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  for (int kt = 0; kt < nt; kt++) {
-    const unsigned char* cur = smem + (kt & 1) * BUF;
-    const unsigned char* nxt = smem + ((kt & 1) ^ 1) * BUF;
+  // one 128-key tile out of buffer `cb` (a literal at both call sites: every LDS read is a per-lane base plus an immediate)
+  auto tile = [&](int kt, int cb) __attribute__((always_inline)) {
+    const unsigned char* cur = smem + cb * BUF;
+    const unsigned char* nxt = smem + (cb ^ 1) * BUF;
     body(sA, sB, cur, 1, cur, 2);
     body(sB, sA, cur, 2, cur, 3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt+1 (requested a whole tile ago) have landed
     __syncthreads();                                  // ... everyone's have
     body(sA, sB, cur, 3, nxt, 0);
     __syncthreads();  // every wave is done with tile kt: its buffer takes tile kt+2
-    if (kt + 2 < nt) stage(kt & 1, kt + 2);
+    if (kt + 2 < nt) stage(cb, kt + 2);
     body(sB, sA, nxt, 0, nxt, 1);
+  };
+  for (int kt = 0; kt < nt; kt += 2) {
+    tile(kt, 0);
+    if (kt + 1 < nt) tile(kt + 1, 1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
 

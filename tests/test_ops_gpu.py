@@ -212,6 +212,27 @@ def test_attention_large_logits_stay_finite(ops):
     assert bool(torch.isfinite(dqkv.float()).all())
 
 
+@pytest.mark.parametrize("profile", ["rising", "falling", "spike"])
+def test_attention_reference_moves_across_tiles(ops, profile):
+    """Key norms that grow / shrink along the sequence or spike at one key: the row maxima move by hundreds (log2 units) between
+    64-key tiles, so the forward's deferred-maximum rebase fires on many tiles (rising), only on the first (falling), or once mid-row
+    (spike); a first tile far BELOW the later maxima must not leave 0 * inf behind."""
+    B, S, H = 1, 640, 2
+    w = H * 64
+    ramp = {"rising": torch.linspace(0.05, 60.0, S), "falling": torch.linspace(60.0, 0.05, S),
+            "spike": torch.where(torch.arange(S) == 400, 80.0, 0.1)}[profile]
+    qkv = rnd(B * S, 3 * w, seed=31)
+    qkv[:, w:2 * w] *= ramp.cuda()[:, None]
+    qkv[:, :w] *= 3.0
+    qkv = qkv.bfloat16()
+    O, lse = ops.attention_fwd(qkv, B, S, H)
+    assert bool(torch.isfinite(O.float()).all()) and bool(torch.isfinite(lse).all())
+    q, k, v, s = _attn_ref(qkv.double(), B, S, H)
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * S, w)
+    assert rms_err(O, ref.float()) < 6e-2  # (as above: |s| in the hundreds, bf16 re-rounding of the pre-scaled Q)
+    assert rel_err(lse, torch.logsumexp(s, -1).float()) < 8e-3
+
+
 @pytest.mark.parametrize("ps,ts", [(16, 16), (8, 8), (4, 8)])
 def test_bricks_stats_mse(ops, ps, ts):
     B, T, H, W = 2, 32, 64, 64
