@@ -387,7 +387,7 @@ def main():
 
     # second timed region: SURVEY.md §8(d)'s step - a NEW volume from host memory and a NEW mask every step
     fed = None
-    if not args.no_feed and not args.tiny:
+    if world == 1 and not args.no_feed and not args.tiny:  # (a 1-GPU figure; the scaling runs time the resident step only)
         from smb_vision_amd.feed import VolumeFeeder
         feeder = VolumeFeeder(_FedSource(rank, gen, cfg_kw["image_size"], cfg_kw["num_frames"]), device, cfg_kw["image_size"], cfg_kw["num_frames"])
         it = iter(feeder)

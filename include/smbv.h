@@ -84,8 +84,9 @@ int smbv_layernorm_bwd(const smbv_bf16* dy, const float* x, const float* mean, c
                        long grp_out, long row_off, void* ws, size_t ws_bytes, smbv_stream stream);
 size_t smbv_layernorm_bwd_workspace_bytes(int rows, int D);
 
-/* softmax_fp32(Q K^T * scale) V, head_dim 64 (spec :196-223, dispatched at :270-289).  Q,K,V: column slices of one
- * token-major [B*S, ld] matrix (head h at columns h*64..); O: [B*S, ldo]; LSE/delta: fp32 [B,H,Sq].
+/* softmax_fp32(Q K^T * scale) V, Dh = 64 (spec :196-223, dispatched at :270-289) or Dh = 32 (the V-JEPA predictor's heads, src/models/vjepa/
+ * modeling_vjepa.py:251-253); any other Dh is SMBV_ERR_SHAPE (the step functions run such heads zero-padded in 64-wide slots).  Q,K,V: column
+ * slices of one token-major [B*S, ld] matrix (head h at columns h*Dh..); O: [B*S, ldo]; LSE/delta: fp32 [B,H,Sq].
  * Sq/q_off: only the queries q_off .. q_off+Sq-1 of every sequence are computed (keys/values: all S); Sq <= 0 means all.
  * (The last decoder block only needs its masked tokens' outputs: spec :717-718 keeps hidden_states[:, -return_token_num:].) */
 int smbv_attention_fwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, smbv_bf16* O, int ldo, float* LSE,

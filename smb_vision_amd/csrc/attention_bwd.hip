@@ -27,6 +27,28 @@ __device__ __forceinline__ int swz128(int row, int c16) {
   return row * 128 + ((c16 ^ (((x & 1) << 2) | (x >> 1))) << 4);
 }
 
+// image row swizzle by head width: 64 -> swz128; 32 -> 64-byte rows, 16-B chunk c of row r at chunk c ^ ((r >> 2) & 3): every ds_read_b128 lane
+// group covers the 64 banks, and within a ds_read_b64_tr_b16 group (4 consecutive rows of a 4-aligned block) the XOR is a constant, so the 4 rows x
+// 4 chunks x 2 halves tile the banks as well
+template <int DH>
+__device__ __forceinline__ int swzr(int row, int c16) {
+  if constexpr (DH == 64) return swz128(row, c16);
+  else return row * 64 + ((c16 ^ ((row >> 2) & 3)) << 4);
+}
+// per-lane SOURCE byte offset (row-major operand, leading dimension ld elements) of LDS-DMA piece i of a wave's 32 rows: a piece lands lane-linear
+// (1 KiB: 8 rows x 128 B at DH 64, 16 rows x 64 B at DH 32), so the image's chunk permutation is applied to the source chunk
+template <int DH>
+__device__ __forceinline__ int dma_src_off(int w, int i, int l, int ld) {
+  if constexpr (DH == 64) {
+    const int row = 32 * w + 8 * i + (l >> 3);
+    const int x = (row >> 1) & 7;
+    return (row * ld + ((l & 7) ^ (((x & 1) << 2) | (x >> 1))) * 8) * 2;
+  } else {
+    const int row = 32 * w + 16 * i + (l >> 2);
+    return (row * ld + ((l & 3) ^ ((row >> 2) & 3)) * 8) * 2;
+  }
+}
+
 __device__ __forceinline__ bf16x8 scale_frag(u32x4 v, float c) {
   u32x4 o;
 #pragma unroll
@@ -34,26 +56,28 @@ __device__ __forceinline__ bf16x8 scale_frag(u32x4 v, float c) {
   return __builtin_bit_cast(bf16x8, o);
 }
 
+template <int DH>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO, int ldo,
                                                          float* __restrict__ delta, int B, int S, int Sq, int qoff, int H) {
-  // 8 lanes per (row, head): 16 B each
+  // DH / 8 lanes per (row, head): 16 B each
+  constexpr int LP = DH / 8;
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  const long pair = gid >> 3;
-  const int sub = gid & 7;
+  const long pair = gid / LP;
+  const int sub = gid % LP;
   const long total = (long)B * Sq * H;
   float acc = 0.f;
   if (pair < total) {
     const long rq = pair / H;
     const long row = (rq / Sq) * S + qoff + (rq % Sq);
     const int head = pair % H;
-    const u32x4 o = *(const u32x4*)(O + row * ldo + head * 64 + sub * 8);
-    const u32x4 g = *(const u32x4*)(dO + row * ldo + head * 64 + sub * 8);
+    const u32x4 o = *(const u32x4*)(O + row * ldo + head * DH + sub * 8);
+    const u32x4 g = *(const u32x4*)(dO + row * ldo + head * DH + sub * 8);
 #pragma unroll
     for (int i = 0; i < 4; i++) acc += bf_lo(o[i]) * bf_lo(g[i]) + bf_hi(o[i]) * bf_hi(g[i]);
   }
   acc += __shfl_xor(acc, 1, 64);
   acc += __shfl_xor(acc, 2, 64);
-  acc += __shfl_xor(acc, 4, 64);
+  if constexpr (LP == 8) acc += __shfl_xor(acc, 4, 64);
   if (pair < total && sub == 0) {
     const long rq = pair / H;
     const int head = pair % H;
@@ -79,29 +103,32 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // The next 128-query tile is copied into the other LDS buffer by LDS-DMA during sub-tiles 0..2 (two barriers per iteration: at the
 // top "everyone has left the previous tile", after sub-tile 2 "the new tile has landed"), so the last sub-tile prefetches across
 // the tile seam as well and the staging costs no registers.
-template <int QT>
+template <int QT, int DH>
 __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                            const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO,
                                                            int ldo, const float* __restrict__ LSE, const float* __restrict__ delta,
                                                            bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int ldd, int S, int Sq, int qoff,
                                                            int H, float scale) {
   static_assert(QT == 128, "the mid-iteration hand-over is written for 4 sub-tiles");
+  static_assert(DH == 64 || DH == 32, "head widths with a native build");
   constexpr int NS = QT / 32;
-  constexpr int BUF = 2 * QT * 128 + 2 * QT * 4;
+  constexpr int KS = DH / 16, DT = DH / 32, RB = 2 * DH;  // QK^T-type k-steps, 32-channel output tiles, LDS row bytes
+  constexpr int NPC = 32 * RB / 1024;                     // LDS-DMA pieces per wave and image (32 rows)
+  constexpr int BUF = 2 * QT * RB + 2 * QT * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int r = l & 31, h2 = l >> 5;
   const int head = blockIdx.y, b = blockIdx.z;
   const size_t row0 = (size_t)b * S;
   const int key = blockIdx.x * 128 + w * 32 + r;
-  const int hoff = head * 64;
+  const int hoff = head * DH;
   const float c = scale * 1.4426950408889634f;
   const float* lse_p = LSE + ((size_t)b * H + head) * Sq;
   const float* del_p = delta + ((size_t)b * H + head) * Sq;
 
-  bf16x8 kf[4], vf[4];
+  bf16x8 kf[KS], vf[KS];
 #pragma unroll
-  for (int ks = 0; ks < 4; ks++) {
+  for (int ks = 0; ks < KS; ks++) {
     u32x4 a = {0, 0, 0, 0}, bb = {0, 0, 0, 0};
     if (key < S) {
       a = *(const u32x4*)(K + (row0 + key) * ld + hoff + 16 * ks + 8 * h2);
@@ -111,40 +138,35 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
     kf[ks] = scale_frag(a, c);
     vf[ks] = __builtin_bit_cast(bf16x8, bb);
   }
-  f32x16 dkt[2], dvt[2];
+  f32x16 dkt[DT], dvt[DT];
 #pragma unroll
-  for (int i = 0; i < 16; i++) { dkt[0][i] = 0.f; dkt[1][i] = 0.f; dvt[0][i] = 0.f; dvt[1][i] = 0.f; }
+  for (int i = 0; i < 16; i++)
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) { dkt[dt][i] = 0.f; dvt[dt][i] = 0.f; }
 
   // Q / dO tiles go global -> LDS by LDS-DMA: wave w stages rows 32w..32w+31 of both images as 4 + 4 pieces of 8 rows x 128 B.
   // A piece lands lane-linear (lane -> row l>>3, chunk position l&7), so the swz128 permutation is applied to the SOURCE chunk.
   // Rows >= Sq are outside the descriptors' range and arrive as zeros.
-  const i32x4 rsq = dma_rsrc(Q + (row0 + qoff) * ld + hoff, (unsigned)(((size_t)(Sq - 1) * ld + 64) * 2));
-  const i32x4 rsd = dma_rsrc(dO + (row0 + qoff) * ldo + hoff, (unsigned)(((size_t)(Sq - 1) * ldo + 64) * 2));
-  int oq[4], od[4];
+  const i32x4 rsq = dma_rsrc(Q + (row0 + qoff) * ld + hoff, (unsigned)(((size_t)(Sq - 1) * ld + DH) * 2));
+  const i32x4 rsd = dma_rsrc(dO + (row0 + qoff) * ldo + hoff, (unsigned)(((size_t)(Sq - 1) * ldo + DH) * 2));
+  int oq[NPC], od[NPC];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int row = 32 * w + 8 * i + (l >> 3);
-    const int x = (row >> 1) & 7;
-    const int cs = (l & 7) ^ (((x & 1) << 2) | (x >> 1));
-    oq[i] = (row * ld + cs * 8) * 2;
-    od[i] = (row * ldo + cs * 8) * 2;
+  for (int i = 0; i < NPC; i++) {
+    oq[i] = dma_src_off<DH>(w, i, l, ld);
+    od[i] = dma_src_off<DH>(w, i, l, ldo);
   }
-  const int oq0 = oq[0], oq1 = oq[1], oq2 = oq[2], oq3 = oq[3], od0 = od[0], od1 = od[1], od2 = od[2], od3 = od[3];
-  const unsigned lds_w = __builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem) + (t >> 6) * 4096));
+  const unsigned lds_w = __builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem) + (t >> 6) * (32 * RB)));
   // The copies and the row-constant load are issued from asm statements (smbv_common.h): hipcc would otherwise drain them with a
   // vmcnt(0) in front of the very next LDS read.  They are waited for once, explicitly, before the "landed" barrier.
   float rraw = 0.f;
   auto stage = [&](int buf, int qt) __attribute__((always_inline)) {
-    const unsigned dq_ = lds_w + (unsigned)buf * BUF, dd_ = dq_ + QT * 128;
+    const unsigned dq_ = lds_w + (unsigned)buf * BUF, dd_ = dq_ + QT * RB;
     const int kq = qt * QT * ld * 2, kd = qt * QT * ldo * 2;
-    dma16_hidden(rsq, dq_, oq0 + kq);
-    dma16_hidden(rsd, dd_, od0 + kd);
-    dma16_hidden(rsq, dq_ + 1024, oq1 + kq);
-    dma16_hidden(rsd, dd_ + 1024, od1 + kd);
-    dma16_hidden(rsq, dq_ + 2048, oq2 + kq);
-    dma16_hidden(rsd, dd_ + 2048, od2 + kd);
-    dma16_hidden(rsq, dq_ + 3072, oq3 + kq);
-    dma16_hidden(rsd, dd_ + 3072, od3 + kd);
+#pragma unroll
+    for (int i = 0; i < NPC; i++) {
+      dma16_hidden(rsq, dq_ + 1024 * i, oq[i] + kq);
+      dma16_hidden(rsd, dd_ + 1024 * i, od[i] + kd);
+    }
     const int qi = min(qt * QT + (t & (QT - 1)), Sq - 1);  // threads 0..QT-1: lse, QT..2QT-1: delta (rows past Sq: clamped, fixed up below)
     const float* src = (t < QT ? lse_p : del_p) + qi;
     asm volatile("global_load_dword %0, %1, off" : "=v"(rraw) : "v"(src) : "memory");
@@ -161,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
     if (t < 2 * QT) {
       const int rr = t % QT;
       const int pos = (rr & ~31) + 16 * ((rr >> 2) & 1) + 4 * ((rr & 31) >> 3) + (rr & 3);
-      ((float*)(smem + buf * BUF + 2 * QT * 128))[(t / QT) * QT + pos] = rstat;
+      ((float*)(smem + buf * BUF + 2 * QT * RB))[(t / QT) * QT + pos] = rstat;
     }
   };
 
@@ -173,8 +195,8 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
     const int qb = rb + 16 * s2 + 4 * h2 + qq;
     const int c16 = 4 * dt + 2 * g1 + (pp >> 1);
     const int sb8 = 8 * (pp & 1);
-    const s16x4 a0 = lds_read_tr16(img + swz128(qb, c16) + sb8);
-    const s16x4 a1 = lds_read_tr16(img + swz128(qb + 8, c16) + sb8);
+    const s16x4 a0 = lds_read_tr16(img + swzr<DH>(qb, c16) + sb8);
+    const s16x4 a1 = lds_read_tr16(img + swzr<DH>(qb + 8, c16) + sb8);
     const s16x8 aa = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
     return __builtin_bit_cast(bf16x8, aa);
   };
@@ -183,17 +205,17 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
   landed(0);
   put_stats(0);
   __syncthreads();
-  bf16x8 qa[4], da[4];
+  bf16x8 qa[KS], da[KS];
   f32x16 s, dp;
   {
     const unsigned char* sq = smem;
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-      qa[ks] = *(const bf16x8*)(sq + swz128(r, 2 * ks + h2));
-      da[ks] = *(const bf16x8*)(sq + QT * 128 + swz128(r, 2 * ks + h2));
+    for (int ks = 0; ks < KS; ks++) {
+      qa[ks] = *(const bf16x8*)(sq + swzr<DH>(r, 2 * ks + h2));
+      da[ks] = *(const bf16x8*)(sq + QT * RB + swzr<DH>(r, 2 * ks + h2));
     }
-    s = *(const f32x16*)((const float*)(sq + 2 * QT * 128) + 16 * h2);
-    dp = *(const f32x16*)((const float*)(sq + 2 * QT * 128) + QT + 16 * h2);
+    s = *(const f32x16*)((const float*)(sq + 2 * QT * RB) + 16 * h2);
+    dp = *(const f32x16*)((const float*)(sq + 2 * QT * RB) + QT + 16 * h2);
   }
   for (int qt = 0; qt < nq; qt++) {
     const int buf = qt & 1;
@@ -201,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
     __syncthreads();  // every wave has left the previous tile: its buffer may be overwritten
     if (more) stage(buf ^ 1, qt + 1);
     const unsigned char* sq = smem + buf * BUF;
-    const unsigned char* sdo = sq + QT * 128;
+    const unsigned char* sdo = sq + QT * RB;
 #pragma unroll
     for (int sub = 0; sub < NS; sub++) {
       const int rb = 32 * sub;
@@ -209,14 +231,14 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
       const unsigned char* nq_img = (sub + 1 < NS) ? sq : smem + (buf ^ 1) * BUF;
       const int nrb = (sub + 1 < NS) ? rb + 32 : 0;
       const bool pre = (sub + 1 < NS) || more;
-      bf16x8 ta[2][2], tb[2][2], pf[2], dsf[2];
+      bf16x8 ta[2][DT], tb[2][DT], pf[2], dsf[2];
       // ---- chain 1
 #pragma unroll
-      for (int ks = 0; ks < 4; ks++) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[ks], s, 0, 0, 0);
+      for (int ks = 0; ks < KS; ks++) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[ks], s, 0, 0, 0);
 #pragma unroll
       for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
-        for (int dt = 0; dt < 2; dt++) ta[s2][dt] = tr_frag(sdo, rb, s2, dt);
+        for (int dt = 0; dt < DT; dt++) ta[s2][dt] = tr_frag(sdo, rb, s2, dt);
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
@@ -225,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
       __builtin_amdgcn_sched_barrier(0);
       // ---- chain 2
 #pragma unroll
-      for (int ks = 0; ks < 4; ks++) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vf[ks], dp, 0, 0, 0);
+      for (int ks = 0; ks < KS; ks++) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vf[ks], dp, 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 16; i++) s[i] = fast_exp2(s[i]);
 #pragma unroll
@@ -235,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
 #pragma unroll
       for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
-        for (int dt = 0; dt < 2; dt++) tb[s2][dt] = tr_frag(sq, rb, s2, dt);
+        for (int dt = 0; dt < DT; dt++) tb[s2][dt] = tr_frag(sq, rb, s2, dt);
       __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
       __builtin_amdgcn_sched_group_barrier(SG_DSR, 4, 0);
       __builtin_amdgcn_sched_group_barrier(SG_TRANS, 2, 0);
@@ -255,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
 #pragma unroll
       for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
-        for (int dt = 0; dt < 2; dt++) dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[s2][dt], pf[s2], dvt[dt], 0, 0, 0);
+        for (int dt = 0; dt < DT; dt++) dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ta[s2][dt], pf[s2], dvt[dt], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 16; i++) dp[i] *= s[i];
 #pragma unroll
@@ -264,8 +286,8 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
         for (int j = 0; j < 8; j++) dsf[s2][j] = (__bf16)dp[8 * s2 + j];
       if (pre) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) qa[ks] = *(const bf16x8*)(nq_img + swz128(nrb + r, 2 * ks + h2));
-        s = *(const f32x16*)((const float*)(nq_img + 2 * QT * 128) + nrb + 16 * h2);
+        for (int ks = 0; ks < KS; ks++) qa[ks] = *(const bf16x8*)(nq_img + swzr<DH>(nrb + r, 2 * ks + h2));
+        s = *(const f32x16*)((const float*)(nq_img + 2 * QT * RB) + nrb + 16 * h2);
       }
 #pragma unroll
       for (int i = 0; i < 4; i++) {
@@ -278,11 +300,11 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
 #pragma unroll
       for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
-        for (int dt = 0; dt < 2; dt++) dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tb[s2][dt], dsf[s2], dkt[dt], 0, 0, 0);
+        for (int dt = 0; dt < DT; dt++) dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tb[s2][dt], dsf[s2], dkt[dt], 0, 0, 0);
       if (pre) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) da[ks] = *(const bf16x8*)(nq_img + QT * 128 + swz128(nrb + r, 2 * ks + h2));
-        dp = *(const f32x16*)((const float*)(nq_img + 2 * QT * 128) + QT + nrb + 16 * h2);
+        for (int ks = 0; ks < KS; ks++) da[ks] = *(const bf16x8*)(nq_img + QT * RB + swzr<DH>(nrb + r, 2 * ks + h2));
+        dp = *(const f32x16*)((const float*)(nq_img + 2 * QT * RB) + QT + nrb + 16 * h2);
       }
 #pragma unroll
       for (int i = 0; i < 4; i++) {
@@ -301,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
     bf16_t* kp = dK + (row0 + key) * ldd + hoff;
     bf16_t* vp = dV + (row0 + key) * ldd + hoff;
 #pragma unroll
-    for (int dt = 0; dt < 2; dt++)
+    for (int dt = 0; dt < DT; dt++)
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
         const int d0 = 32 * dt + 8 * rg + 4 * h2;
@@ -323,25 +345,28 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
 // K/V tiles of 128 keys arrive by LDS-DMA two tiles ahead into a 2-buffer ring (barriers: before body 2 "tile T+1 has landed",
 // before body 3 "tile T is dead", after which tile T+2 is requested into its buffer).  The pipeline's last body runs its A and C
 // chains on a stale sub-tile; their results are never used.
-template <int KT>
+template <int KT, int DH>
 __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                           const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO, int ldo,
                                                           const float* __restrict__ LSE, const float* __restrict__ delta,
                                                           bf16_t* __restrict__ dQ, int ldd, int S, int Sq, int qoff, int H, float scale) {
   static_assert(KT == 128, "bodies are unrolled for 4 sub-tiles per tile");
-  constexpr int BUF = 2 * KT * 128;  // K image | V image
+  static_assert(DH == 64 || DH == 32, "head widths with a native build");
+  constexpr int KS = DH / 16, DT = DH / 32, RB = 2 * DH;  // QK^T-type k-steps, 32-channel output tiles, LDS row bytes
+  constexpr int NPC = 32 * RB / 1024;                     // LDS-DMA pieces per wave and image (32 rows)
+  constexpr int BUF = 2 * KT * RB;  // K image | V image
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int r = l & 31, h2 = l >> 5;
   const int head = blockIdx.y, b = blockIdx.z;
   const size_t row0 = (size_t)b * S;
   const int q = blockIdx.x * 128 + w * 32 + r;
-  const int hoff = head * 64;
+  const int hoff = head * DH;
   const float c = scale * 1.4426950408889634f;
 
-  bf16x8 qf[4], dof[4];
+  bf16x8 qf[KS], dof[KS];
 #pragma unroll
-  for (int ks = 0; ks < 4; ks++) {
+  for (int ks = 0; ks < KS; ks++) {
     u32x4 a = {0, 0, 0, 0}, bb = {0, 0, 0, 0};
     if (q < Sq) {
       a = *(const u32x4*)(Q + (row0 + qoff + q) * ld + hoff + 16 * ks + 8 * h2);
@@ -360,53 +385,47 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
   f32x16 sinit, dinit;
 #pragma unroll
   for (int i = 0; i < 16; i++) { sinit[i] = nlse2; dinit[i] = ndl; }
-  f32x16 dqt[2];
+  f32x16 dqt[DT];
 #pragma unroll
-  for (int i = 0; i < 16; i++) { dqt[0][i] = 0.f; dqt[1][i] = 0.f; }
+  for (int i = 0; i < 16; i++)
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) dqt[dt][i] = 0.f;
 
   // LDS-DMA staging: wave w copies rows 32w..32w+31 of the K and V tiles (4 + 4 pieces of 8 rows x 128 B, swz128 applied to the
   // source chunk); rows >= S are outside the descriptors and arrive as zeros.
-  const i32x4 rsk = dma_rsrc(K + row0 * ld + hoff, (unsigned)(((size_t)(S - 1) * ld + 64) * 2));
-  const i32x4 rsv = dma_rsrc(V + row0 * ld + hoff, (unsigned)(((size_t)(S - 1) * ld + 64) * 2));
-  int og[4];
+  const i32x4 rsk = dma_rsrc(K + row0 * ld + hoff, (unsigned)(((size_t)(S - 1) * ld + DH) * 2));
+  const i32x4 rsv = dma_rsrc(V + row0 * ld + hoff, (unsigned)(((size_t)(S - 1) * ld + DH) * 2));
+  int og[NPC];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int row = 32 * w + 8 * i + (l >> 3);
-    const int x = (row >> 1) & 7;
-    og[i] = (row * ld + ((l & 7) ^ (((x & 1) << 2) | (x >> 1))) * 8) * 2;
-  }
-  const int og0 = og[0], og1 = og[1], og2 = og[2], og3 = og[3];
-  const unsigned lds_w = __builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem) + (t >> 6) * 4096));
+  for (int i = 0; i < NPC; i++) og[i] = dma_src_off<DH>(w, i, l, ld);
+  const unsigned lds_w = __builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem) + (t >> 6) * (32 * RB)));
   // (issued from asm statements, see smbv_common.h: hipcc would drain a visible LDS-DMA in front of the next LDS read)
   auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
-    const unsigned dk_ = lds_w + (unsigned)buf * BUF, dv_ = dk_ + KT * 128;
+    const unsigned dk_ = lds_w + (unsigned)buf * BUF, dv_ = dk_ + KT * RB;
     const int ko = kt * KT * ld * 2;
-    dma16_hidden(rsk, dk_, og0 + ko);
-    dma16_hidden(rsv, dv_, og0 + ko);
-    dma16_hidden(rsk, dk_ + 1024, og1 + ko);
-    dma16_hidden(rsv, dv_ + 1024, og1 + ko);
-    dma16_hidden(rsk, dk_ + 2048, og2 + ko);
-    dma16_hidden(rsv, dv_ + 2048, og2 + ko);
-    dma16_hidden(rsk, dk_ + 3072, og3 + ko);
-    dma16_hidden(rsv, dv_ + 3072, og3 + ko);
+#pragma unroll
+    for (int i = 0; i < NPC; i++) {
+      dma16_hidden(rsk, dk_ + 1024 * i, og[i] + ko);
+      dma16_hidden(rsv, dv_ + 1024 * i, og[i] + ko);
+    }
   };
 
   const int g1 = (l >> 4) & 1, qq = (l >> 2) & 3, pp = l & 3;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   auto rows = [&](const unsigned char* img, int sub, bf16x8* f) __attribute__((always_inline)) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) f[ks] = *(const bf16x8*)(img + swz128(32 * sub + r, 2 * ks + h2));
+    for (int ks = 0; ks < KS; ks++) f[ks] = *(const bf16x8*)(img + swzr<DH>(32 * sub + r, 2 * ks + h2));
   };
-  auto trk = [&](const unsigned char* img, int sub, bf16x8 (*f)[2]) __attribute__((always_inline)) {
+  auto trk = [&](const unsigned char* img, int sub, bf16x8 (*f)[DT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
-      for (int dt = 0; dt < 2; dt++) {
+      for (int dt = 0; dt < DT; dt++) {
         const int kb = 32 * sub + 16 * s2 + 4 * h2 + qq;
         const int c16 = 4 * dt + 2 * g1 + (pp >> 1);
         const int sb8 = 8 * (pp & 1);
-        const s16x4 a0 = lds_read_tr16(img + swz128(kb, c16) + sb8);
-        const s16x4 a1 = lds_read_tr16(img + swz128(kb + 8, c16) + sb8);
+        const s16x4 a0 = lds_read_tr16(img + swzr<DH>(kb, c16) + sb8);
+        const s16x4 a1 = lds_read_tr16(img + swzr<DH>(kb + 8, c16) + sb8);
         const s16x8 aa = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
         f[s2][dt] = __builtin_bit_cast(bf16x8, aa);
       }
@@ -417,17 +436,17 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
   if (nt > 1) stage(1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  bf16x8 ka[4], va[4], tk[2][2];
+  bf16x8 ka[KS], va[KS], tk[2][DT];
   f32x16 sA, sB, dp;
   {
     rows(smem, 0, ka);
-    rows(smem + KT * 128, 0, va);
+    rows(smem + KT * RB, 0, va);
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], ks == 0 ? sinit : sA, 0, 0, 0);
+    for (int ks = 0; ks < KS; ks++) sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], ks == 0 ? sinit : sA, 0, 0, 0);
     rows(smem, 1, ka);
     trk(smem, 0, tk);
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[ks], dof[ks], ks == 0 ? dinit : dp, 0, 0, 0);
+    for (int ks = 0; ks < KS; ks++) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[ks], dof[ks], ks == 0 ? dinit : dp, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 16; i++) sA[i] = fast_exp2(sA[i]);
   }
@@ -436,14 +455,14 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
     bf16x8 dsf[2];
     // ---- chain A
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) sN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], ks == 0 ? sinit : sN, 0, 0, 0);
+    for (int ks = 0; ks < KS; ks++) sN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], ks == 0 ? sinit : sN, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 16; i++) dp[i] *= sC[i];
 #pragma unroll
     for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
       for (int j = 0; j < 8; j++) dsf[s2][j] = (__bf16)dp[8 * s2 + j];
-    rows(img1 + KT * 128, sub1, va);
+    rows(img1 + KT * RB, sub1, va);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
@@ -455,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
 #pragma unroll
     for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
-      for (int dt = 0; dt < 2; dt++) dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tk[s2][dt], dsf[s2], dqt[dt], 0, 0, 0);
+      for (int dt = 0; dt < DT; dt++) dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tk[s2][dt], dsf[s2], dqt[dt], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 8; i++) { sN[i] = fast_exp2(sN[i]); asm volatile("" : "+v"(sN[i])); }  // (pinned: hipcc otherwise sinks the last body's exps into the next iteration's head)
     rows(img2, sub2, ka);
@@ -468,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
     __builtin_amdgcn_sched_barrier(0);
     // ---- chain C
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[ks], dof[ks], ks == 0 ? dinit : dp, 0, 0, 0);
+    for (int ks = 0; ks < KS; ks++) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[ks], dof[ks], ks == 0 ? dinit : dp, 0, 0, 0);
 #pragma unroll
     for (int i = 8; i < 16; i++) { sN[i] = fast_exp2(sN[i]); asm volatile("" : "+v"(sN[i])); }
     trk(img1, sub1, tk);
@@ -502,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
   if (q < Sq) {
     bf16_t* qp = dQ + (row0 + qoff + q) * ldd + hoff;
 #pragma unroll
-    for (int dt = 0; dt < 2; dt++)
+    for (int dt = 0; dt < DT; dt++)
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
         const int d0 = 32 * dt + 8 * rg + 4 * h2;
@@ -516,14 +535,15 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
                   float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st) {
   if (Sq <= 0) { Sq = S; qoff = 0; }
   if (qoff < 0 || qoff + Sq > S) { set_error("attention_bwd: query range outside the sequence"); return SMBV_ERR_SHAPE; }
-  if (Dh != 64) { set_error("attention_bwd: head_dim %d not supported (only 64)", Dh); return SMBV_ERR_SHAPE; }
+  if (Dh != 64 && Dh != 32) { set_error("attention_bwd: head_dim %d not supported (64 or 32; other widths run zero-padded in 64-wide slots, block.h)", Dh); return SMBV_ERR_SHAPE; }
   if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 7) || (ldd & 3)) { set_error("attention_bwd: bad shape"); return SMBV_ERR_SHAPE; }
   if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)dO) & 15) || (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 7)) { set_error("attention_bwd: alignment"); return SMBV_ERR_ALIGN; }
   if ((size_t)(S + 256) * ld * 2 >= (1ull << 31) || (size_t)(S + 256) * ldo * 2 >= (1ull << 31)) { set_error("attention_bwd: one sequence spans >= 2 GiB of an operand matrix; the LDS-DMA offsets are 32-bit"); return SMBV_ERR_SHAPE; }
   const long pairs = (long)B * Sq * H;
   int rc = SMBV_OK;
   if (parts & 1) {
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(pairs * 8, 256)), dim3(256), 0, st, O, dO, ldo, delta, B, S, Sq, qoff, H);
+    if (Dh == 64) hipLaunchKernelGGL(attn_delta_kernel<64>, dim3(cdiv(pairs * 8, 256)), dim3(256), 0, st, O, dO, ldo, delta, B, S, Sq, qoff, H);
+    else hipLaunchKernelGGL(attn_delta_kernel<32>, dim3(cdiv(pairs * 4, 256)), dim3(256), 0, st, O, dO, ldo, delta, B, S, Sq, qoff, H);
     rc = check_launch("attn_delta");
     if (rc) return rc;
   }
@@ -541,12 +561,14 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     }
   }
   if (parts & 2) {
-    hipLaunchKernelGGL((attn_dkv2_kernel<128>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale);
+    if (Dh == 64) hipLaunchKernelGGL((attn_dkv2_kernel<128, 64>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale);
+    else hipLaunchKernelGGL((attn_dkv2_kernel<128, 32>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale);
     rc = check_launch("attn_dkv");
     if (rc) return rc;
   }
   if (parts & 4) {
-    hipLaunchKernelGGL((attn_dq2_kernel<128>), dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale);
+    if (Dh == 64) hipLaunchKernelGGL((attn_dq2_kernel<128, 64>), dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale);
+    else hipLaunchKernelGGL((attn_dq2_kernel<128, 32>), dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale);
     rc = check_launch("attn_dq");
   }
   if (fj) {

@@ -59,9 +59,16 @@ __device__ __forceinline__ bf16x8 scale_bf16x8(u32x4 v, float c) {
 }
 
 
+// DH = 64: K / V images with 128-byte rows (swz_k64 / swz_v64), a copy piece is 8 rows.  DH = 32 (the V-JEPA predictor's heads): 64-byte rows,
+// a copy piece is 16 rows; the K image keeps 16-B chunk c of row r at chunk c ^ ((r >> 2) & 3) (every ds_read_b128 lane group covers the 64 banks),
+// the V image needs no swizzle at all (the 4 keys x 2 column halves x 4 sub-columns of a tr-read group already tile the 64 banks).
+template <int DH>
 __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, int ld,
                                                            bf16_t* __restrict__ O, int ldo, float* __restrict__ LSE, int S, int Sq, int qoff, int H, float scale) {
-  constexpr int SLOT = 2 * 64 * 128;  // K image | V image
+  static_assert(DH == 64 || DH == 32, "head widths with a native build");
+  constexpr int KS = DH / 16, DT = DH / 32, RB = 2 * DH;  // QK^T k-steps, 32-channel output tiles, LDS row bytes
+  constexpr int IMG = 64 * RB, SLOT = 2 * IMG;           // K image | V image
+  constexpr int NP = IMG / 1024 / 4 * 2;                  // copy pieces per wave and tile (K + V): 4 at DH 64, 2 at DH 32
   __shared__ __attribute__((aligned(16))) unsigned char smem[3 * SLOT];
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -69,57 +76,72 @@ __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restr
   const int head = blockIdx.y, b = blockIdx.z;
   const size_t row0 = (size_t)b * S;
   const int q = blockIdx.x * 128 + w * 32 + r;
-  const int hoff = head * 64;
+  const int hoff = head * DH;
   const float c = scale * 1.4426950408889634f;
 
-  bf16x8 qf[4];
+  bf16x8 qf[KS];
 #pragma unroll
-  for (int ks = 0; ks < 4; ks++) {
+  for (int ks = 0; ks < KS; ks++) {
     u32x4 v = {0, 0, 0, 0};
     if (q < Sq) v = *(const u32x4*)(Q + (row0 + qoff + q) * ld + hoff + 16 * ks + 8 * h2);
     asm volatile("" : "+v"(v));  // consumed here: the wait for these loads stays out of the tile loop
     qf[ks] = scale_bf16x8(v, c);
   }
-  f32x16 ot[2], cneg;
+  f32x16 ot[DT], cneg;
 #pragma unroll
-  for (int i = 0; i < 16; i++) { ot[0][i] = 0.f; ot[1][i] = 0.f; cneg[i] = 0.f; }
+  for (int i = 0; i < 16; i++) {
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) ot[dt][i] = 0.f;
+    cneg[i] = 0.f;
+  }
   float m2 = 0.f, l_a = 0.f;
 
-  const i32x4 rsk = dma_rsrc(K + row0 * ld + hoff, (unsigned)(((size_t)(S - 1) * ld + 64) * 2));
-  const i32x4 rsv = dma_rsrc(V + row0 * ld + hoff, (unsigned)(((size_t)(S - 1) * ld + 64) * 2));
-  const int rw0 = 16 * w + (l >> 3), rw1 = rw0 + 8;
-  const int ok0 = (rw0 * ld + ((l & 7) ^ ((rw0 >> 1) & 7)) * 8) * 2, ok1 = (rw1 * ld + ((l & 7) ^ ((rw1 >> 1) & 7)) * 8) * 2;
-  const int ov0 = (rw0 * ld + ((l & 7) ^ (((rw0 >> 1) & 1) << 2)) * 8) * 2, ov1 = (rw1 * ld + ((l & 7) ^ (((rw1 >> 1) & 1) << 2)) * 8) * 2;
+  const i32x4 rsk = dma_rsrc(K + row0 * ld + hoff, (unsigned)(((size_t)(S - 1) * ld + DH) * 2));
+  const i32x4 rsv = dma_rsrc(V + row0 * ld + hoff, (unsigned)(((size_t)(S - 1) * ld + DH) * 2));
+  // copy side (the LDS end of an LDS-DMA is lane-linear, so the image's chunk permutation is applied to the SOURCE address)
+  int ok0, ok1 = 0, ov0, ov1 = 0;
+  if constexpr (DH == 64) {  // wave w: rows 16 w .. + 15 of both images as two pieces of 8 rows
+    const int rw0 = 16 * w + (l >> 3), rw1 = rw0 + 8;
+    ok0 = (rw0 * ld + ((l & 7) ^ ((rw0 >> 1) & 7)) * 8) * 2;
+    ok1 = (rw1 * ld + ((l & 7) ^ ((rw1 >> 1) & 7)) * 8) * 2;
+    ov0 = (rw0 * ld + ((l & 7) ^ (((rw0 >> 1) & 1) << 2)) * 8) * 2;
+    ov1 = (rw1 * ld + ((l & 7) ^ (((rw1 >> 1) & 1) << 2)) * 8) * 2;
+  } else {                   // wave w: rows 16 w .. + 15 of both images as one piece of 16 rows
+    const int rw = 16 * w + (l >> 2);
+    ok0 = (rw * ld + ((l & 3) ^ ((rw >> 2) & 3)) * 8) * 2;
+    ov0 = (rw * ld + (l & 3) * 8) * 2;
+  }
   const int tile_bytes = 64 * ld * 2;
-  const unsigned lds_w = __builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem) + w * 2048));
+  const unsigned lds_w = __builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem) + w * (IMG / 4)));
   auto stage = [&](int j, int slot) __attribute__((always_inline)) {
-    const unsigned dk = lds_w + (unsigned)slot * SLOT, dv = dk + 64 * 128;
+    const unsigned dk = lds_w + (unsigned)slot * SLOT, dv = dk + IMG;
     const int ko = j * tile_bytes;
     dma16_hidden(rsk, dk, ok0 + ko);
-    dma16_hidden(rsk, dk + 1024, ok1 + ko);
+    if constexpr (DH == 64) dma16_hidden(rsk, dk + 1024, ok1 + ko);
     dma16_hidden(rsv, dv, ov0 + ko);
-    dma16_hidden(rsv, dv + 1024, ov1 + ko);
+    if constexpr (DH == 64) dma16_hidden(rsv, dv + 1024, ov1 + ko);
   };
   const int g1 = (l >> 4) & 1, qq = (l >> 2) & 3, pp = l & 3;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
-  // per-lane LDS offsets; everything else about a read (slot, key tile, k-step) is an immediate:  swz_k64(32 kt2 + r, 2 ks + h2) = ka[ks] + 4096 kt2,
-  // swz_v64(16 kstep + 8 e + 4 h2 + qq, 2 dt + g1) + 8 pp = va[dt] + 2048 kstep + 1024 e   (bit 1 of the key is bit 1 of qq)
-  const unsigned char* ka[4];
-  const unsigned char* va[2];
+  // per-lane LDS offsets; everything else about a read (slot, key tile, k-step) is an immediate.  DH 64: swz_k64(32 kt2 + r, 2 ks + h2) = ka[ks] +
+  // 4096 kt2,  swz_v64(16 kstep + 8 e + 4 h2 + qq, 2 dt + g1) + 8 pp = va[dt] + 2048 kstep + 1024 e  (bit 1 of the key is bit 1 of qq);  DH 32: the
+  // same with 64-byte rows
+  const unsigned char* ka[KS];
+  const unsigned char* va[DT];
 #pragma unroll
-  for (int ks = 0; ks < 4; ks++) ka[ks] = smem + swz_k64(r, 2 * ks + h2);
+  for (int ks = 0; ks < KS; ks++) ka[ks] = smem + (DH == 64 ? swz_k64(r, 2 * ks + h2) : r * 64 + (((2 * ks + h2) ^ ((r >> 2) & 3)) << 4));
 #pragma unroll
-  for (int dt = 0; dt < 2; dt++) va[dt] = smem + 64 * 128 + swz_v64(4 * h2 + qq, 2 * dt + g1) + 8 * pp;
+  for (int dt = 0; dt < DT; dt++) va[dt] = smem + IMG + (DH == 64 ? swz_v64(4 * h2 + qq, 2 * dt + g1) : (4 * h2 + qq) * 64 + 32 * g1) + 8 * pp;
 
   auto tile = [&](int j, int slot) __attribute__((always_inline)) {  // slot: a literal at each of the three call sites
     f32x16 sc[2];
 #pragma unroll
     for (int kt2 = 0; kt2 < 2; kt2++) {
-      bf16x8 kf[4];
+      bf16x8 kf[KS];
 #pragma unroll
-      for (int ks = 0; ks < 4; ks++) kf[ks] = *(const bf16x8*)(ka[ks] + slot * SLOT + 4096 * kt2);
+      for (int ks = 0; ks < KS; ks++) kf[ks] = *(const bf16x8*)(ka[ks] + slot * SLOT + 32 * RB * kt2);
 #pragma unroll
-      for (int ks = 0; ks < 4; ks++) sc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ks == 0 ? cneg : sc[kt2], 0, 0, 0);   // S'^T - m2
+      for (int ks = 0; ks < KS; ks++) sc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ks == 0 ? cneg : sc[kt2], 0, 0, 0);   // S'^T - m2
     }
     if (j * 64 + 64 > S) {  // ragged last tile: keys >= S get -inf
 #pragma unroll
@@ -142,8 +164,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restr
       l_a *= alpha;
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        ot[0][i] *= alpha;
-        ot[1][i] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) ot[dt][i] *= alpha;
         sc[0][i] -= d;
         sc[1][i] -= d;
         cneg[i] = -m2;
@@ -159,31 +181,33 @@ __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restr
         pf[i] = (__bf16)p;
       }
 #pragma unroll
-      for (int dt = 0; dt < 2; dt++) {
-        const s16x4 v0 = lds_read_tr16(va[dt] + slot * SLOT + 2048 * kstep);
-        const s16x4 v1 = lds_read_tr16(va[dt] + slot * SLOT + 2048 * kstep + 1024);
+      for (int dt = 0; dt < DT; dt++) {
+        const s16x4 v0 = lds_read_tr16(va[dt] + slot * SLOT + 16 * RB * kstep);
+        const s16x4 v1 = lds_read_tr16(va[dt] + slot * SLOT + 16 * RB * kstep + 8 * RB);
         const s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, ot[dt], 0, 0, 0);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile j have returned before it can reach the next barrier
   };
+  auto landed = [&]() __attribute__((always_inline)) {  // this wave's NP pieces of the oldest tile in flight (the next tile's NP may still fly)
+    if constexpr (NP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the tile is published; everybody is done with the tile before it, whose slot the next copy takes
+  };
   const int nt = (S + 63) / 64;
   stage(0, 0);
   stage(1, 1);
   for (int j = 0; j < nt; j += 3) {  // tile j lives in slot j % 3
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // this wave's four pieces of tile j (tile j + 1 may still fly)
-    __builtin_amdgcn_s_barrier();                     // tile j is published; everybody is done with tile j - 1, whose slot tile j + 2 takes
+    landed();
     stage(j + 2, 2);
     tile(j, 0);
     if (j + 1 >= nt) break;
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    landed();
     stage(j + 3, 0);
     tile(j + 1, 1);
     if (j + 2 >= nt) break;
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    landed();
     stage(j + 4, 1);
     tile(j + 2, 2);
   }
@@ -194,7 +218,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restr
   if (q < Sq) {
     bf16_t* op = O + (row0 + qoff + q) * ldo + hoff;
 #pragma unroll
-    for (int dt = 0; dt < 2; dt++)
+    for (int dt = 0; dt < DT; dt++)
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
         const int d0 = 32 * dt + 8 * rg + 4 * h2;
@@ -209,11 +233,12 @@ int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf1
                   float scale, int Sq, int qoff, hipStream_t st) {
   if (Sq <= 0) { Sq = S; qoff = 0; }
   if (qoff < 0 || qoff + Sq > S) { set_error("attention_fwd: query range [%d, %d) outside the sequence (%d)", qoff, qoff + Sq, S); return SMBV_ERR_SHAPE; }
-  if (Dh != 64) { set_error("attention_fwd: head_dim %d not supported (only 64)", Dh); return SMBV_ERR_SHAPE; }
+  if (Dh != 64 && Dh != 32) { set_error("attention_fwd: head_dim %d not supported (64 or 32; other widths run zero-padded in 64-wide slots, block.h)", Dh); return SMBV_ERR_SHAPE; }
   if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 3)) { set_error("attention_fwd: bad shape B=%d S=%d H=%d ld=%d ldo=%d", B, S, H, ld, ldo); return SMBV_ERR_SHAPE; }
   if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || ((uintptr_t)O & 7)) { set_error("attention_fwd: alignment"); return SMBV_ERR_ALIGN; }
   if ((size_t)(S + 256) * ld * 2 >= (1ull << 31)) { set_error("attention_fwd: one sequence spans %zu bytes of the QKV matrix; the LDS-DMA offsets are 32-bit", (size_t)S * ld * 2); return SMBV_ERR_SHAPE; }
-  hipLaunchKernelGGL(attn_fwd3_kernel, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale);
+  if (Dh == 64) hipLaunchKernelGGL(attn_fwd3_kernel<64>, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale);
+  else hipLaunchKernelGGL(attn_fwd3_kernel<32>, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale);
   return check_launch("attention_fwd");
 }
 

@@ -17,15 +17,17 @@ struct BlockPtrs {  // fp32 parameters (or their gradients) of one block
 struct BlockDims {
   size_t rows = 0;  // B * S tokens
   int w = 0, ff = 0, B = 0, S = 0, H = 0;
-  int Dh = 64;      // true head dim (8..64, multiple of 8).  The attention kernels work on 64-wide heads: smaller heads are zero-padded
-                    // in the QKV / projection weights (exact: padded q/k columns add 0 to every score, padded v columns give 0 outputs)
+  int Dh = 64;      // true head dim (8..64, multiple of 8).  The attention kernels have native builds for 64- and 32-wide heads; any other
+                    // width runs in 64-wide slots, zero-padded in the QKV / projection weights (exact: padded q/k columns add 0 to every
+                    // score, padded v columns give 0 outputs)
   float eps = 1e-12f;
   int rope_grid = 0;              // > 0: 3-axis RoPE on q and k with this grid size (tokens per row; tokens per frame = grid^2)
   const int* pos = nullptr;       // token position ids for RoPE (null = index within the sequence)
   const float* rope_table = nullptr;
   int attn_fp8 = 0;               // 1: attention forward on the block-scaled fp8 MFMA (attention_fp8.hip); the backward stays bf16
-  int wa() const { return H * 64; }
-  bool padded() const { return Dh != 64; }
+  int slot() const { return Dh == 32 ? 32 : 64; }  // columns a head occupies in the QKV / attention-output matrices
+  int wa() const { return H * slot(); }
+  bool padded() const { return Dh != slot(); }
   float scale() const { return 1.0f / std::sqrt((float)Dh); }
 };
 

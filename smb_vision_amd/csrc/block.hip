@@ -33,7 +33,7 @@ void carve_layer(Carver& c, LayerWs& L, const BlockDims& d, const LayerWs* share
 size_t layer_prep_job_count(const BlockDims& d) { return d.padded() ? (size_t)(16 + 11 * d.H) : 16; }
 
 int prep_layer(PrepList& pl, const BlockPtrs& p, LayerWs& L, const BlockDims& d, hipStream_t st) {
-  const int w = d.w, ff = d.ff, wa = d.wa(), Dh = d.Dh;
+  const int w = d.w, ff = d.ff, wa = d.wa(), Dh = d.Dh, hs = d.slot();
   const size_t ww = (size_t)w * w;
   if (!d.padded()) {
     pl.cast(p.q_w, L.wqkv, w, w);
@@ -60,14 +60,14 @@ int prep_layer(PrepList& pl, const BlockPtrs& p, LayerWs& L, const BlockDims& d,
     for (int sec = 0; sec < 3; sec++)
       for (int h = 0; h < d.H; h++) {
         const float* src = wsrc[sec] + (size_t)h * Dh * w;                       // rows h*Dh .. of [w_out, w_in]
-        pl.cast(src, L.wqkv + ((size_t)sec * wa + h * 64) * w, Dh, w);
-        pl.tcast(src, L.wqkv_t + (size_t)sec * wa + h * 64, Dh, w, 3 * wa);
-        if (bsrc[sec]) pl.add(bsrc[sec] + h * Dh, L.bqkv + sec * wa + h * 64, 1, Dh, Dh, Dh, 2);
+        pl.cast(src, L.wqkv + ((size_t)sec * wa + h * hs) * w, Dh, w);
+        pl.tcast(src, L.wqkv_t + (size_t)sec * wa + h * hs, Dh, w, 3 * wa);
+        if (bsrc[sec]) pl.add(bsrc[sec] + h * Dh, L.bqkv + sec * wa + h * hs, 1, Dh, Dh, Dh, 2);
       }
     for (int h = 0; h < d.H; h++) {
       // proj weight [w, w_in = H*Dh]: column block h*Dh.. -> padded column block h*64..
-      pl.add(p.proj_w + h * Dh, L.proj + h * 64, w, Dh, w, wa, 0);
-      pl.add(p.proj_w + h * Dh, L.proj_t + (size_t)h * 64 * w, w, Dh, w, w, 1);
+      pl.add(p.proj_w + h * Dh, L.proj + h * hs, w, Dh, w, wa, 0);
+      pl.add(p.proj_w + h * Dh, L.proj_t + (size_t)h * hs * w, w, Dh, w, w, 1);
     }
   }
   pl.cast(p.fc1_w, L.fc1, ff, w);
@@ -115,9 +115,10 @@ int layer_fwd(const BlockPtrs& p, LayerWs& L, const BlockDims& d, BwdScratch& sc
     GemmEpi e; e.bias = L.bqkv; e.out_bf16 = L.qkv; e.ld_ob = 3 * wa;
     RC(gemm_nt(L.ln1, w, L.wqkv, w, M, 3 * wa, w, e, st));
   }
-  if (d.rope_grid > 0) RC(rope3d(L.qkv, 3 * wa, wa, M, S, H, 64, d.Dh, d.rope_grid, d.pos, d.rope_table, 0, st));
+  if (d.rope_grid > 0) RC(rope3d(L.qkv, 3 * wa, wa, M, S, H, d.slot(), d.Dh, d.rope_grid, d.pos, d.rope_table, 0, st));
+  if (d.attn_fp8 && d.slot() != 64) { set_error("layer_fwd: the fp8 attention forward is built for 64-wide head slots (head_dim %d)", d.Dh); return SMBV_ERR_SHAPE; }
   if (d.attn_fp8) RC(attention_fwd_fp8(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, wa, L.lse, B, S, H, 64, d.scale(), Sq, qoff, sc.f8ws, sc.f8ws_bytes, st));
-  else RC(attention_fwd(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, wa, L.lse, B, S, H, 64, d.scale(), Sq, qoff, st));
+  else RC(attention_fwd(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, wa, L.lse, B, S, H, d.slot(), d.scale(), Sq, qoff, st));
   if (Sq > 0) {
     // ranged tail: projection + MLP on the Sq tokens only; x_mid / x_out keep the full [B*S, w] layout, ln2 / pre / act are compact
     const int Mq = B * Sq;
@@ -228,8 +229,8 @@ int layer_bwd(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDi
   // ---- attention (dQ exists only for the ranged queries; dK/dV for every token) ----
   if (ranged) HIPRC(hipMemsetAsync(sc.d_qkv, 0, (size_t)M * 3 * wa * sizeof(bf16_t), st));
   RC(attention_bwd(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, sc.d_o, wa, L.lse, sc.delta, sc.d_qkv, sc.d_qkv + wa, sc.d_qkv + 2 * wa, 3 * wa, B,
-                   S, H, 64, d.scale(), 7, Sq, qoff, st));
-  if (d.rope_grid > 0) RC(rope3d(sc.d_qkv, 3 * wa, wa, M, S, H, 64, d.Dh, d.rope_grid, d.pos, d.rope_table, 1, st));
+                   S, H, d.slot(), d.scale(), 7, Sq, qoff, st));
+  if (d.rope_grid > 0) RC(rope3d(sc.d_qkv, 3 * wa, wa, M, S, H, d.slot(), d.Dh, d.rope_grid, d.pos, d.rope_table, 1, st));
   // ---- QKV ----
   // (the three products forked above had the whole attention backward to finish: joining them here costs nothing and makes every later
   // write on `st` - LN1 backward rewrites g / gb - safe whatever the scheduling of the two queues)

@@ -6,7 +6,7 @@
 // The encoder runs over ALL N tokens (no masking before it, :507-539).  The predictor sequence is held in position-sorted order
 // from the start (the reference concatenates [context, target] and then gathers by argsort, :718-719): context embeddings are
 // scattered to their slots, target slots are filled with the mask token, and RoPE takes the sorted position ids.
-// Predictor heads (head_dim 32 at the default 384/12) run zero-padded in 64-wide slots (block.h).
+// Predictor heads (head_dim 32 at the default 384/12) use the native 32-wide attention build; widths other than 32 / 64 run zero-padded in 64-wide slots (block.h).
 #include "block.h"
 #include "../../include/smbv.h"
 

@@ -110,16 +110,16 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, grp=(0, 0, 0)):
     return dx, dxb, dg, db
 
 
-def attention_fwd(qkv, B, S, H, scale=None, Sq=0, q_off=0):
-    """qkv: bf16 [B*S, 3*H*64] (q | k | v column blocks).  Returns (O bf16 [B*S, H*64], LSE fp32 [B,H,S])."""
+def attention_fwd(qkv, B, S, H, scale=None, Sq=0, q_off=0, Dh=64):
+    """qkv: bf16 [B*S, 3*H*Dh] (q | k | v column blocks), Dh 64 or 32.  Returns (O bf16 [B*S, H*Dh], LSE fp32 [B,H,S])."""
     _need_gpu(qkv)
     lib = _lib.load()
-    w = H * 64
-    scale = scale if scale is not None else 64 ** -0.5
+    w = H * Dh
+    scale = scale if scale is not None else Dh ** -0.5
     O = torch.zeros(B * S, w, dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty(B, H, Sq if Sq > 0 else S, dtype=torch.float32, device=qkv.device)
     base = qkv.data_ptr()
-    check(lib.smbv_attention_fwd(base, base + 2 * w, base + 4 * w, qkv.stride(0), _p(O), w, _p(lse), B, S, H, 64, scale, Sq, q_off, _stream()),
+    check(lib.smbv_attention_fwd(base, base + 2 * w, base + 4 * w, qkv.stride(0), _p(O), w, _p(lse), B, S, H, Dh, scale, Sq, q_off, _stream()),
           "smbv_attention_fwd")
     return O, lse
 
@@ -139,15 +139,15 @@ def attention_fwd_fp8(qkv, B, S, H, scale=None, Sq=0, q_off=0):
     return O, lse
 
 
-def attention_bwd(qkv, O, dO, lse, B, S, H, scale=None, parts=7, out=None, Sq=0, q_off=0):
+def attention_bwd(qkv, O, dO, lse, B, S, H, scale=None, parts=7, out=None, Sq=0, q_off=0, Dh=64):
     _need_gpu(qkv, O, dO, lse)
     lib = _lib.load()
-    w = H * 64
-    scale = scale if scale is not None else 64 ** -0.5
+    w = H * Dh
+    scale = scale if scale is not None else Dh ** -0.5
     dqkv, delta = out if out is not None else (torch.zeros_like(qkv), torch.empty(B, H, Sq if Sq > 0 else S, dtype=torch.float32, device=qkv.device))
     base, dbase = qkv.data_ptr(), dqkv.data_ptr()
     check(lib.smbv_attention_bwd(base, base + 2 * w, base + 4 * w, qkv.stride(0), _p(O), _p(dO), w, _p(lse), _p(delta), dbase, dbase + 2 * w,
-                                 dbase + 4 * w, dqkv.stride(0), B, S, H, 64, scale, parts, Sq, q_off, _stream()), "smbv_attention_bwd")
+                                 dbase + 4 * w, dqkv.stride(0), B, S, H, Dh, scale, parts, Sq, q_off, _stream()), "smbv_attention_bwd")
     return dqkv, delta
 
 

@@ -147,20 +147,22 @@ def test_layernorm_row_remap(ops):
     assert rel_err(y, ref) < 6e-3
 
 
-def _attn_ref(qkv, B, S, H):
-    w = H * 64
-    q, k, v = (qkv.float()[:, i * w:(i + 1) * w].view(B, S, H, 64).transpose(1, 2) for i in range(3))
-    s = q @ k.transpose(-1, -2) * 0.125
+def _attn_ref(qkv, B, S, H, Dh=64):
+    w = H * Dh
+    q, k, v = (qkv.float()[:, i * w:(i + 1) * w].view(B, S, H, Dh).transpose(1, 2) for i in range(3))
+    s = q @ k.transpose(-1, -2) * Dh ** -0.5
     return q, k, v, s
 
 
+@pytest.mark.parametrize("Dh", [64, 32])
 @pytest.mark.parametrize("B,S,H", [(1, 32, 1), (2, 12, 2), (1, 100, 2), (2, 256, 1), (1, 1000, 3), (1, 2048, 2)])
-def test_attention_fwd_bwd(ops, B, S, H):
-    w = H * 64
+def test_attention_fwd_bwd(ops, B, S, H, Dh):
+    """Dh 32: the native build for the V-JEPA predictor's heads (384 / 12, modeling_vjepa.py:251-253) - 64-byte LDS rows, half the MFMA k-steps."""
+    w = H * Dh
     qkv = rnd(B * S, 3 * w, seed=1).bfloat16()
-    O, lse = ops.attention_fwd(qkv, B, S, H)
+    O, lse = ops.attention_fwd(qkv, B, S, H, Dh=Dh)
     qf = qkv.float().requires_grad_(True)
-    q, k, v, s = _attn_ref(qf, B, S, H)
+    q, k, v, s = _attn_ref(qf, B, S, H, Dh)
     p = torch.softmax(s, -1)
     ref = (p @ v).transpose(1, 2).reshape(B * S, w)
     assert rel_err(O, ref) < 1.5e-2
@@ -169,9 +171,9 @@ def test_attention_fwd_bwd(ops, B, S, H):
     # operand, the size of the bf16 score rounding the reference's autocast matmul has anyway)
     assert rel_err(lse, torch.logsumexp(s, -1)) < 2e-3
     dO = rnd(B * S, w, seed=2).bfloat16()
-    dqkv, delta = ops.attention_bwd(qkv, O, dO, lse, B, S, H)
+    dqkv, delta = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Dh=Dh)
     ref.backward(dO.float())
-    assert rel_err(delta, (dO.float() * O.float()).view(B, S, H, 64).sum(-1).transpose(1, 2)) < 1e-4
+    assert rel_err(delta, (dO.float() * O.float()).view(B, S, H, Dh).sum(-1).transpose(1, 2)) < 1e-4
     for i, name in enumerate("qkv"):
         a, b = dqkv[:, i * w:(i + 1) * w], qf.grad[:, i * w:(i + 1) * w]
         assert rel_err(a, b) < 2.5e-2, name
@@ -300,14 +302,15 @@ def test_fused_adamw_matches_torch():
     assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-12) and float(sa["step"]) == 4
 
 
+@pytest.mark.parametrize("Dh", [64, 32])
 @pytest.mark.parametrize("B,S,H,Sq,qoff", [(2, 200, 2, 120, 80), (1, 300, 1, 45, 255), (1, 512, 2, 384, 128)])
-def test_attention_query_subrange(ops, B, S, H, Sq, qoff):
+def test_attention_query_subrange(ops, B, S, H, Sq, qoff, Dh):
     """Only queries qoff..qoff+Sq-1 of each sequence are computed (keys/values: all S) - the last decoder block's case."""
-    w = H * 64
+    w = H * Dh
     qkv = rnd(B * S, 3 * w, seed=11).bfloat16()
-    O, lse = ops.attention_fwd(qkv, B, S, H, Sq=Sq, q_off=qoff)
+    O, lse = ops.attention_fwd(qkv, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh)
     qf = qkv.float().requires_grad_(True)
-    q, k, v, s = _attn_ref(qf, B, S, H)
+    q, k, v, s = _attn_ref(qf, B, S, H, Dh)
     s = s[:, :, qoff:qoff + Sq]
     ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, Sq, w)
     got = O.view(B, S, w)[:, qoff:qoff + Sq]
@@ -317,26 +320,27 @@ def test_attention_query_subrange(ops, B, S, H, Sq, qoff):
     dO = torch.zeros(B, S, w, device="cuda")
     dO[:, qoff:qoff + Sq] = rnd(B, Sq, w, seed=12)
     dO = dO.bfloat16().view(B * S, w)
-    dqkv, delta = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff)
+    dqkv, delta = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh)
     ref.backward(dO.float().view(B, S, w)[:, qoff:qoff + Sq])
     for i, name in enumerate("qkv"):
         a, b = dqkv[:, i * w:(i + 1) * w], qf.grad[:, i * w:(i + 1) * w]
         assert rel_err(a, b) < 2.5e-2 and rms_err(a, b) < 1e-2, name
 
 
-def test_attention_kernels_are_run_to_run_identical(ops):
+@pytest.mark.parametrize("Dh", [64, 32])
+def test_attention_kernels_are_run_to_run_identical(ops, Dh):
     """No atomics anywhere and every LDS hand-over (LDS-DMA ring slots, tile seams) is ordered by counted waits + barriers: repeated launches
     on a shape with many tiles per block must agree bit for bit (a race would show up as run-to-run differences)."""
     B, S, H = 1, 4224, 4   # 33 tiles of 128: ring wrap-around, odd tile count, ragged nothing
-    w = H * 64
+    w = H * Dh
     qkv = rnd(B * S, 3 * w, seed=31).bfloat16()
     dO = rnd(B * S, w, seed=32).bfloat16()
-    O0, lse0 = ops.attention_fwd(qkv, B, S, H)
-    d0, _ = ops.attention_bwd(qkv, O0, dO, lse0, B, S, H)
+    O0, lse0 = ops.attention_fwd(qkv, B, S, H, Dh=Dh)
+    d0, _ = ops.attention_bwd(qkv, O0, dO, lse0, B, S, H, Dh=Dh)
     for _ in range(8):
-        O, lse = ops.attention_fwd(qkv, B, S, H)
+        O, lse = ops.attention_fwd(qkv, B, S, H, Dh=Dh)
         assert torch.equal(O, O0) and torch.equal(lse, lse0)
-        d, _ = ops.attention_bwd(qkv, O0, dO, lse0, B, S, H)
+        d, _ = ops.attention_bwd(qkv, O0, dO, lse0, B, S, H, Dh=Dh)
         assert torch.equal(d, d0)
 
 

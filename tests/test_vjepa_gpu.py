@@ -130,6 +130,36 @@ def test_vjepa_step_matches_reference_golden():
         assert torch.allclose(t, 0.5 * b + 0.5 * q.detach(), rtol=1e-6, atol=1e-7)
 
 
+def test_vjepa_padded_head_widths_match_oracle():
+    """Head widths with no native attention build (encoder 64 / 4 = 16, predictor 96 / 2 = 48) run zero-padded in 64-wide slots (block.h):
+    one step against the CPU oracle on the same weights (parity unpinned by a reference golden: the goldens' widths are 64 and 32)."""
+    import oracle.vjepa_oracle as vo
+    from smb_vision_amd.modeling_vjepa import make_target_encoder, vjepa_loss
+    c = dict(TINY, hidden_size=64, num_attention_heads=4, pred_hidden_size=96, pred_num_attention_heads=2)
+    cfg = vo.VJEPAConfig(**c)
+    params = vo.init_params(cfg, seed=5, nonzero_small=True)
+    n = (c["frames_per_clip"] // c["tubelet_size"]) * (c["crop_size"] // c["patch_size"]) ** 2
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(3))
+    cm, tm = perm[: n // 3].sort().values[None].repeat(2, 1), perm[n // 3:].sort().values[None].repeat(2, 1)
+    pix = torch.rand(2, c["frames_per_clip"], 1, c["crop_size"], c["crop_size"], generator=torch.Generator().manual_seed(4))
+    model = build(c, params)
+    target = make_target_encoder(model)
+    loss, out = vjepa_loss(model, target, None, {"pixel_values_videos": pix.cuda(), "context_mask": [cm.cuda()], "target_mask": [tm.cuda()]})
+    loss.backward()
+    torch.cuda.synchronize()
+    ref_loss, ref_pred, _, ref_grads = vo.vjepa_step(params, params, cfg, pix, [cm], [tm])
+    assert rel(out.predictor_output.last_hidden_state.detach().cpu(), ref_pred) < 3e-2
+    assert abs(float(loss) - float(ref_loss)) < 1e-2 * float(ref_loss)
+    for k, p_ in model.named_parameters():
+        ref = ref_grads[k]
+        nrm = float(ref.norm())
+        if nrm < 1e-10:
+            assert float(p_.grad.norm()) < 1e-6, k
+            continue
+        r = float((p_.grad.cpu() - ref).norm()) / nrm
+        assert r < (2e-1 if k.endswith("attention.key.bias") else 8e-2), (k, r, nrm)
+
+
 def test_vjepa_default_masks_and_errors():
     blob, c = load("vjepa_tiny")
     p_on = {k[6:]: v for k, v in blob.items() if k.startswith("param.")}
