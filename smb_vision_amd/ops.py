@@ -30,8 +30,9 @@ def _ws(nbytes, dev):
 
 
 def gemm_nt(A, B, *, bias=None, rowadd=None, rowidx=None, gelu=False, save_pre=False, dgelu_pre=None, out_bf16=True, out_f32=False,
-            alpha=1.0, grp=None, out_rows=None):
-    """C = epi(A[M,K] @ B[N,K]^T).  Returns dict with 'bf16', 'f32', 'pre' entries as requested."""
+            alpha=1.0, grp=None, out_rows=None, reuse=None):
+    """C = epi(A[M,K] @ B[N,K]^T).  Returns dict with 'bf16', 'f32', 'pre' entries as requested.  reuse: a dict returned by an earlier call of the
+    same shape - its tensors are written again instead of allocating (and zero-filling) new ones (timing loops)."""
     _need_gpu(A, B)
     lib = _lib.load()
     M, K = A.shape
@@ -45,13 +46,13 @@ def gemm_nt(A, B, *, bias=None, rowadd=None, rowidx=None, gelu=False, save_pre=F
     e.dgelu_pre, e.ld_pre = _p(dgelu_pre), (dgelu_pre.stride(0) if dgelu_pre is not None else 0)
     e.act_gelu = int(gelu)
     if save_pre:
-        res["pre"] = torch.empty(rows, N, dtype=torch.bfloat16, device=A.device)
+        res["pre"] = reuse["pre"] if reuse else torch.empty(rows, N, dtype=torch.bfloat16, device=A.device)
         e.aux_pre, e.ld_aux = res["pre"].data_ptr(), N
     if out_bf16:
-        res["bf16"] = torch.zeros(rows, N, dtype=torch.bfloat16, device=A.device)
+        res["bf16"] = reuse["bf16"] if reuse else torch.zeros(rows, N, dtype=torch.bfloat16, device=A.device)
         e.out_bf16, e.ld_ob = res["bf16"].data_ptr(), N
     if out_f32:
-        res["f32"] = torch.zeros(rows, N, dtype=torch.float32, device=A.device)
+        res["f32"] = reuse["f32"] if reuse else torch.zeros(rows, N, dtype=torch.float32, device=A.device)
         e.out_f32, e.ld_of = res["f32"].data_ptr(), N
     if grp:
         e.grp_in, e.grp_out = grp
