@@ -148,7 +148,7 @@ def _free_port():
     return p
 
 
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, overlap=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -157,7 +157,9 @@ def _dp_worker(rank, world, port, q):
         from smb_vision_amd.dp import DataParallelEngine
         torch.cuda.set_device(0)
         model = _mim_model(100 + rank)                   # different initial weights per rank: the broadcast must fix that
-        dp = DataParallelEngine(model, overlap=False)    # gloo: the engine's SUM + scale path; RCCL uses AVG on the side stream
+        # gloo: the engine's SUM + scale path (RCCL uses AVG).  overlap=True still drives everything else the RCCL launch does: per-group HIP events
+        # created here, recorded by smbv_mim_backward as each gradient group completes, waited for by the communication stream bucket by bucket
+        dp = DataParallelEngine(model, overlap=overlap, bucket_bytes=1 << 16)
         dp.broadcast_parameters(model)
         pix, mask = _mim_batch(10 + rank)                # different data per rank
         model(pixel_values=pix, bool_masked_pos=mask).loss.backward()
@@ -168,12 +170,13 @@ def _dp_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_mim_dp_param_grads_are_the_mean_of_the_rank_gradients():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_mim_dp_param_grads_are_the_mean_of_the_rank_gradients(overlap):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in ps:
         p.start()
     res = sorted((q.get(timeout=300) for _ in ps), key=lambda t: t[0])

@@ -189,7 +189,7 @@ TINY = dict(patch_size=8, crop_size=32, frames_per_clip=8, tubelet_size=2, in_ch
             mlp_ratio=4.0, pred_hidden_size=64, pred_num_hidden_layers=2, pred_num_attention_heads=2, pred_num_mask_tokens=10, pred_mlp_ratio=4.0)
 
 
-def _vjepa_dp_worker(rank, world, port, q):
+def _vjepa_dp_worker(rank, world, port, q, overlap=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -201,7 +201,9 @@ def _vjepa_dp_worker(rank, world, port, q):
         torch.cuda.set_device(0)
         torch.manual_seed(0)
         m = SmbVJEPA2Model(VJEPA2Config(**TINY)).cuda().train()
-        dp = DataParallelEngine(m, overlap=False)  # gloo has no device-side AVG: the engine's SUM + scale path, as in tests/test_dp_cpu.py
+        # gloo has no device-side AVG: the engine's SUM + scale path, as in tests/test_dp_cpu.py; overlap=True adds the per-group HIP events the
+        # backward records and the communication stream waits for (what the RCCL launch uses)
+        dp = DataParallelEngine(m, overlap=overlap, bucket_bytes=1 << 16)
         dp.broadcast_parameters(m)
         g = torch.Generator().manual_seed(10 + rank)      # different data per rank
         pix = torch.rand(1, TINY["frames_per_clip"], 1, TINY["crop_size"], TINY["crop_size"], generator=g).cuda()
@@ -215,14 +217,15 @@ def _vjepa_dp_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_vjepa_gradients_are_averaged_across_ranks():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_vjepa_gradients_are_averaged_across_ranks(overlap):
     """Two processes on the one GPU (gloo): after backward both ranks hold the same, non-trivial, averaged gradient arena."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_vjepa_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    ps = [ctx.Process(target=_vjepa_dp_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in ps:
         p.start()
     res = sorted(q.get(timeout=240) for _ in ps)
