@@ -119,6 +119,8 @@ static int vjepa_forward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, c
   const BlockDims de = venc_dims(c, &io), dp = vpred_dims(c, &io);
   const size_t Re = de.rows, Rp = dp.rows, Rc = (size_t)vpb(c) * c.Nctx, Rt = (size_t)vpb(c) * c.Ntgt;
   const int Sp = c.Nctx + c.Ntgt;
+  SideStream prep_side;
+  int prep_join_layer = -1;
   {
     PrepList pl;
     pl.cast(p.pe_w, W.pe_w, c.d, K);
@@ -130,7 +132,15 @@ static int vjepa_forward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, c
       pl.tcast(p.pproj_w, W.pproj_t, c.d, c.pd, c.d);
       for (int l = 0; l < c.players; l++) RC(prep_layer(pl, vblock(p.pred[l]), W.pred[l], dp, st));
     }
-    RC(prep_weights(pl.jobs.data(), (int)pl.jobs.size(), st));
+    // as in mim_step.hip: the first launch (64 jobs) on `st`, the others on the side stream beside the brick gather and the first encoder blocks
+    const int njobs = (int)pl.jobs.size(), first = std::min(njobs, 64);
+    const bool split = njobs > first && !de.padded() && !(with_pred && dp.padded());
+    RC(prep_weights(pl.jobs.data(), split ? first : njobs, st));
+    if (split) {
+      RC(prep_side.begin(st));
+      RC(prep_weights(pl.jobs.data() + first, njobs - first, prep_side.st));
+      prep_join_layer = std::max(0, (first - 1) / 16);  // 1 model-level job, then 16 per un-padded block, in program order
+    }
   }
   // encoder over all N tokens: Conv3d patch embedding (+bias, no position table: RoPE instead), L blocks, final LayerNorm
   RC(gather_bricks(io.pixel_values, io.all_idx, (int)Re, c.N, W.a_patch, c.T, c.H, c.W, c.ts, c.ps, st));
@@ -138,7 +148,11 @@ static int vjepa_forward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, c
     GemmEpi e; e.bias = p.pe_b; e.out_f32 = W.x[0]; e.ld_of = c.d;
     RC(gemm_nt(W.a_patch, K, W.pe_w, K, (int)Re, c.d, K, e, st));
   }
-  for (int l = 0; l < c.layers; l++) RC(layer_fwd(vblock(p.enc[l]), W.enc[l], de, W.sc, W.x[l], W.x[l + 1], nullptr, 0, 0, st));
+  for (int l = 0; l < c.layers; l++) {
+    if (l == prep_join_layer) RC(prep_side.end(st));
+    RC(layer_fwd(vblock(p.enc[l]), W.enc[l], de, W.sc, W.x[l], W.x[l + 1], nullptr, 0, 0, st));
+  }
+  if (prep_join_layer >= c.layers) RC(prep_side.end(st));
   RC(layernorm_fwd(W.x[c.layers], p.enc_ln_w, p.enc_ln_b, W.enc_ln, W.enc_mean, W.enc_rstd, (int)Re, c.d, c.ln_eps, 0, 0, 0, st, io.enc_out));
   if (!with_pred) return SMBV_OK;
   // predictor: context rows -> Linear(d -> pd) -> their slots of the position-sorted sequence; target slots <- mask token
