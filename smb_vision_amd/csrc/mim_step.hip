@@ -128,6 +128,8 @@ static int mim_forward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const s
       RC(prep_side.begin(st));
       RC(prep_weights(pl.jobs.data() + first, njobs - first, prep_side.st));
       prep_join_layer = std::max(0, (first - 5) / 16);  // 5 model-level jobs, then 16 per un-padded block, in program order
+      // the target statistics depend on the volume and the mask only: same side stream, long done when the loss needs them
+      RC(brick_stats(io.pixel_values, io.mask_idx, (int)Rm, c.Nmask, W.bmean, W.brinv, c.T, c.H, c.W, c.ts, c.ps, prep_side.st));
     }
   }
 
@@ -158,7 +160,7 @@ static int mim_forward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const s
     RC(gemm_nt(W.lnf, c.dd, W.head, c.dd, (int)Rm, K, c.dd, e, st));
   }
   // per-patch normalised targets + MSE (spec :822-897)
-  RC(brick_stats(io.pixel_values, io.mask_idx, (int)Rm, c.Nmask, W.bmean, W.brinv, c.T, c.H, c.W, c.ts, c.ps, st));
+  if (prep_join_layer < 0) RC(brick_stats(io.pixel_values, io.mask_idx, (int)Rm, c.Nmask, W.bmean, W.brinv, c.T, c.H, c.W, c.ts, c.ps, st));
   RC(mse_fwd(io.pixel_values, io.mask_idx, (int)Rm, c.Nmask, W.bmean, W.brinv, io.logits, W.row_partial, io.loss, c.T, c.H, c.W, c.ts, c.ps, st));
   return SMBV_OK;
 }
