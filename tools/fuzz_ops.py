@@ -16,25 +16,26 @@ for i in range(n_cases):
         Sq = rng.randint(1, S); qoff = rng.randint(0, S - Sq)
     else:
         Sq, qoff = 0, 0
-    w = H * 64
+    Dh = rng.choice([64, 32])
+    w = H * Dh
     g = torch.Generator(device="cuda").manual_seed(i)
     qkv = (torch.randn(B * S, 3 * w, generator=g, device="cuda") * rng.choice([0.5, 1.0, 2.0])).bfloat16()
-    O, lse = ops.attention_fwd(qkv, B, S, H, Sq=Sq, q_off=qoff)
+    O, lse = ops.attention_fwd(qkv, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh)
     qf = qkv.float().requires_grad_(True)
-    q, k, v = (qf[:, j * w:(j + 1) * w].view(B, S, H, 64).transpose(1, 2) for j in range(3))
-    s = q @ k.transpose(-1, -2) * 0.125
+    q, k, v = (qf[:, j * w:(j + 1) * w].view(B, S, H, Dh).transpose(1, 2) for j in range(3))
+    s = q @ k.transpose(-1, -2) * Dh ** -0.5
     sq, qo = (Sq, qoff) if Sq else (S, 0)
     s = s[:, :, qo:qo + sq]
     ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, sq, w)
     got = O.view(B, S, w)[:, qo:qo + sq]
     dO = torch.zeros(B, S, w, device="cuda"); dO[:, qo:qo + sq] = torch.randn(B, sq, w, generator=g, device="cuda")
     dO = dO.bfloat16().view(B * S, w)
-    dqkv, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff)
+    dqkv, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh)
     ref.backward(dO.float().view(B, S, w)[:, qo:qo + sq])
     e = [rel(got, ref), rel(lse, torch.logsumexp(s, -1))] + [rel(dqkv[:, j * w:(j + 1) * w], qf.grad[:, j * w:(j + 1) * w]) for j in range(3)]
     ok = e[0] < 2.5e-2 and e[1] < 4e-3 and max(e[2:]) < 4e-2 and bool(torch.isfinite(dqkv.float()).all())
     bad += not ok
-    print(f"attn B{B} S{S} H{H} Sq{Sq} qoff{qoff}: O {e[0]:.1e} lse {e[1]:.1e} dq {e[2]:.1e} dk {e[3]:.1e} dv {e[4]:.1e} {'ok' if ok else 'FAIL'}", flush=True)
+    print(f"attn Dh{Dh} B{B} S{S} H{H} Sq{Sq} qoff{qoff}: O {e[0]:.1e} lse {e[1]:.1e} dq {e[2]:.1e} dk {e[3]:.1e} dv {e[4]:.1e} {'ok' if ok else 'FAIL'}", flush=True)
 for i in range(n_cases):
     M = rng.choice([rng.randint(1, 300), rng.randint(300, 9000)])
     N, K = 8 * rng.randint(1, 400), 8 * rng.randint(1, 260)
