@@ -6,16 +6,17 @@ import torch
 from smb_vision_amd import ops
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 bad = 0
-for name, S, H, Sq, qoff in (("enc", 7168, 12, 0, 0), ("dec", 20480, 6, 0, 0), ("dec-tail", 20480, 6, 13312, 7168), ("ragged", 5003, 3, 0, 0)):
-    w = H * 64
+for name, S, H, Sq, qoff, Dh in (("enc", 7168, 12, 0, 0, 64), ("dec", 20480, 6, 0, 0, 64), ("dec-tail", 20480, 6, 13312, 7168, 64), ("ragged", 5003, 3, 0, 0, 64),
+                                 ("predictor", 20480, 12, 0, 0, 32), ("ragged-32", 5003, 3, 0, 0, 32)):
+    w = H * Dh
     g = torch.Generator(device="cuda").manual_seed(0)
     qkv = torch.randn(S, 3 * w, generator=g, device="cuda").bfloat16()
     dO = torch.randn(S, w, generator=g, device="cuda").bfloat16()
-    O0, l0 = ops.attention_fwd(qkv, 1, S, H, Sq=Sq, q_off=qoff)
-    d0, _ = ops.attention_bwd(qkv, O0, dO, l0, 1, S, H, Sq=Sq, q_off=qoff)
+    O0, l0 = ops.attention_fwd(qkv, 1, S, H, Sq=Sq, q_off=qoff, Dh=Dh)
+    d0, _ = ops.attention_bwd(qkv, O0, dO, l0, 1, S, H, Sq=Sq, q_off=qoff, Dh=Dh)
     for i in range(N):
-        O, l = ops.attention_fwd(qkv, 1, S, H, Sq=Sq, q_off=qoff)
-        d, _ = ops.attention_bwd(qkv, O0, dO, l0, 1, S, H, Sq=Sq, q_off=qoff)
+        O, l = ops.attention_fwd(qkv, 1, S, H, Sq=Sq, q_off=qoff, Dh=Dh)
+        d, _ = ops.attention_bwd(qkv, O0, dO, l0, 1, S, H, Sq=Sq, q_off=qoff, Dh=Dh)
         if not (torch.equal(O, O0) and torch.equal(l, l0) and torch.equal(d, d0)):
             bad += 1
             print(f"{name}: run {i} differs (fwd {torch.equal(O, O0)}, lse {torch.equal(l, l0)}, bwd {torch.equal(d, d0)})", flush=True)
