@@ -223,18 +223,15 @@ __device__ __forceinline__ void epilogue_nt_lds(f32x4 (&acc)[4][4], unsigned cha
   epilogue_rows32(ws, acc[2], acc[3], m0 + wm * 64 + 32, n, ncol, b0, b1, l, M, e);
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
-                                                             int M, int N, int K, int tiles_m, int tiles_n, GemmEpi e, int dbg) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * BM * BK * 2];  // [buf][A|B][128 rows][128 B]
+// One output tile of the LDS-DMA NT kernel.  HALF = false: 128 x 128, waves 2 x 2 of 64 x 64.  HALF = true: 128 x 64 (the mixed-tile launch below),
+// waves 4 x 1 of 32 x 64 - the same MFMA per output element in the same K order, so a product is bitwise independent of how its tiles were cut.
+template <bool HALF>
+__device__ __forceinline__ void nt_dma_tile(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N, int K, int m0, int n0,
+                                            const GemmEpi& e, unsigned char* smem, int dbg) {
+  constexpr int NI = HALF ? 2 : 4;  // 16-row fragments of A per wave
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = w >> 1, wn = w & 1;
-  // bijective XCD remap (blocks b, b+8, ... share an XCD): XCD x owns a contiguous chunk of the tile list
-  const int nwg = tiles_m * tiles_n, bid = blockIdx.x;
-  const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
-  const int tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-  const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int wm = HALF ? w : (w >> 1), wn = HALF ? 0 : (w & 1);
   const int nk = K / BK;
 
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(((size_t)(M - 1) * lda + K) * 2), 0x00020000);
@@ -248,23 +245,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(const bf16_t* __res
   const int oa_e = ((m0 + row_base) * lda + cs_even * 8) * 2, oa_o = ((m0 + row_base + 8) * lda + cs_odd * 8) * 2;
   const int ob_e = ((n0 + row_base) * ldb + cs_even * 8) * 2, ob_o = ((n0 + row_base + 8) * ldb + cs_odd * 8) * 2;
   const int sa16 = lda * 32, sb16 = ldb * 32;  // 16 rows further, in bytes
+  const bool stage_b = !HALF || w < 2;         // a half tile has 64 weight rows: waves 0 and 1 copy them
   auto stage = [=](int buf, int kt) __attribute__((always_inline)) {
     unsigned char* sa = smem + buf * (2 * BM * BK * 2) + w * 4096;
     unsigned char* sb = sa + BM * BK * 2;
     const int kb = kt * BK * 2;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(sa), 16, oa_e + kb, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(sb), 16, ob_e + kb, 0, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(sa + 1024), 16, oa_o + kb, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(sb + 1024), 16, ob_o + kb, 0, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(sa + 2048), 16, oa_e + sa16 + kb, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(sb + 2048), 16, ob_e + sb16 + kb, 0, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(sa + 3072), 16, oa_o + sa16 + kb, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(sb + 3072), 16, ob_o + sb16 + kb, 0, 0, 0);
+    if (stage_b) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(sb), 16, ob_e + kb, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(sb + 1024), 16, ob_o + kb, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(sb + 2048), 16, ob_e + sb16 + kb, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(sb + 3072), 16, ob_o + sb16 + kb, 0, 0, 0);
+    }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[NI][4];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < NI; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -277,25 +277,53 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(const bf16_t* __res
     const unsigned char* sb = sa + BM * BK * 2;
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
-      bf16x8 af[4], bfr[4];
+      bf16x8 af[NI], bfr[4];
       const int ch = (l >> 4) + 4 * ks;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int ar = wm * 64 + i * 16 + (l & 15);
-        const int br = wn * 64 + i * 16 + (l & 15);
-        af[i] = *(const bf16x8*)(sa + swz_nt(ar, ch));
-        bfr[i] = *(const bf16x8*)(sb + swz_nt(br, ch));
-      }
+      for (int i = 0; i < NI; i++) af[i] = *(const bf16x8*)(sa + swz_nt(wm * (16 * NI) + i * 16 + (l & 15), ch));
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8*)(sb + swz_nt(wn * 64 + j * 16 + (l & 15), ch));
+#pragma unroll
+      for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // D[n][m]
     }
     __syncthreads();
   }
-  if (dbg == 1) { if (acc[0][0][0] == 1234.5f) e.out_f32[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; return; }
-  epilogue_nt_lds(acc, smem, w, m0, n0, wm, wn, l, M, N, e);
+  if (dbg == 1) { if (acc[0][0][0] == 1234.5f) e.out_f32[0] = acc[1][1][1] + acc[1][2][2] + acc[1][3][3]; return; }
+  if constexpr (!HALF) {
+    epilogue_nt_lds(acc, smem, w, m0, n0, wm, wn, l, M, N, e);
+  } else {
+    const GemmEpi ee = e;  // by-value copy: keeps the kernel-argument struct from being pinned in memory
+    float* ws = (float*)(smem + w * 16384);
+    const int n = n0 + (l & 7) * 8;
+    const bool ncol = n < N;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (ee.bias && ncol) { b0 = *(const f32x4*)(ee.bias + n); b1 = *(const f32x4*)(ee.bias + n + 4); }
+    epilogue_rows32(ws, acc[0], acc[1], m0 + w * 32, n, ncol, b0, b1, l, M, ee);
+  }
+}
+
+// full_rows = tiles_m: every tile is 128 x 128.  full_rows < tiles_m (the mixed-tile launch): tile rows full_rows .. tiles_m - 1 are cut into 128 x 64
+// half tiles, 2 tiles_n per row.  A grid of 256 < T <= 384 full tiles puts two tiles on some CUs and one on the others (all blocks are co-resident, two per
+// CU); cutting the last rows so that the launch has <= 512 blocks, the halves issued AFTER the full tiles of the same XCD, pairs every full tile with a
+// half: 1.5 tiles of work on the busiest CU instead of 2 (the encoder's N = 768 products: 336 tiles -> 168 + 336 halves).
+__global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
+                                                             int M, int N, int K, int tiles_m, int tiles_n, int full_rows, GemmEpi e, int dbg) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * BM * BK * 2];  // [buf][A|B][128 rows][128 B]
+  // bijective XCD remap (blocks b, b+8, ... share an XCD): XCD x owns a contiguous chunk of the tile list - of each kind of tile
+  const int bid = blockIdx.x, xcd = bid & 7, pos = bid >> 3;
+  const int n_full = full_rows * tiles_n, n_half = (tiles_m - full_rows) * tiles_n * 2;
+  auto chunk_tile = [&](int n, int p) { const int qd = n >> 3, rm = n & 7; return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + p; };
+  const int mine_full = (n_full >> 3) + (xcd < (n_full & 7) ? 1 : 0);
+  if (pos < mine_full) {
+    const int tile = chunk_tile(n_full, pos);
+    nt_dma_tile<false>(A, lda, B, ldb, M, N, K, (tile / tiles_n) * BM, (tile % tiles_n) * BN, e, smem, dbg);
+  } else {
+    const int tile = chunk_tile(n_half, pos - mine_full);
+    nt_dma_tile<true>(A, lda, B, ldb, M, N, K, (full_rows + tile / (2 * tiles_n)) * BM, (tile % (2 * tiles_n)) * (BN / 2), e, smem, dbg);
+  }
 }
 
 int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, hipStream_t st) {
@@ -318,7 +346,18 @@ int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, in
                       (!e.aux_pre || ((e.ld_aux & 7) == 0 && ((uintptr_t)e.aux_pre & 15) == 0)) &&
                       (!e.dgelu_pre || ((e.ld_pre & 7) == 0 && ((uintptr_t)e.dgelu_pre & 15) == 0)) && ((size_t)M * lda * 2 < (1ull << 31)) && ((size_t)N * ldb * 2 < (1ull << 31));
   if (dma_ok && !(g_variant & 32)) {
-    hipLaunchKernelGGL(gemm_nt_dma_kernel, dim3(tm * tn), dim3(256), 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, (g_variant & 64) ? 1 : ((g_variant & 128) ? 2 : 0));
+    // mixed-tile launch (see the kernel): grids of 256 < T <= 384 tiles whose N is a whole number of tiles; the full rows are what 512 block slots leave
+    int full_rows = tm;
+    const int T = tm * tn;
+    if (T > 256 && T <= 384 && N % BN == 0 && !(g_variant & 1024)) {
+      const int need = 2 * T - 512;                       // full tiles so that full + halves <= 512 blocks
+      int fr = std::max(0, cdiv(need, tn));
+      // both kinds split evenly over the 8 XCDs (the kernel hands each XCD a contiguous chunk of each kind, full tiles first)
+      while (fr < tm && (((fr * tn) & 7) || (((tm - fr) * tn * 2) & 7))) fr++;
+      if (fr < tm) full_rows = fr;
+    }
+    const int blocks = full_rows * tn + (tm - full_rows) * tn * 2;
+    hipLaunchKernelGGL(gemm_nt_dma_kernel, dim3(blocks), dim3(256), 0, st, A, lda, B, ldb, M, N, K, tm, tn, full_rows, e, (g_variant & 64) ? 1 : ((g_variant & 128) ? 2 : 0));
     return check_launch("gemm_nt_dma");
   }
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(tm * tn), dim3(256), 0, st, A, lda, B, ldb, M, N, K, tm, e);

@@ -379,6 +379,35 @@ def test_gemm_nt_ring_kernel_matches_reference_and_first_generation(ops, M, N, K
                 assert torch.equal(a[k], b[k]), (v, k)
 
 
+@pytest.mark.parametrize("M,N,K", [(7168, 768, 768), (7168, 768, 3072), (13312, 384, 4096), (7000, 768, 320), (6450, 768, 64)])
+def test_gemm_nt_mixed_tile_launch_is_bitwise_the_plain_one(ops, M, N, K):
+    """Grids of 257..384 tiles are launched with their last tile rows cut into 128 x 64 halves (gemm.hip: at most 1.5 tiles of work on any CU instead of
+    2): every epilogue kind must come out bit for bit as from the all-128 x 128 launch (debug bit 1024) - same MFMA per element, same K order -
+    including a ragged last row of tiles (M = 7000, 6450)."""
+    import ctypes
+    from smb_vision_amd import _lib
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    assert 256 < -(-M // 128) * (N // 128) <= 384
+    A = rnd(M, K, seed=1).bfloat16()
+    B = rnd(N, K, seed=2, scale=0.05).bfloat16()
+    bias = rnd(N, seed=3)
+    resid = rnd(M, N, seed=4)
+    pre_b = rnd(M, N, seed=7).bfloat16()
+    runs = {}
+    for v in (0, 1024):
+        raw.smbv_debug_set_variant(v)
+        try:
+            runs[v] = (ops.gemm_nt(A, B, bias=bias, rowadd=resid, out_bf16=True, out_f32=True), ops.gemm_nt(A, B, bias=bias, gelu=True, save_pre=True),
+                       ops.gemm_nt(A, B, dgelu_pre=pre_b), ops.gemm_nt(A, B, out_bf16=False, out_f32=True, alpha=0.5))
+        finally:
+            raw.smbv_debug_set_variant(0)
+    ref = A.float() @ B.float().t()
+    assert rel_err(runs[0][0]["f32"], ref + bias + resid) < 1e-5 * math.sqrt(K) + 1e-5
+    for a, b in zip(runs[0], runs[1024]):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize("M,N1,N2", [(300, 136, 72), (4096, 128, 128), (7168, 768, 3072), (4100, 3072, 768), (2000, 2304, 768), (26, 64, 4096)])
 def test_gemm_tn_bias_column_sums_ride_along(ops, M, N1, N2):
     """smbv_gemm_tn_bias: weight gradient AND bias gradient (column sums of dY) of a linear from ONE pass - the sums are an extra X^T * ones MFMA
