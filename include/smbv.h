@@ -44,7 +44,7 @@ int smbv_version(void);                                   /* ABI version (major*
 int smbv_last_error(char* buf, size_t len);               /* copies the thread's last error text; returns its length */
 /* Tuning / A-B hook used by tools/ and by the kernel-equivalence tests, NOT by the product path: selects alternative kernels for the same
  * arithmetic (process-wide, not thread-safe; 0 = the shipped selection).  Bits: 32 register-staged GEMMs; 256 first-generation 128x128 NT
- * GEMM everywhere / 131072 second-generation ring NT GEMM everywhere (default: by shape); 512 four-slot ring; 262144 ring with 64-deep K slices; 1024 no mixed-tile NT launches (all tiles 128 x 128); 8192 attention dQ and dK/dV on
+ * GEMM everywhere / 131072 second-generation ring NT GEMM everywhere (default: by shape); 512 four-slot ring; 262144 ring with 64-deep K slices; 1024 no mixed-tile NT launches (all tiles 128 x 128); 2048 attention forward with the guarded sweep only (no optimistic first sweep); 8192 attention dQ and dK/dV on
  * one stream; 16384 weight- and input-gradient GEMMs on one stream; 32768 / 65536 TN tile selection; bits 20-23 GEMM ablation (timing only). */
 void smbv_debug_set_variant(int bits);
 

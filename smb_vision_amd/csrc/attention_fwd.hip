@@ -29,6 +29,7 @@
 // Softmax statistics in fp32.
 #include "smbv_common.h"
 #include "smbv_kernels.h"
+#include <type_traits>
 
 namespace smbv {
 
@@ -64,7 +65,7 @@ __device__ __forceinline__ bf16x8 scale_bf16x8(u32x4 v, float c) {
 // the V image needs no swizzle at all (the 4 keys x 2 column halves x 4 sub-columns of a tr-read group already tile the 64 banks).
 template <int DH>
 __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, int ld,
-                                                           bf16_t* __restrict__ O, int ldo, float* __restrict__ LSE, int S, int Sq, int qoff, int H, float scale) {
+                                                           bf16_t* __restrict__ O, int ldo, float* __restrict__ LSE, int S, int Sq, int qoff, int H, float scale, int guarded_only) {
   static_assert(DH == 64 || DH == 32, "head widths with a native build");
   constexpr int KS = DH / 16, DT = DH / 32, RB = 2 * DH;  // QK^T k-steps, 32-channel output tiles, LDS row bytes
   constexpr int IMG = 64 * RB, SLOT = 2 * IMG;           // K image | V image
@@ -133,7 +134,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restr
 #pragma unroll
   for (int dt = 0; dt < DT; dt++) va[dt] = smem + IMG + (DH == 64 ? swz_v64(4 * h2 + qq, 2 * dt + g1) : (4 * h2 + qq) * 64 + 32 * g1) + 8 * pp;
 
-  auto tile = [&](int j, int slot) __attribute__((always_inline)) {  // slot: a literal at each of the three call sites
+  // slot: a literal at each call site.  guard (std::true_type / std::false_type): with it, the tile's row maximum is formed and the running reference
+  // raised when a score outgrows it by 2^THR; without it, the scores are exponentiated against the reference as it stands (see the sweeps below).
+  auto tile = [&](int j, int slot, auto guard) __attribute__((always_inline)) {
+    constexpr bool GUARD = decltype(guard)::value;
     f32x16 sc[2];
 #pragma unroll
     for (int kt2 = 0; kt2 < 2; kt2++) {
@@ -152,23 +156,25 @@ __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restr
           if (key >= S) sc[kt2][i] = -INFINITY;
         }
     }
-    float mx = fmaxf(sc[0][0], sc[1][0]);
+    if constexpr (GUARD) {
+      float mx = fmaxf(sc[0][0], sc[1][0]);
 #pragma unroll
-    for (int i = 1; i < 16; i++) mx = fmaxf(fmaxf(mx, sc[0][i]), sc[1][i]);
-    mx = halves_max(mx);
-    const bool rebase = j == 0 || mx > ATTN_DEFER_THR;
-    if (__builtin_amdgcn_ballot_w64(rebase) != 0) {  // rare after the first tile: the reference only moves when a score outgrows it by 2^6
-      const float d = rebase ? mx : 0.f;
-      const float alpha = j == 0 ? 0.f : fast_exp2(-d);  // (nothing is accumulated before tile 0: no 0 * inf for very negative first maxima)
-      m2 += d;
-      l_a *= alpha;
+      for (int i = 1; i < 16; i++) mx = fmaxf(fmaxf(mx, sc[0][i]), sc[1][i]);
+      mx = halves_max(mx);
+      const bool rebase = j == 0 || mx > ATTN_DEFER_THR;
+      if (__builtin_amdgcn_ballot_w64(rebase) != 0) {  // rare after the first tile: the reference only moves when a score outgrows it by 2^6
+        const float d = rebase ? mx : 0.f;
+        const float alpha = j == 0 ? 0.f : fast_exp2(-d);  // (nothing is accumulated before tile 0: no 0 * inf for very negative first maxima)
+        m2 += d;
+        l_a *= alpha;
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
+        for (int i = 0; i < 16; i++) {
 #pragma unroll
-        for (int dt = 0; dt < DT; dt++) ot[dt][i] *= alpha;
-        sc[0][i] -= d;
-        sc[1][i] -= d;
-        cneg[i] = -m2;
+          for (int dt = 0; dt < DT; dt++) ot[dt][i] *= alpha;
+          sc[0][i] -= d;
+          sc[1][i] -= d;
+          cneg[i] = -m2;
+        }
       }
     }
 #pragma unroll
@@ -196,24 +202,58 @@ __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restr
     __builtin_amdgcn_s_barrier();  // the tile is published; everybody is done with the tile before it, whose slot the next copy takes
   };
   const int nt = (S + 63) / 64;
-  stage(0, 0);
-  stage(1, 1);
-  for (int j = 0; j < nt; j += 3) {  // tile j lives in slot j % 3
+  // One sweep over the key tiles (tile j lives in ring slot j % 3; the first tile always sets the reference to its row maxima).
+  auto sweep = [&](auto guard) __attribute__((always_inline)) {
+    stage(0, 0);
+    stage(1, 1);
     landed();
-    stage(j + 2, 2);
-    tile(j, 0);
-    if (j + 1 >= nt) break;
-    landed();
-    stage(j + 3, 0);
-    tile(j + 1, 1);
-    if (j + 2 >= nt) break;
-    landed();
-    stage(j + 4, 1);
-    tile(j + 2, 2);
+    stage(2, 2);
+    tile(0, 0, std::true_type{});
+    for (int j = 1; j < nt; j += 3) {
+      landed();
+      stage(j + 2, 0);
+      tile(j, 1, guard);
+      if (j + 1 >= nt) break;
+      landed();
+      stage(j + 3, 1);
+      tile(j + 1, 2, guard);
+      if (j + 2 >= nt) break;
+      landed();
+      stage(j + 4, 2);
+      tile(j + 2, 0, guard);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the sweep (or the workgroup)
+  };
+  // OPTIMISTIC sweep first: with bf16 probabilities and fp32 sums the reference only has to keep exp2(s - m) finite - accuracy does not depend on it - so the
+  // sweep exponentiates every later tile against the FIRST tile's row maxima and forms no maximum at all (21 of the loop's ~190 vector instructions per tile,
+  // 6-9 % of the kernel: the loop is vector-issue bound).  It is valid iff no row sum left the range: a score more than ~100 (log2 units) above its row's
+  // first-tile maximum shows as a sum >= 2^100 / inf / NaN.  Then - decided for the whole block, whose waves share the K / V stream - everything is reset and
+  // the sweep repeated with the guarded tiles.  Scores FAR BELOW the reference underflow to 0, which is what their weight is.
+  if (guarded_only) sweep(std::true_type{});  // debug bit 2048 (A/B and the equivalence test)
+  else sweep(std::false_type{});
+  float l_tot = halves_sum(l_a);
+  if (!guarded_only) {
+    int* flag = (int*)smem;
+    __syncthreads();  // every wave is done with the ring
+    if (t == 0) *flag = 0;
+    __syncthreads();
+    if (__builtin_amdgcn_ballot_w64(!(l_tot < 0x1p100f)) != 0 && l == 0) *(volatile int*)flag = 1;
+    __syncthreads();
+    const int redo = *(volatile int*)flag;
+    __syncthreads();  // (the flag lives in the ring the next sweep overwrites)
+    if (redo) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) ot[dt][i] = 0.f;
+        cneg[i] = 0.f;
+      }
+      m2 = 0.f;
+      l_a = 0.f;
+      sweep(std::true_type{});
+      l_tot = halves_sum(l_a);
+    }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
-
-  const float l_tot = halves_sum(l_a);
   const float inv = 1.0f / l_tot;
   if (q < Sq) {
     bf16_t* op = O + (row0 + qoff + q) * ldo + hoff;
@@ -229,6 +269,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restr
   }
 }
 
+extern int g_variant;  // debug hook, capi.hip (smbv_debug_set_variant)
+
 int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf16_t* O, int ldo, float* LSE, int B, int S, int H, int Dh,
                   float scale, int Sq, int qoff, hipStream_t st) {
   if (Sq <= 0) { Sq = S; qoff = 0; }
@@ -237,8 +279,8 @@ int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf1
   if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 3)) { set_error("attention_fwd: bad shape B=%d S=%d H=%d ld=%d ldo=%d", B, S, H, ld, ldo); return SMBV_ERR_SHAPE; }
   if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || ((uintptr_t)O & 7)) { set_error("attention_fwd: alignment"); return SMBV_ERR_ALIGN; }
   if ((size_t)(S + 512) * ld * 2 >= (1ull << 31)) { set_error("attention_fwd: one sequence spans %zu bytes of the QKV matrix; the LDS-DMA offsets are 32-bit", (size_t)S * ld * 2); return SMBV_ERR_SHAPE; }
-  if (Dh == 64) hipLaunchKernelGGL(attn_fwd3_kernel<64>, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale);
-  else hipLaunchKernelGGL(attn_fwd3_kernel<32>, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale);
+  if (Dh == 64) hipLaunchKernelGGL(attn_fwd3_kernel<64>, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale, (g_variant & 2048) ? 1 : 0);
+  else hipLaunchKernelGGL(attn_fwd3_kernel<32>, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale, (g_variant & 2048) ? 1 : 0);
   return check_launch("attention_fwd");
 }
 

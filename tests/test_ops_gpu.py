@@ -235,6 +235,43 @@ def test_attention_reference_moves_across_tiles(ops, profile):
     assert rel_err(lse, torch.logsumexp(s, -1).float()) < 8e-3
 
 
+@pytest.mark.parametrize("Dh", [64, 32])
+def test_attention_optimistic_sweep_and_its_fallback(ops, Dh):
+    """The forward first sweeps the keys WITHOUT per-tile maxima (every tile exponentiated against the first tile's row maxima) and repeats the sweep with
+    the guarded tiles only if a row sum left the fp32 range (attention_fwd.hip).  (a) ordinary logits: the optimistic result agrees with the guarded-only
+    kernel (debug bit 2048) to bf16 rounding; (b) logits that grow by hundreds after the first tile: the fallback must fire - finite output that is BITWISE
+    the guarded-only kernel's, since the repeated sweep is that kernel's."""
+    import ctypes
+    from smb_vision_amd import _lib
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    B, S, H = 2, 700, 2
+    w = H * Dh
+
+    def both(qkv):
+        out = {}
+        for v in (0, 2048):
+            raw.smbv_debug_set_variant(v)
+            try:
+                out[v] = ops.attention_fwd(qkv, B, S, H, Dh=Dh)
+            finally:
+                raw.smbv_debug_set_variant(0)
+        return out
+
+    qkv = rnd(B * S, 3 * w, seed=41).bfloat16()
+    r = both(qkv)
+    q, k, v, s = _attn_ref(qkv, B, S, H, Dh)
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * S, w)
+    for key in (0, 2048):
+        assert rel_err(r[key][0], ref) < 1.5e-2 and rel_err(r[key][1], torch.logsumexp(s, -1)) < 2e-3
+    assert rel_err(r[0][0], r[2048][0]) < 8e-3 and float((r[0][1] - r[2048][1]).abs().max()) < 1e-4
+    hot = rnd(B * S, 3 * w, seed=42)
+    hot[:, w:2 * w] *= torch.linspace(0.05, 60.0, S).repeat(B).cuda()[:, None]   # key norms (and with them the logits) rise along the sequence
+    hot[:, :w] *= 3.0
+    r = both(hot.bfloat16())
+    assert bool(torch.isfinite(r[0][0].float()).all()) and bool(torch.isfinite(r[0][1]).all())
+    assert torch.equal(r[0][0], r[2048][0]) and torch.equal(r[0][1], r[2048][1])
+
+
 @pytest.mark.parametrize("ps,ts", [(16, 16), (8, 8), (4, 8)])
 def test_bricks_stats_mse(ops, ps, ts):
     B, T, H, W = 2, 32, 64, 64

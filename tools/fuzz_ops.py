@@ -1,5 +1,5 @@
 """Randomised shape sweep of the attention and GEMM entry points against fp32 torch references (tolerances of tests/test_ops_gpu.py).
-usage: fuzz_ops.py [n_cases] [seed]"""
+usage: fuzz_ops.py [n_cases] [seed] [debug_variant]"""
 import sys, os, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,6 +7,9 @@ from smb_vision_amd import ops
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+if len(sys.argv) > 3:
+    from smb_vision_amd import _lib
+    _lib.load().smbv_debug_set_variant(int(sys.argv[3]))
 def rel(a, b): return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-30))
 bad = 0
 for i in range(n_cases):
@@ -33,9 +36,11 @@ for i in range(n_cases):
     dqkv, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh)
     ref.backward(dO.float().view(B, S, w)[:, qo:qo + sq])
     e = [rel(got, ref), rel(lse, torch.logsumexp(s, -1))] + [rel(dqkv[:, j * w:(j + 1) * w], qf.grad[:, j * w:(j + 1) * w]) for j in range(3)]
-    ok = e[0] < 2.5e-2 and e[1] < 4e-3 and max(e[2:]) < 4e-2 and bool(torch.isfinite(dqkv.float()).all())
+    rms = max(float((dqkv[:, j * w:(j + 1) * w].float() - qf.grad[:, j * w:(j + 1) * w]).pow(2).mean().sqrt() / qf.grad[:, j * w:(j + 1) * w].pow(2).mean().sqrt()) for j in range(3))
+    # max-abs bound 5e-2 (single elements of a short query range carry the bf16 rounding of dS un-averaged), rms bound 1.5e-2 as in tests/test_ops_gpu.py
+    ok = e[0] < 2.5e-2 and e[1] < 4e-3 and max(e[2:]) < 5e-2 and rms < 1.5e-2 and bool(torch.isfinite(dqkv.float()).all())
     bad += not ok
-    print(f"attn Dh{Dh} B{B} S{S} H{H} Sq{Sq} qoff{qoff}: O {e[0]:.1e} lse {e[1]:.1e} dq {e[2]:.1e} dk {e[3]:.1e} dv {e[4]:.1e} {'ok' if ok else 'FAIL'}", flush=True)
+    print(f"attn Dh{Dh} B{B} S{S} H{H} Sq{Sq} qoff{qoff}: O {e[0]:.1e} lse {e[1]:.1e} dq {e[2]:.1e} dk {e[3]:.1e} dv {e[4]:.1e} rms {rms:.1e} {'ok' if ok else 'FAIL'}", flush=True)
 for i in range(n_cases):
     M = rng.choice([rng.randint(1, 300), rng.randint(300, 9000)])
     N, K = 8 * rng.randint(1, 400), 8 * rng.randint(1, 260)
