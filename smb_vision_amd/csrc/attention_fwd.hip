@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restr
     cneg[i] = 0.f;
   }
   float m2 = 0.f, l_a = 0.f;
+  float ref_shift = 0.f;  // added to the first tile's row maxima when they become the reference (the optimistic sweep, below)
 
   const i32x4 rsk = dma_rsrc(K + row0 * ld + hoff, (unsigned)(((size_t)(S - 1) * ld + DH) * 2));
   const i32x4 rsv = dma_rsrc(V + row0 * ld + hoff, (unsigned)(((size_t)(S - 1) * ld + DH) * 2));
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restr
       mx = halves_max(mx);
       const bool rebase = j == 0 || mx > ATTN_DEFER_THR;
       if (__builtin_amdgcn_ballot_w64(rebase) != 0) {  // rare after the first tile: the reference only moves when a score outgrows it by 2^6
-        const float d = rebase ? mx : 0.f;
+        const float d = rebase ? mx + (j == 0 ? ref_shift : 0.f) : 0.f;
         const float alpha = j == 0 ? 0.f : fast_exp2(-d);  // (nothing is accumulated before tile 0: no 0 * inf for very negative first maxima)
         m2 += d;
         l_a *= alpha;
@@ -229,8 +230,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restr
   // 6-9 % of the kernel: the loop is vector-issue bound).  It is valid iff no row sum left the range: a score more than ~100 (log2 units) above its row's
   // first-tile maximum shows as a sum >= 2^100 / inf / NaN.  Then - decided for the whole block, whose waves share the K / V stream - everything is reset and
   // the sweep repeated with the guarded tiles.  Scores FAR BELOW the reference underflow to 0, which is what their weight is.
+  // (its reference sits 2^32 ABOVE the first tile's maxima: what can overflow is a later score, so the window is put where it helps - scores up to ~130
+  // log2 units above the first tile's maximum stay in range, scores more than ~94 below it flush to the zero their weight rounds to anyway)
   if (guarded_only) sweep(std::true_type{});  // debug bit 2048 (A/B and the equivalence test)
-  else sweep(std::false_type{});
+  else { ref_shift = 32.f; sweep(std::false_type{}); ref_shift = 0.f; }
   float l_tot = halves_sum(l_a);
   if (!guarded_only) {
     int* flag = (int*)smem;
