@@ -1,9 +1,9 @@
-// Fused multi-head self-attention forward (flash-style, no mask, non-causal, dropout 0) for head_dim 64.
+// Fused multi-head self-attention forward (flash-style, no mask, non-causal, dropout 0) for head_dim 64 and 32.
 // Replaces eager_attention_forward / SDPA / flash-attn at src/models/videomae/modeling_videomae.py:196-223, 270-289:
 //   O = softmax_fp32(Q K^T * Dh^-0.5) V, plus LSE per query row for the backward.
 //
 // Layout: Q, K, V are column slices of one token-major matrix [B*S, ld] (the fused QKV GEMM output), head h at
-// columns h*64 .. h*64+63; O is token-major [B*S, ldo].  No head-major copies are made.
+// columns h*Dh .. h*Dh+Dh-1; O is token-major [B*S, ldo].  No head-major copies are made.
 //
 // Work decomposition: grid (ceil(S/128), H, B); 4 waves per block, each wave owns 32 query rows; K/V tiles of 64 keys travel
 // global -> LDS by LDS-DMA into a ring of three 16-KiB slots (two tiles in flight, one barrier per tile, no staging registers).
@@ -18,14 +18,15 @@
 //   * Q is pre-multiplied by scale*log2(e) once: scores come out of the MFMA in the exp2 domain;
 //   * the running reference -m sits in a persistent 16-register block used as the C input of the first QK MFMA of each
 //     chain, so p = exp2(acc) needs no per-element subtract;
-//   * the reference is only moved (and O, l rescaled) when a tile's maximum exceeds it by more than 2^THR (deferred
-//     max): exp2 arguments stay <= THR, exact in fp32; tile 0 always rebases;
+//   * NO per-tile maximum in the first sweep over the keys: with bf16 probabilities and fp32 sums the reference only has to keep exp2 finite, so
+//     every tile is exponentiated against the first tile's row maxima (+ 32); a block whose row sums left the range repeats the sweep with guarded
+//     tiles, in which the reference moves (and O, l are rescaled) when a tile's maximum exceeds it by more than 2^THR - see the kernel;
 //   * no address arithmetic in the loop: the tile loop is unrolled over the ring's three slots, so every LDS read is one of six
 //     per-lane base registers plus an immediate (with the slot computed from j, 44 of the loop's ~230 vector instructions were
 //     address adds: 0.82 -> 0.70 ms at S = 20,480, H = 6);
 //   * <= 168 registers -> THREE blocks per CU (three waves per SIMD) rather than hand-placing two waves' instruction streams: the
-//     hand-phased two-wave form of round 1 measured 0.82 ms against 0.68 ms for this plain loop (tools/attn_fwd_ab.py history in
-//     profiles/README.md).
+//     hand-phased two-wave form of round 1 measured 0.82 ms against 0.68 ms for this plain loop with guarded tiles, 0.63 ms with the optimistic
+//     sweep (profiles/README.md).
 // Softmax statistics in fp32.
 #include "smbv_common.h"
 #include "smbv_kernels.h"
