@@ -1,4 +1,4 @@
-// Fused multi-head self-attention backward (flash-style recompute from LSE), head_dim 64.
+// Fused multi-head self-attention backward (flash-style recompute from LSE), head_dim 64 and 32 (template parameter DH).
 // Autograd of src/models/videomae/modeling_videomae.py:196-223 (softmax(QK^T*scale) V).
 //
 // Three launches, no float atomics (bitwise reproducible):
