@@ -14,7 +14,9 @@
  *   - pointers must be 16-byte aligned unless noted;
  *   - return value: 0 = ok, negative = SMBV_ERR_* (bad shape / alignment / argument / workspace), positive = hipError_t;
  *     smbv_last_error() returns the message of the calling thread's last failure; no C++ exception crosses the ABI;
- *   - re-entrant and stream-ordered; safe from autograd's backward thread;
+ *   - stream-ordered; callable from any host thread (autograd's backward thread included), but the step / block / attention-backward entry
+ *     points fork onto the per-device side streams below and are NOT safe to run from two host threads on the SAME device at once (the library
+ *     serialises the fork / join bookkeeping with a per-device mutex; the side streams themselves are shared);
  *   - state inside the library: the immutable code object; a thread-local error string; per device, ONE private non-blocking side
  *     stream and a few events created on first use and kept for the life of the process (attention backward runs its dQ and dK/dV
  *     kernels side by side, the block backward its weight-gradient products beside the input-gradient ones; everything forked is
@@ -40,7 +42,12 @@ extern "C" {
 typedef void* smbv_stream;   /* hipStream_t */
 typedef uint16_t smbv_bf16;
 
-int smbv_version(void);                                   /* ABI version (major*1000 + minor) */
+/* ABI version = major*1000 + minor.  A binding must check major == SMBV_ABI_MAJOR (struct layouts / argument meanings are only stable within one
+ * major) and minor >= the newest entry point it calls.  2000: every *_cfg struct opens with `struct_bytes` (= sizeof of the caller's struct, checked
+ * by the library: a binding compiled against a shorter or longer layout is refused with SMBV_ERR_ARG instead of being read past its end);
+ * 1000-1002 (round 1-2) had no such guard and grew smbv_mim_cfg / smbv_vjepa_cfg in place. */
+#define SMBV_ABI_MAJOR 2
+int smbv_version(void);
 int smbv_last_error(char* buf, size_t len);               /* copies the thread's last error text; returns its length */
 /* Tuning / A-B hook used by tools/ and by the kernel-equivalence tests, NOT by the product path: selects alternative kernels for the same
  * arithmetic (process-wide, not thread-safe; 0 = the shipped selection).  Bits: 32 register-staged GEMMs; 256 first-generation 128x128 NT
@@ -130,6 +137,7 @@ size_t smbv_colsum_workspace_bytes(int M, int N);
 /* ---- the whole MIM train step: VideoMAEForPreTraining.forward (spec :753-908) and its autograd -------------------- */
 
 typedef struct smbv_mim_cfg {
+  int struct_bytes;               /* sizeof(smbv_mim_cfg) as the caller compiled it */
   int B, T, H, W;                 /* volume batch: pixel_values fp32 [B,T,1,H,W] */
   int ps, ts;                     /* patch_size, tubelet_size */
   int N, Nvis, Nmask;             /* tokens per volume: all / visible / masked */
@@ -192,6 +200,7 @@ int smbv_mim_backward(const smbv_mim_cfg* cfg, const smbv_mim_tensors* params, c
  *      embedding export (all tokens, no mask) and as the classification head (spec :917-989) sits on it. ---- */
 
 typedef struct smbv_encoder_cfg {
+  int struct_bytes;               /* sizeof(smbv_encoder_cfg) as the caller compiled it */
   int B, T, H, W;                 /* pixel_values fp32 [B,T,1,H,W] */
   int ps, ts;
   int N, Nsel;                    /* tokens per volume; tokens processed (N without a mask, the visible ones with bool_masked_pos) */
@@ -268,6 +277,7 @@ int smbv_ema_update(const smbv_adam_chunk* chunks_dev, int nchunks, float moment
 /* ---- the V-JEPA online-model step: VJEPA2Model.forward with context/target masks (modeling_vjepa.py:1081-1163) and its autograd ---- */
 
 typedef struct smbv_vjepa_cfg {
+  int struct_bytes;                /* sizeof(smbv_vjepa_cfg) as the caller compiled it */
   int B, T, H, W;                  /* pixel_values_videos fp32 [B,T,1,H,W], H == W == crop_size */
   int ps, ts;                      /* patch_size, tubelet_size */
   int N, Nctx, Ntgt;               /* tokens per volume; context / target tokens per volume */

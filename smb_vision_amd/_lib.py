@@ -8,6 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsmbv.so")
 MAX_LAYERS = 48
+ABI_MAJOR, ABI_MINOR_NEEDED = 2, 0  # include/smbv.h SMBV_ABI_MAJOR; the newest entry point these bindings call
 
 c_f = C.c_void_p  # all device pointers travel as void*
 
@@ -24,9 +25,17 @@ class GemmEpi(C.Structure):
     ]
 
 
-class MimCfg(C.Structure):
+class _Cfg(C.Structure):
+    """cfg structs open with ``struct_bytes`` (ABI 2000): filled in here so that a binding / library layout mismatch is refused by the library."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_bytes = C.sizeof(type(self))
+
+
+class MimCfg(_Cfg):
     _fields_ = [(n, C.c_int) for n in
-                ("B", "T", "H", "W", "ps", "ts", "N", "Nvis", "Nmask", "d", "heads", "ff", "layers", "dd", "dheads", "dff", "dlayers")] + \
+                ("struct_bytes", "B", "T", "H", "W", "ps", "ts", "N", "Nvis", "Nmask", "d", "heads", "ff", "layers", "dd", "dheads", "dff", "dlayers")] + \
                [("ln_eps", C.c_float), ("dec_norm_eps", C.c_float), ("recompute", C.c_int), ("attn_fp8", C.c_int)]
 
 
@@ -47,8 +56,8 @@ class MimIO(C.Structure):
                 ("loss", c_f), ("logits", c_f), ("grad_scale", c_f)]
 
 
-class EncoderCfg(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("B", "T", "H", "W", "ps", "ts", "N", "Nsel", "d", "heads", "ff", "layers")] + \
+class EncoderCfg(_Cfg):
+    _fields_ = [(n, C.c_int) for n in ("struct_bytes", "B", "T", "H", "W", "ps", "ts", "N", "Nsel", "d", "heads", "ff", "layers")] + \
                [("ln_eps", C.c_float), ("final_ln", C.c_int), ("final_ln_eps", C.c_float), ("train", C.c_int)]
 
 
@@ -69,8 +78,8 @@ class AdamHyper(C.Structure):
                 ("bias_corr1", C.c_float), ("bias_corr2", C.c_float), ("max_grad_norm", C.c_float)]
 
 
-class VjepaCfg(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("B", "T", "H", "W", "ps", "ts", "N", "Nctx", "Ntgt", "d", "heads", "ff", "layers", "pd", "pheads", "pff", "players")] + \
+class VjepaCfg(_Cfg):
+    _fields_ = [(n, C.c_int) for n in ("struct_bytes", "B", "T", "H", "W", "ps", "ts", "N", "Nctx", "Ntgt", "d", "heads", "ff", "layers", "pd", "pheads", "pff", "players")] + \
                [("ln_eps", C.c_float), ("n_masks", C.c_int)]
 
 
@@ -158,6 +167,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if an export declared in include/smbv.h is missing
         fn.restype = res
         fn.argtypes = args
+    ver = lib.smbv_version()
+    if ver // 1000 != ABI_MAJOR or ver % 1000 < ABI_MINOR_NEEDED:
+        raise SmbvError(f"{LIB_PATH} reports ABI {ver}; these bindings need major {ABI_MAJOR}, minor >= {ABI_MINOR_NEEDED} "
+                        "(rebuild with python -m smb_vision_amd.build)")
     _lib = lib
     return lib
 

@@ -555,11 +555,14 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
   if ((parts & 6) == 6 && !(g_variant & 8192)) {
     fj = fork_join_for_current_device();
     if (fj) {
-      HIPRC(hipEventRecord(fj->fork, st));
-      HIPRC(hipStreamWaitEvent(fj->side, fj->fork, 0));
+      RC(stream_edge(fj, fj->fork, st, fj->side));
       st_dq = fj->side;
     }
   }
+  struct Join {  // (also on the error returns below: the forked stream never stays un-joined)
+    ForkJoin* fj; hipStream_t st;
+    ~Join() { if (fj) stream_edge(fj, fj->join, fj->side, st); }
+  } join{fj, st};
   if (parts & 2) {
     if (Dh == 64) hipLaunchKernelGGL((attn_dkv2_kernel<128, 64>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale);
     else hipLaunchKernelGGL((attn_dkv2_kernel<128, 32>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale);
@@ -571,11 +574,7 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     else hipLaunchKernelGGL((attn_dq2_kernel<128, 32>), dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale);
     rc = check_launch("attn_dq");
   }
-  if (fj) {
-    HIPRC(hipEventRecord(fj->join, fj->side));
-    HIPRC(hipStreamWaitEvent(st, fj->join, 0));
-  }
-  return rc;
+  return rc;  // ~Join: `st` waits for the dQ kernel
 }
 
 }  // namespace smbv

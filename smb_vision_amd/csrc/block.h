@@ -53,8 +53,12 @@ struct ForkJoin {  // streams.hip
   hipStream_t side = nullptr, wside = nullptr;
   hipEvent_t fork = nullptr, join = nullptr, wfork = nullptr, wjoin = nullptr;
   bool ready = false;
+  void* mu = nullptr;  // std::mutex*: a record + wait pair on one of the events above is made under it (two host threads on one device)
 };
 ForkJoin* fork_join_for_current_device();
+// `to` waits for everything enqueued on `from` so far: hipEventRecord(ev, from) + hipStreamWaitEvent(to, ev) as ONE step under the device's mutex,
+// so that another host thread's re-record of the same event cannot fall between the two
+int stream_edge(ForkJoin* fj, hipEvent_t ev, hipStream_t from, hipStream_t to);
 
 // The library's per-device weight-gradient side stream (streams.hip).  begin(): work enqueued on `st` afterwards
 // starts only after everything enqueued on the caller's stream so far; end(): the caller's stream waits for all side work.  With the debug
@@ -63,8 +67,10 @@ struct SideStream {
   hipStream_t st = nullptr;
   void* impl = nullptr;
   bool used = false;
+  hipStream_t caller_ = nullptr;
   int begin(hipStream_t caller);
   int end(hipStream_t caller);
+  ~SideStream() { if (used) end(caller_); }  // an error return between begin() and end() still joins the side stream back into the caller's
 };
 
 struct Carver {

@@ -48,7 +48,7 @@ using namespace smbv;
 
 extern "C" {
 
-int smbv_version(void) { return 1002; }  // 1002: attention entry points accept Dh = 32
+int smbv_version(void) { return 2000; }  // 2000: *_cfg structs open with struct_bytes (validated); see include/smbv.h
 void smbv_debug_set_variant(int bits) { smbv::g_variant = bits; }
 
 int smbv_last_error(char* buf, size_t len) {

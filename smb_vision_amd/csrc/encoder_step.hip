@@ -27,6 +27,7 @@ static BlockDims edims(const smbv_encoder_cfg& c) {
 }
 
 static int check_cfg(const smbv_encoder_cfg& c) {
+  if (c.struct_bytes != (int)sizeof(smbv_encoder_cfg)) { set_error("encoder: cfg.struct_bytes = %d, this library's smbv_encoder_cfg is %d bytes (binding built against another ABI: check smbv_version())", c.struct_bytes, (int)sizeof(smbv_encoder_cfg)); return SMBV_ERR_ARG; }
   if (c.B <= 0 || c.layers <= 0 || c.layers > SMBV_MAX_LAYERS) { set_error("encoder: bad batch/layer counts"); return SMBV_ERR_SHAPE; }
   if (c.ps <= 0 || c.ts <= 0 || c.T % c.ts || c.H % c.ps || c.W % c.ps || (c.ps & 3)) { set_error("encoder: volume %dx%dx%d not divisible by tubelet %d / patch %d", c.T, c.H, c.W, c.ts, c.ps); return SMBV_ERR_SHAPE; }
   const int N = (c.T / c.ts) * (c.H / c.ps) * (c.W / c.ps);

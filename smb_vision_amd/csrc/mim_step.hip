@@ -41,6 +41,7 @@ static BlockPtrs to_block(const smbv_layer_ptrs& p) {
 }
 
 static int check_cfg(const smbv_mim_cfg& c) {
+  if (c.struct_bytes != (int)sizeof(smbv_mim_cfg)) { set_error("mim: cfg.struct_bytes = %d, this library's smbv_mim_cfg is %d bytes (binding built against another ABI: check smbv_version())", c.struct_bytes, (int)sizeof(smbv_mim_cfg)); return SMBV_ERR_ARG; }
   if (c.B <= 0 || c.layers <= 0 || c.dlayers <= 0 || c.layers > SMBV_MAX_LAYERS || c.dlayers > SMBV_MAX_LAYERS) { set_error("mim: bad batch/layer counts"); return SMBV_ERR_SHAPE; }
   if (c.ps <= 0 || c.ts <= 0 || c.T % c.ts || c.H % c.ps || c.W % c.ps || (c.ps & 3)) { set_error("mim: volume %dx%dx%d not divisible by tubelet %d / patch %d", c.T, c.H, c.W, c.ts, c.ps); return SMBV_ERR_SHAPE; }
   const int N = (c.T / c.ts) * (c.H / c.ps) * (c.W / c.ps);

@@ -23,9 +23,17 @@ ForkJoin* fork_join_for_current_device() {
     hipEvent_t* ev[4] = {&f.fork, &f.join, &f.wfork, &f.wjoin};
     for (auto e : ev)
       if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    f.mu = new std::mutex();
     f.ready = true;
   }
   return &f;
+}
+
+int stream_edge(ForkJoin* fj, hipEvent_t ev, hipStream_t from, hipStream_t to) {
+  std::lock_guard<std::mutex> lk(*(std::mutex*)fj->mu);
+  HIPRC(hipEventRecord(ev, from));
+  HIPRC(hipStreamWaitEvent(to, ev, 0));
+  return SMBV_OK;
 }
 
 int SideStream::begin(hipStream_t caller) {
@@ -36,18 +44,17 @@ int SideStream::begin(hipStream_t caller) {
   }
   ForkJoin* fj = (ForkJoin*)impl;
   if (!fj) { st = caller; return SMBV_OK; }
-  HIPRC(hipEventRecord(fj->wfork, caller));
-  HIPRC(hipStreamWaitEvent(fj->wside, fj->wfork, 0));
+  RC(stream_edge(fj, fj->wfork, caller, fj->wside));
   used = true;
+  caller_ = caller;
   return SMBV_OK;
 }
 
 int SideStream::end(hipStream_t caller) {
   ForkJoin* fj = (ForkJoin*)impl;
   if (!fj || !used) return SMBV_OK;
-  HIPRC(hipEventRecord(fj->wjoin, fj->wside));
-  HIPRC(hipStreamWaitEvent(caller, fj->wjoin, 0));
   used = false;
+  RC(stream_edge(fj, fj->wjoin, fj->wside, caller));
   return SMBV_OK;
 }
 

@@ -48,6 +48,7 @@ static BlockPtrs vblock(const smbv_block_ptrs& p) {
 }
 
 static int vcheck(const smbv_vjepa_cfg& c) {
+  if (c.struct_bytes != (int)sizeof(smbv_vjepa_cfg)) { set_error("vjepa: cfg.struct_bytes = %d, this library's smbv_vjepa_cfg is %d bytes (binding built against another ABI: check smbv_version())", c.struct_bytes, (int)sizeof(smbv_vjepa_cfg)); return SMBV_ERR_ARG; }
   if (c.n_masks < 0 || c.n_masks > 64) { set_error("vjepa: n_masks %d out of range", c.n_masks); return SMBV_ERR_SHAPE; }
   if (c.B <= 0 || c.layers <= 0 || c.players < 0 || c.layers > SMBV_MAX_LAYERS || c.players > SMBV_MAX_LAYERS) { set_error("vjepa: bad batch/layer counts"); return SMBV_ERR_SHAPE; }
   if (c.ps <= 0 || c.ts <= 0 || c.T % c.ts || c.H % c.ps || c.W % c.ps || (c.ps & 3) || c.H != c.W) { set_error("vjepa: volume %dx%dx%d vs tubelet %d / patch %d (square crops only)", c.T, c.H, c.W, c.ts, c.ps); return SMBV_ERR_SHAPE; }

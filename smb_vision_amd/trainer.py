@@ -19,6 +19,8 @@ produced (accelerate's ``sync_each_batch`` behaviour): mean of sums == sum of me
 """
 from __future__ import annotations
 
+import re
+
 import torch
 import torch.distributed as dist
 from transformers import Trainer
@@ -27,6 +29,7 @@ from .dp import DataParallelEngine
 from .optim import SmbvAdamW
 
 _NATIVE_OPTIMS = ("adamw_torch", "adamw_torch_fused", "adamw_hf")
+_NORM_COMPONENT = re.compile(r"(?:^|\.)(?:layer_?)?norm(?:_?\w*)?\.(?:weight|bias)$", re.IGNORECASE)  # ...norm1.weight, ...layernorm_before.bias, ...
 
 
 class DevicePrefetcher:
@@ -136,6 +139,17 @@ class SmbTrainer(Trainer):
         finally:
             self.accelerator.device_placement = placement
         return DevicePrefetcher(loader, next(self.model.parameters()).device)
+
+    # -- decay grouping -------------------------------------------------------------------------------------------------------------------
+    def get_decay_parameter_names(self, model):
+        """HF excludes LayerNorm parameters from weight decay by MODULE TYPE (``nn.LayerNorm``) or by name (``bias``, ``layernorm``, ``.norm.``).  The
+        native models keep their parameters in plain containers named as the reference's state dict names them (``norm1`` / ``norm2`` for the V-JEPA
+        blocks, ``src/models/vjepa/modeling_vjepa.py:426-478``), which match neither rule - so the LayerNorm gains are taken out here by their
+        container name.  Pinned by ``tests/golden/decay_names.json`` (HF's own split of the reference classes)."""
+        names = Trainer.get_decay_parameter_names(self, model)
+        if not _is_native(model):
+            return names
+        return [n for n in names if not _NORM_COMPONENT.search(n)]
 
     # -- fused optimizer tail -------------------------------------------------------------------------------------------------------------
     def create_optimizer(self, model=None):

@@ -364,6 +364,30 @@ def make_vjepa_multimask(name="vjepa_multimask"):
     print(name, {k: tuple(v.shape) for k, v in blob.items() if k.startswith("out.")})
 
 
+def make_decay_names(name="decay_names"):
+    """The decay / no-decay split HF ``Trainer.get_decay_parameter_names`` computes for the reference model classes (``run_mim.py`` /
+    ``run_vjepa.py`` hand those to ``Trainer``; ``scripts/training/run_vjepa.sh:23`` sets --weight_decay 0.01): parameter NAMES only, as JSON."""
+    import json
+    from transformers import Trainer, VideoMAEConfig, VideoMAEForPreTraining
+    sys.path.insert(0, os.path.join(REF, "src"))
+    from models.vjepa.configuration_vjepa import VJEPA2Config
+    from models.vjepa.modeling_vjepa import VJEPA2Model
+    out = {}
+    mim = VideoMAEForPreTraining(VideoMAEConfig(num_channels=1, **GOLDEN_CONFIGS["mim_tiny_p16"]["cfg"]))
+    dec = set(Trainer.get_decay_parameter_names(None, mim))
+    pin = lambda k: k.replace("attention.attention.query.bias", "attention.attention.q_bias").replace("attention.attention.value.bias", "attention.attention.v_bias")
+    names = [k for k, _ in mim.named_parameters() if not k.endswith("attention.attention.key.bias")]
+    out["mim"] = {"decay": sorted(pin(k) for k in names if k in dec), "no_decay": sorted(pin(k) for k in names if k not in dec)}
+    vj = VJEPA2Model(VJEPA2Config(**VJEPA_TINY))
+    dec = set(Trainer.get_decay_parameter_names(None, vj))
+    names = [k for k, _ in vj.named_parameters()]
+    out["vjepa"] = {"decay": sorted(k for k in names if k in dec), "no_decay": sorted(k for k in names if k not in dec)}
+    out["_generator"] = "transformers %s Trainer.get_decay_parameter_names on transformers.VideoMAEForPreTraining / reference VJEPA2Model" % __import__("transformers").__version__
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(name, {k: (len(v["decay"]), len(v["no_decay"])) for k, v in out.items() if not k.startswith("_")})
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["mim", "vjepa", "encoder"]
     if "mim" in which:
@@ -377,3 +401,5 @@ if __name__ == "__main__":
         make_vjepa_multimask()
     if "encoder" in which:
         make_encoder()
+    if "decay" in which:
+        make_decay_names()

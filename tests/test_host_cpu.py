@@ -222,3 +222,40 @@ def test_host_index_lists_equal_the_device_sort_and_the_reference_boolean_indexi
     bad[1, :] = False
     with pytest.raises(ValueError, match="same number"):
         split_mask_indices_host(bad)
+
+
+def test_decay_groups_equal_hf_split_of_the_reference_classes():
+    """ADVICE r2: SmbTrainer's decay / no-decay split must be the one HF computes for the reference classes (LayerNorm gains and every bias undecayed);
+    tests/golden/decay_names.json holds that split (make_golden.py decay)."""
+    import json
+    from transformers import VideoMAEConfig, VJEPA2Config
+    from smb_vision_amd.modeling_videomae import SmbVideoMAEForPreTraining
+    from smb_vision_amd.modeling_vjepa import SmbVJEPA2Model
+    from smb_vision_amd.trainer import SmbTrainer
+    ref = json.load(open(os.path.join(G, "decay_names.json")))
+    vj = dict(patch_size=8, crop_size=32, frames_per_clip=8, tubelet_size=2, in_chans=1, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+              mlp_ratio=4.0, pred_hidden_size=64, pred_num_hidden_layers=2, pred_num_attention_heads=2, pred_num_mask_tokens=10, pred_mlp_ratio=4.0)
+    for key, model in (("mim", SmbVideoMAEForPreTraining(VideoMAEConfig(num_channels=1, **TINY))), ("vjepa", SmbVJEPA2Model(VJEPA2Config(**vj)))):
+        names = [n for n, _ in model.named_parameters()]
+        decay = set(SmbTrainer.get_decay_parameter_names(None, model))
+        assert sorted(n for n in names if n in decay) == ref[key]["decay"], key
+        assert sorted(n for n in names if n not in decay) == ref[key]["no_decay"], key
+
+
+def test_cfg_struct_size_guard_and_abi_major():
+    """a binding compiled against another struct layout is refused (struct_bytes), and the loader checks the ABI major."""
+    lib = _lib.load()
+    assert lib.smbv_version() // 1000 == _lib.ABI_MAJOR
+    hdr = open(os.path.join(ROOT, "include", "smbv.h")).read()
+    assert int(re.search(r"#define SMBV_ABI_MAJOR (\d+)", hdr).group(1)) == _lib.ABI_MAJOR
+    cfg = _lib.MimCfg(B=1, T=320, H=512, W=512, ps=16, ts=16, N=20480, Nvis=7168, Nmask=13312, d=768, heads=12, ff=3072, layers=12,
+                      dd=384, dheads=6, dff=1536, dlayers=4, ln_eps=1e-12, dec_norm_eps=1e-5)
+    assert cfg.struct_bytes == ctypes.sizeof(_lib.MimCfg) and lib.smbv_mim_workspace_bytes(ctypes.byref(cfg)) > 0
+    cfg.struct_bytes -= 8  # the round-2 layout without recompute / attn_fp8
+    assert lib.smbv_mim_workspace_bytes(ctypes.byref(cfg)) == 0 and "struct_bytes" in _lib.last_error()
+    v = _lib.VjepaCfg()
+    v.struct_bytes = 4
+    assert lib.smbv_vjepa_workspace_bytes(ctypes.byref(v)) == 0 and "struct_bytes" in _lib.last_error()
+    e = _lib.EncoderCfg()
+    e.struct_bytes = 0
+    assert lib.smbv_encoder_workspace_bytes(ctypes.byref(e)) == 0 and "struct_bytes" in _lib.last_error()
