@@ -20,8 +20,13 @@ prints ONE JSON line (the task contract):
                         `step` the whole-step figure (18.46 TFLOP algorithmic fwd+bwd per volume).  Peak 2.5 PFLOP/s dense bf16.
   cpu_baseline          the CPU oracle (oracle/mim_oracle.py, kind "port", fused CPU attention as the reference defaults to SDPA) on this host's cores:
                         one warm-up step on a 2+1-layer model, then 2 timed FULL steps (forward + loss + backward) of the same workload.  Rank 0, N == 1.
+  cpu_baseline.reference_class   the class the reference trains (src/run_mim.py:13-21 imports transformers.VideoMAEForPreTraining) on the same workload and cores:
+                        fp32, SDPA attention, forward + loss + backward, one warm-up on a 2+1-layer model and ONE timed full step - beside the port, which stays the
+                        headline CPU figure (kind "port"); it validates that the port is not a slower or faster program than the reference's own class.
+  config.vjepa_ms_per_step / config.vit_large_fp8_recompute_ms_per_step   BASELINE.json configs 4 and 5 (one GPU), a few steps each after the headline leg.
   config.trainer_ms_per_step   the same workload through the shipped harness (smb_vision_amd.run_mim: HF Trainer + SmbTrainer's optimizer tail) with
                         volumes handed over as pinned fp32 CPU tensors the way the reference's DataLoader does; N == 1 only.
+N > 1: `fed` is reported too (every rank feeds its own volumes over PCIe at once).
 Diagnostics (not the metric): --vjepa (BASELINE.json config 4), --vit-large (config 5's model), --tiny, --no-optimizer, --torch-optimizer.
 """
 from __future__ import annotations
@@ -148,6 +153,32 @@ def cpu_baseline(threads, timed=2):
                        f"step on a 2+1-layer model then {timed} timed full steps ({', '.join(f'{t:.1f}s' for t in ts)}), optimizer excluded")
 
 
+def reference_class_baseline(threads):
+    """transformers.VideoMAEForPreTraining - the class src/run_mim.py:13-21 imports and :345-357 instantiates - on the bench workload: fp32, SDPA,
+    forward + loss + backward on the host's cores.  One warm-up on a 2+1-layer model, one timed full step."""
+    from transformers import VideoMAEConfig, VideoMAEForPreTraining
+    from smb_vision_amd.masking import MaskGenerator
+    torch.set_num_threads(threads)
+    np.random.seed(42)
+    mask = MaskGenerator(512, 320, 32, 16, 0.65)().unsqueeze(0)
+    pix = torch.rand(1, 320, 1, 512, 512, generator=torch.Generator().manual_seed(1234))
+
+    def one(cfg_kw):
+        cfg = VideoMAEConfig(**cfg_kw)
+        cfg._attn_implementation = "sdpa"
+        torch.manual_seed(42)
+        m = VideoMAEForPreTraining(cfg).float().train()
+        t0 = time.perf_counter()
+        out = m(pixel_values=pix, bool_masked_pos=mask)
+        out.loss.backward()
+        return time.perf_counter() - t0, float(out.loss)
+
+    one(dict(VIT_BASE, num_hidden_layers=2, decoder_num_hidden_layers=1))
+    dt, loss = one(VIT_BASE)
+    return dict(value=1.0 / dt, unit="volumes/s", seconds_per_step=round(dt, 2), loss=loss, cores=threads,
+                what="transformers.VideoMAEForPreTraining (the reference's model class, src/run_mim.py:13-21), fp32, sdpa, forward + loss + backward, 1 timed step")
+
+
 class _FedSource:
     """Endless (raw int16 HU volume in page-locked memory, extras) stream: 4 distinct volumes cycled, a fresh mask per step from the bit-exact
     generator (global numpy RNG, as the reference's GenerateMask) with the token lists built on the host."""
@@ -215,10 +246,9 @@ def trainer_ms_per_step(cfg_kw, steps=10, warm=8):
     return (Clock.t1 - Clock.t0) / steps * 1e3
 
 
-def run_vjepa(args, device, world, rank):
-    """--vjepa: BASELINE.json config 4 (ViT-base encoder + default predictor, 512x512x320, B = 1, 3 mask blocks): online forward + frozen target
-    forward + L1 + EMA + backward + fused clip / AdamW.  Diagnostic line, same barrier protocol."""
-    import torch.distributed as dist
+def vjepa_leg(device, world, rank, steps, warmup):
+    """BASELINE.json config 4 (ViT-base encoder + default predictor, 512x512x320, B = 1, 3 mask blocks): online forward + frozen target
+    forward + L1 + EMA + backward + fused clip / AdamW.  Returns (seconds for `steps` steps, final loss, info)."""
     from transformers import VJEPA2Config
     from smb_vision_amd.masking import VJEPAMaskGenerator
     from smb_vision_amd.modeling_vjepa import MomentumEncoder, SmbVJEPA2Model, make_target_encoder, vjepa_loss
@@ -246,9 +276,18 @@ def run_vjepa(args, device, world, rank):
         opt.zero_grad(set_to_none=True)
         return loss
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         loss = step()
-    dt = timed_region(step, args.steps, world, device)
+    dt = timed_region(step, steps, world, device)
+    info = dict(tokens=model.num_patches, context=int(cm.shape[1]), target=int(tm.shape[1]), final_loss=float(loss.detach()))
+    del model, target, ema, opt
+    torch.cuda.empty_cache()
+    return dt, info
+
+
+def run_vjepa(args, device, world, rank):
+    """--vjepa: the config-4 leg as the bench's only line (diagnostic), same barrier protocol."""
+    dt, info = vjepa_leg(device, world, rank, args.steps, args.warmup)
     if rank == 0:
         ms = dt / args.steps * 1e3
         tf = world * VJEPA_STEP_TFLOP / (ms * 1e-3)
@@ -256,10 +295,33 @@ def run_vjepa(args, device, world, rank):
                           "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                           "config": {"workload": "V-JEPA ViT-base encoder (12L/768) + predictor (12L/384, 12 heads x 32), 512x512x320, B=1/GPU, 3 mask blocks: online fwd + "
-                                                 "target fwd + L1 + EMA + bwd + clip + AdamW", "tokens": model.num_patches, "context": int(cm.shape[1]), "target": int(tm.shape[1]),
-                                     "parallelism": f"dp{world}", "final_loss": float(loss.detach())},
+                                                 "target fwd + L1 + EMA + bwd + clip + AdamW", "tokens": info["tokens"], "context": info["context"], "target": info["target"],
+                                     "parallelism": f"dp{world}", "final_loss": info["final_loss"]},
                           "roofline": {"bound": "mfma", "kernel": "whole step (per GPU)", "achieved": tf / world, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                        "frac": tf / world / MFMA_PEAK_TFLOPS, "traffic": None, "flop_per_volume_T": VJEPA_STEP_TFLOP}}), flush=True)
+
+
+def vit_large_leg(device, steps=4, warmup=2):
+    """BASELINE.json config 5's model on one GPU: ViT-large MIM (encoder 1024/24L/16H/4096, decoder 512/12L/8H/2048), fp8 attention forward + per-layer
+    recompute; fwd + loss + bwd + clip + AdamW.  Returns ms per step."""
+    from smb_vision_amd.optim import SmbvAdamW
+    kw = dict(VIT_BASE, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, decoder_hidden_size=512,
+              decoder_num_hidden_layers=12, decoder_num_attention_heads=8, decoder_intermediate_size=2048, smbv_attention_fp8=True, smbv_recompute="always")
+    model, pix, mask, _ = build(0, device, kw)
+    model.gradient_checkpointing_enable()
+    opt = SmbvAdamW(list(model.parameters()), lr=1.5e-4, betas=(0.9, 0.95), weight_decay=0.05, max_grad_norm=1.0)
+
+    def step():
+        model(pixel_values=pix, bool_masked_pos=mask).loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+
+    for _ in range(warmup):
+        step()
+    dt = timed_region(step, steps, 1, device)
+    del model, opt
+    torch.cuda.empty_cache()
+    return dt / steps * 1e3
 
 
 def timed_region(step, steps, world, device):
@@ -291,6 +353,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--no-feed", action="store_true", help="skip the second timed region (new volume + mask per step through the VolumeFeeder)")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip config.vjepa_ms_per_step / config.vit_large_fp8_recompute_ms_per_step")
+    ap.add_argument("--no-reference-class", action="store_true", help="skip cpu_baseline.reference_class (transformers.VideoMAEForPreTraining on the host cores)")
     ap.add_argument("--no-trainer", action="store_true", help="skip config.trainer_ms_per_step (the HF-Trainer harness at full size)")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward only (diagnostic; not the metric)")
     ap.add_argument("--torch-optimizer", action="store_true", help="clip_grad_norm_ + torch fused AdamW instead of the fused HIP optimizer tail")
@@ -388,7 +452,7 @@ def main():
 
     # second timed region: SURVEY.md §8(d)'s step - a NEW volume from host memory and a NEW mask every step
     fed = None
-    if world == 1 and not args.no_feed and not args.tiny:  # (a 1-GPU figure; the scaling runs time the resident step only)
+    if not args.no_feed and not args.tiny:  # (N > 1: every rank feeds its own volumes - PCIe contention shows in the scaling runs)
         from smb_vision_amd.feed import VolumeFeeder
         feeder = VolumeFeeder(_FedSource(rank, gen, cfg_kw["image_size"], cfg_kw["num_frames"]), device, cfg_kw["image_size"], cfg_kw["num_frames"])
         it = iter(feeder)
@@ -461,11 +525,32 @@ def main():
             except Exception as e:
                 line["config"]["trainer_ms_per_step"] = None
                 line["config"]["trainer_error"] = repr(e)
+        plain = not args.tiny and not args.vit_large and not args.fp8 and not args.recompute and opt is not None and not args.torch_optimizer
+        if world == 1 and plain and not args.no_extra_configs:  # BASELINE.json configs 4 and 5 on one GPU, driver-visible
+            try:
+                dtv, info = vjepa_leg(device, 1, 0, steps=5, warmup=2)
+                line["config"]["vjepa_ms_per_step"] = dtv / 5 * 1e3
+                line["config"]["vjepa"] = dict(info, tflop_per_step=VJEPA_STEP_TFLOP, frac_of_mfma_peak=VJEPA_STEP_TFLOP / (dtv / 5) / MFMA_PEAK_TFLOPS,
+                                               what="BASELINE.json config 4: V-JEPA ViT-base encoder + predictor, 512x512x320, B=1, 3 mask blocks")
+            except Exception as e:
+                line["config"]["vjepa_ms_per_step"], line["config"]["vjepa_error"] = None, repr(e)
+            try:
+                msl = vit_large_leg(device)
+                line["config"]["vit_large_fp8_recompute_ms_per_step"] = msl
+                line["config"]["vit_large"] = dict(tflop_per_step=64.41, frac_of_mfma_peak_excl_recompute=64.41 / (msl * 1e-3) / MFMA_PEAK_TFLOPS,
+                                                   what="BASELINE.json config 5's model on one GPU: ViT-large MIM, fp8 e4m3 attention forward + per-layer recompute")
+            except Exception as e:
+                line["config"]["vit_large_fp8_recompute_ms_per_step"], line["config"]["vit_large_error"] = None, repr(e)
         if world == 1 and not args.no_cpu_baseline and not args.tiny:
             try:
                 line["cpu_baseline"] = cpu_baseline(cpu_threads())
             except Exception as e:  # the baseline leg must never take the bench line down
                 line["cpu_baseline"] = {"error": repr(e)}
+            if "error" not in line["cpu_baseline"] and not args.no_reference_class:
+                try:
+                    line["cpu_baseline"]["reference_class"] = reference_class_baseline(cpu_threads())
+                except Exception as e:
+                    line["cpu_baseline"]["reference_class"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

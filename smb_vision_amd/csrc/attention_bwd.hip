@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO,
                                                            int ldo, const float* __restrict__ LSE, const float* __restrict__ delta,
                                                            bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int ldd, int S, int Sq, int qoff,
-                                                           int H, float scale) {
+                                                           int H, float scale, int xcd_order) {
   static_assert(QT == 128, "the mid-iteration hand-over is written for 4 sub-tiles");
   static_assert(DH == 64 || DH == 32, "head widths with a native build");
   constexpr int NS = QT / 32;
@@ -118,9 +118,10 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int r = l & 31, h2 = l >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
+  int tile_x = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  if (xcd_order) xcd_block_order((S + 127) / 128, H, tile_x, head, b);
   const size_t row0 = (size_t)b * S;
-  const int key = blockIdx.x * 128 + w * 32 + r;
+  const int key = tile_x * 128 + w * 32 + r;
   const int hoff = head * DH;
   const float c = scale * 1.4426950408889634f;
   const float* lse_p = LSE + ((size_t)b * H + head) * Sq;
@@ -349,7 +350,7 @@ template <int KT, int DH>
 __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                           const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO, int ldo,
                                                           const float* __restrict__ LSE, const float* __restrict__ delta,
-                                                          bf16_t* __restrict__ dQ, int ldd, int S, int Sq, int qoff, int H, float scale) {
+                                                          bf16_t* __restrict__ dQ, int ldd, int S, int Sq, int qoff, int H, float scale, int xcd_order) {
   static_assert(KT == 128, "bodies are unrolled for 4 sub-tiles per tile");
   static_assert(DH == 64 || DH == 32, "head widths with a native build");
   constexpr int KS = DH / 16, DT = DH / 32, RB = 2 * DH;  // QK^T-type k-steps, 32-channel output tiles, LDS row bytes
@@ -358,9 +359,10 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int r = l & 31, h2 = l >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
+  int tile_x = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  if (xcd_order) xcd_block_order((Sq + 127) / 128, H, tile_x, head, b);
   const size_t row0 = (size_t)b * S;
-  const int q = blockIdx.x * 128 + w * 32 + r;
+  const int q = tile_x * 128 + w * 32 + r;
   const int hoff = head * DH;
   const float c = scale * 1.4426950408889634f;
 
@@ -563,15 +565,18 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     ForkJoin* fj; hipStream_t st;
     ~Join() { if (fj) stream_edge(fj, fj->join, fj->side, st); }
   } join{fj, st};
+  const int xo = (g_variant & (1 << 24)) ? 1 : 0;  // A/B: XCD-aware block order (smbv_common.h xcd_block_order)
+  const dim3 gkv = xo ? dim3(cdiv(S, 128) * H * B) : dim3(cdiv(S, 128), H, B);
+  const dim3 gq = xo ? dim3(cdiv(Sq, 128) * H * B) : dim3(cdiv(Sq, 128), H, B);
   if (parts & 2) {
-    if (Dh == 64) hipLaunchKernelGGL((attn_dkv2_kernel<128, 64>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale);
-    else hipLaunchKernelGGL((attn_dkv2_kernel<128, 32>), dim3(cdiv(S, 128), H, B), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale);
+    if (Dh == 64) hipLaunchKernelGGL((attn_dkv2_kernel<128, 64>), gkv, dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale, xo);
+    else hipLaunchKernelGGL((attn_dkv2_kernel<128, 32>), gkv, dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale, xo);
     rc = check_launch("attn_dkv");
     if (rc) return rc;
   }
   if (parts & 4) {
-    if (Dh == 64) hipLaunchKernelGGL((attn_dq2_kernel<128, 64>), dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale);
-    else hipLaunchKernelGGL((attn_dq2_kernel<128, 32>), dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale);
+    if (Dh == 64) hipLaunchKernelGGL((attn_dq2_kernel<128, 64>), gq, dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, xo);
+    else hipLaunchKernelGGL((attn_dq2_kernel<128, 32>), gq, dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, xo);
     rc = check_launch("attn_dq");
   }
   return rc;  // ~Join: `st` waits for the dQ kernel

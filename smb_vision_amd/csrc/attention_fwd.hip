@@ -66,7 +66,7 @@ __device__ __forceinline__ bf16x8 scale_bf16x8(u32x4 v, float c) {
 // the V image needs no swizzle at all (the 4 keys x 2 column halves x 4 sub-columns of a tr-read group already tile the 64 banks).
 template <int DH>
 __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, int ld,
-                                                           bf16_t* __restrict__ O, int ldo, float* __restrict__ LSE, int S, int Sq, int qoff, int H, float scale, int guarded_only) {
+                                                           bf16_t* __restrict__ O, int ldo, float* __restrict__ LSE, int S, int Sq, int qoff, int H, float scale, int guarded_only, int xcd_order) {
   static_assert(DH == 64 || DH == 32, "head widths with a native build");
   constexpr int KS = DH / 16, DT = DH / 32, RB = 2 * DH;  // QK^T k-steps, 32-channel output tiles, LDS row bytes
   constexpr int IMG = 64 * RB, SLOT = 2 * IMG;           // K image | V image
@@ -75,9 +75,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restr
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int r = l & 31, h2 = l >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
+  int tile_x = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  if (xcd_order) xcd_block_order((Sq + 127) / 128, H, tile_x, head, b);
   const size_t row0 = (size_t)b * S;
-  const int q = blockIdx.x * 128 + w * 32 + r;
+  const int q = tile_x * 128 + w * 32 + r;
   const int hoff = head * DH;
   const float c = scale * 1.4426950408889634f;
 
@@ -283,8 +284,10 @@ int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf1
   if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 3)) { set_error("attention_fwd: bad shape B=%d S=%d H=%d ld=%d ldo=%d", B, S, H, ld, ldo); return SMBV_ERR_SHAPE; }
   if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || ((uintptr_t)O & 7)) { set_error("attention_fwd: alignment"); return SMBV_ERR_ALIGN; }
   if ((size_t)(S + 512) * ld * 2 >= (1ull << 31)) { set_error("attention_fwd: one sequence spans %zu bytes of the QKV matrix; the LDS-DMA offsets are 32-bit", (size_t)S * ld * 2); return SMBV_ERR_SHAPE; }
-  if (Dh == 64) hipLaunchKernelGGL(attn_fwd3_kernel<64>, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale, (g_variant & 2048) ? 1 : 0);
-  else hipLaunchKernelGGL(attn_fwd3_kernel<32>, dim3(cdiv(Sq, 128), H, B), dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale, (g_variant & 2048) ? 1 : 0);
+  const int xo = (g_variant & (1 << 24)) ? 1 : 0;  // A/B: XCD-aware block order (smbv_common.h xcd_block_order)
+  const dim3 grid = xo ? dim3(cdiv(Sq, 128) * H * B) : dim3(cdiv(Sq, 128), H, B);
+  if (Dh == 64) hipLaunchKernelGGL(attn_fwd3_kernel<64>, grid, dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale, (g_variant & 2048) ? 1 : 0, xo);
+  else hipLaunchKernelGGL(attn_fwd3_kernel<32>, grid, dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale, (g_variant & 2048) ? 1 : 0, xo);
   return check_launch("attention_fwd");
 }
 

@@ -118,6 +118,19 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + er) + x * 0.3989422804014327f * e2;
 }
 
+// XCD-aware block order for grids whose blocks share an operand stream per (batch, head): the dispatcher deals consecutive block ids round-robin
+// over the 8 XCDs (MI355X guide, T1), so with blockIdx.x = tile every XCD's private L2 ends up fetching EVERY head's stream.  With nt tiles per head
+// and a 1-D grid of nt * heads * batch blocks, this bijection hands each XCD a contiguous run of (batch, head, tile) triples instead: the blocks that
+// are co-resident on one XCD sweep the same head's stream, which its L2 then fetches once.  Speed only - any placement gives the same results.
+__device__ __forceinline__ void xcd_block_order(int nt, int heads, int& tile, int& head, int& b) {
+  const int n = gridDim.x, id = blockIdx.x;
+  const int q8 = n >> 3, r8 = n & 7, xcd = id & 7, slot = id >> 3;
+  const int g = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  tile = g % nt;
+  head = (g / nt) % heads;
+  b = g / (nt * heads);
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace smbv

@@ -43,10 +43,11 @@ def merge_ranges(ranges: Sequence[Tuple[int, int]], bucket_elems: int) -> List[T
     return out
 
 
-def allreduce_mean_(flat: torch.Tensor, group=None):
-    """In-place mean over ranks (AVG where the backend has it, SUM + scale otherwise, e.g. gloo on CPU)."""
+def allreduce_mean_(flat: torch.Tensor, group=None, force: bool = False):
+    """In-place mean over ranks (AVG where the backend has it, SUM + scale otherwise, e.g. gloo on CPU).  ``force``: issue the collective at world
+    size 1 too (an identity; what lets a one-GPU box execute the RCCL code path, tests/test_accum_dp_gpu.py)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return None
     if flat.is_cuda and "nccl" in str(dist.get_backend(group)).lower():  # RCCL: averaging collective, asynchronous on its own stream
         return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group, async_op=True)
@@ -56,13 +57,14 @@ def allreduce_mean_(flat: torch.Tensor, group=None):
 
 
 class DataParallelEngine:
-    def __init__(self, model, group=None, bucket_bytes: int = 32 << 20, overlap: bool = True):
+    def __init__(self, model, group=None, bucket_bytes: int = 32 << 20, overlap: bool = True, force_collectives: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("DataParallelEngine needs torch.distributed to be initialised (one process per GPU)")
         self.group = group
         self.world = dist.get_world_size(group)
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.overlap = overlap
+        self.force_collectives = force_collectives  # run every bucket's collective even at world size 1 (the averaging all-reduce is then an identity)
         self.comm_stream: Optional[torch.cuda.Stream] = None
         self._events: List[torch.cuda.Event] = []
         self._ev_array = None
@@ -110,10 +112,11 @@ class DataParallelEngine:
         flat = model.flat_grads()
         if self._buckets is None:
             self._setup(model)
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return
+        force = self.force_collectives
         if self.comm_stream is None:  # no overlap (or CPU tensors in the gloo tests): plain bucketed all-reduce
-            works = [allreduce_mean_(flat[a:b], self.group) for a, b, _ in self._buckets]
+            works = [allreduce_mean_(flat[a:b], self.group, force) for a, b, _ in self._buckets]
             for w in works:
                 if w is not None:
                     w.wait()
@@ -123,7 +126,7 @@ class DataParallelEngine:
         with torch.cuda.stream(self.comm_stream):
             for a, b, last in self._buckets:
                 self.comm_stream.wait_event(self._events[last])
-                works.append(allreduce_mean_(flat[a:b], self.group))
+                works.append(allreduce_mean_(flat[a:b], self.group, force))
         with torch.cuda.stream(main):
             for w in works:
                 if w is not None:

@@ -19,6 +19,7 @@ produced (accelerate's ``sync_each_batch`` behaviour): mean of sums == sum of me
 """
 from __future__ import annotations
 
+import os
 import re
 
 import torch
@@ -120,9 +121,10 @@ class SmbTrainer(Trainer):
     def _prepare_for_training(self, *args, **kwargs):
         out = super()._prepare_for_training(*args, **kwargs)
         model = self.model
-        if _is_native(model) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and self.dp_engine is None:
+        force = os.environ.get("SMBV_DP_FORCE_COLLECTIVES", "0") == "1"  # keep the collective path alive at world size 1 (a one-GPU rehearsal of the RCCL path)
+        if _is_native(model) and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force) and self.dp_engine is None:
             overlap = "nccl" in str(dist.get_backend()).lower()  # the side-stream overlap needs RCCL's stream-ordered collectives
-            self.dp_engine = DataParallelEngine(model, bucket_bytes=self._dp_bucket_bytes, overlap=overlap)
+            self.dp_engine = DataParallelEngine(model, bucket_bytes=self._dp_bucket_bytes, overlap=overlap, force_collectives=force)
             self.dp_engine.broadcast_parameters(model)
         return out
 

@@ -227,3 +227,72 @@ def test_run_mim_under_a_two_process_launch_keeps_replicas_in_sync(tmp_path):
         assert torch.equal(s0["initial"][k], s1["initial"][k]), k
         moved += int(not torch.equal(s0["final"][k], s0["initial"][k]))
     assert moved > 0.9 * len(s0["final"])
+
+
+def _rccl_world1_worker(port, q, which):
+    """One rank, backend "nccl" (= RCCL): the engine's overlap path with the collectives forced on at world size 1 - per-group HIP events recorded by
+    smbv_*_backward, the communication stream waiting on them bucket by bucket, ``all_reduce(AVG, async_op=True)`` under that stream, the compute
+    stream joined before the optimizer - on the real device."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from smb_vision_amd.dp import DataParallelEngine
+        from smb_vision_amd.optim import SmbvAdamW
+        if which == "mim":
+            model = _mim_model(100)
+            pix, mask = _mim_batch(10)
+            fn = lambda: model(pixel_values=pix, bool_masked_pos=mask).loss
+        else:
+            from transformers import VJEPA2Config
+            from smb_vision_amd.modeling_vjepa import SmbVJEPA2Model
+            torch.manual_seed(0)
+            model = SmbVJEPA2Model(VJEPA2Config(**VJ_TINY)).cuda().train()
+            n = (VJ_TINY["frames_per_clip"] // VJ_TINY["tubelet_size"]) * (VJ_TINY["crop_size"] // VJ_TINY["patch_size"]) ** 2
+            g = torch.Generator().manual_seed(1)
+            pix = torch.rand(2, VJ_TINY["frames_per_clip"], 1, VJ_TINY["crop_size"], VJ_TINY["crop_size"], generator=g).cuda()
+            perm = torch.randperm(n, generator=g)
+            cm, tm = perm[: n // 2].sort().values[None].repeat(2, 1).cuda(), perm[n // 2:].sort().values[None].repeat(2, 1).cuda()
+            fn = lambda: model(pixel_values_videos=pix, context_mask=[cm], target_mask=[tm]).predictor_output.last_hidden_state.square().mean()
+        plain = _single_grads(model, fn)                                  # no engine attached
+        dp = DataParallelEngine(model, overlap=True, bucket_bytes=1 << 16, force_collectives=True)
+        dp.broadcast_parameters(model)                                     # RCCL broadcast (identity at world 1)
+        through = _single_grads(model, fn)                                 # events -> comm stream -> all_reduce(AVG, async) -> join
+        n_buckets = len(dp._buckets)
+        same = all(torch.equal(a, b) for a, b in zip(plain, through))
+        opt = SmbvAdamW(model.parameters(), lr=1e-3, max_grad_norm=1.0)
+        before = [p.detach().clone() for p in model.parameters()]
+        for _ in range(3):                                                 # three full steps: backward + collectives + optimizer, no deadlock
+            opt.zero_grad(set_to_none=True)
+            fn().backward()
+            opt.step()
+        torch.cuda.synchronize()
+        moved = sum(int(not torch.equal(a, p)) for a, p in zip(before, model.parameters()))
+        q.put(dict(same=same, n_buckets=n_buckets, overlap=dp.comm_stream is not None, n_events=len(dp._events), moved=moved, n_params=len(before),
+                   backend=str(dist.get_backend())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which", ["mim", "vjepa"])
+def test_rccl_collective_path_runs_on_hardware_at_world_size_one(which):
+    """the RCCL lines of dp.py (ReduceOp.AVG with async_op under the side stream, the event-gated bucket loop) execute on an MI355X:
+    backend "nccl" at world size 1 with DataParallelEngine(force_collectives=True).  An averaging all-reduce over one rank is the identity, so the
+    gradients must come out bit for bit as without the engine, and optimizer steps behind it must not deadlock.  (The 8-GPU curve stays the driver's.)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(_free_port(), q, which))
+    p.start()
+    try:
+        res = q.get(timeout=420)
+    finally:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    assert p.exitcode == 0
+    assert res["backend"] == "nccl" and res["overlap"] and res["n_events"] >= 4 and res["n_buckets"] >= 3, res
+    assert res["same"], "gradients changed through the world-size-1 averaging all-reduce"
+    assert res["moved"] > 0.9 * res["n_params"], res
