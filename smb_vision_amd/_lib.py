@@ -5,6 +5,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsmbv.so")
 MAX_LAYERS = 48
@@ -175,18 +177,38 @@ def load():
     return lib
 
 
-def detach_aliased_grads(params, arena):
+def detach_aliased_grads(params, arena, offsets=None, owner=None):
     """Gradient accumulation support.  A step's gradients are written into ONE persistent flat arena and handed to autograd as views of
     it; when ``p.grad`` is None autograd keeps such a view as ``p.grad`` (no copy).  If a parameter still holds that alias when the
     next backward starts (``gradient_accumulation_steps > 1`` as scripts/training/run_vjepa.sh:28 sets, or ``zero_grad(set_to_none=
-    False)``), the arena is about to be overwritten underneath it: give the parameter its own copy first, so that autograd's
-    ``p.grad += view`` afterwards is the sum the reference computes.  Costs nothing when every ``p.grad`` is None."""
+    False)``), the arena is about to be overwritten underneath it: the parameter needs its own storage first, so that autograd's
+    ``p.grad += view`` afterwards is the sum the reference computes.  Costs nothing when every ``p.grad`` is None.
+
+    With ``offsets`` / ``owner`` (the model) the private storage is ONE persistent accumulation arena kept on the model (``owner._gacc``): one
+    device copy of the whole arena and ``p.grad`` re-pointed to views of it at the same offsets.  Their addresses never change from cycle to cycle, so
+    SmbvAdamW's device-side chunk table is built once (per-parameter clones gave new pointers, and a table rebuild + upload, every step)."""
     lo = arena.data_ptr()
     hi = lo + arena.numel() * arena.element_size()
-    for p in params:
-        g = p.grad
-        if g is not None and lo <= g.data_ptr() < hi:
-            p.grad = g.clone()
+    aliased = [i for i, p in enumerate(params) if p.grad is not None and lo <= p.grad.data_ptr() < hi]
+    if not aliased:
+        return
+    if offsets is None or owner is None:
+        for i in aliased:
+            params[i].grad = params[i].grad.clone()
+        return
+    acc = getattr(owner, "_gacc", None)
+    if acc is None or acc.shape != arena.shape or acc.device != arena.device:
+        acc = torch.empty_like(arena)
+        owner._gacc = acc
+    whole = len(aliased) == len(params)  # the usual case: every parameter still holds this step's view -> one copy of the arena
+    if whole:
+        acc.copy_(arena)
+    for i in aliased:
+        p = params[i]
+        view = acc[offsets[i]:offsets[i] + p.numel()].view(p.shape)
+        if not whole:  # (some parameters already accumulate in `acc`: their slices must stay)
+            view.copy_(p.grad)
+        p.grad = view
 
 
 def last_error() -> str:

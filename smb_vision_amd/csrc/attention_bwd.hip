@@ -565,7 +565,7 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     ForkJoin* fj; hipStream_t st;
     ~Join() { if (fj) stream_edge(fj, fj->join, fj->side, st); }
   } join{fj, st};
-  const int xo = (g_variant & (1 << 24)) ? 1 : 0;  // A/B: XCD-aware block order (smbv_common.h xcd_block_order)
+  const int xo = (g_variant & (1 << 25)) ? 1 : 0;  // A/B: XCD-aware block order (smbv_common.h xcd_block_order) - measured null for the backward pair (tools/attn_ab.py 0 33554432), off
   const dim3 gkv = xo ? dim3(cdiv(S, 128) * H * B) : dim3(cdiv(S, 128), H, B);
   const dim3 gq = xo ? dim3(cdiv(Sq, 128) * H * B) : dim3(cdiv(Sq, 128), H, B);
   if (parts & 2) {

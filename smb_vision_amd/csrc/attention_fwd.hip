@@ -284,7 +284,7 @@ int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf1
   if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 3)) { set_error("attention_fwd: bad shape B=%d S=%d H=%d ld=%d ldo=%d", B, S, H, ld, ldo); return SMBV_ERR_SHAPE; }
   if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || ((uintptr_t)O & 7)) { set_error("attention_fwd: alignment"); return SMBV_ERR_ALIGN; }
   if ((size_t)(S + 512) * ld * 2 >= (1ull << 31)) { set_error("attention_fwd: one sequence spans %zu bytes of the QKV matrix; the LDS-DMA offsets are 32-bit", (size_t)S * ld * 2); return SMBV_ERR_SHAPE; }
-  const int xo = (g_variant & (1 << 24)) ? 1 : 0;  // A/B: XCD-aware block order (smbv_common.h xcd_block_order)
+  const int xo = (g_variant & (1 << 24)) ? 0 : 1;  // XCD-aware block order (smbv_common.h xcd_block_order): -1..3 % at every shape (tools/attn_ab.py); bit 24 = plain grid
   const dim3 grid = xo ? dim3(cdiv(Sq, 128) * H * B) : dim3(cdiv(Sq, 128), H, B);
   if (Dh == 64) hipLaunchKernelGGL(attn_fwd3_kernel<64>, grid, dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale, (g_variant & 2048) ? 1 : 0, xo);
   else hipLaunchKernelGGL(attn_fwd3_kernel<32>, grid, dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale, (g_variant & 2048) ? 1 : 0, xo);

@@ -755,12 +755,25 @@ static bool gemm_tn_use_256(int M, int N1, int N2) {
   return ((g_variant & 65536) ? tiles >= 1 : tiles >= 32) && tiles <= 256 && tiles * s >= 192;
 }
 
-__global__ void reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ slabs, int nslab, size_t n4, size_t slab_stride4) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+// One finishing launch per weight-gradient product: blocks [0, nb_slab) sum the token slabs (four in flight, slab order: reproducible), blocks
+// [nb_slab, ...) sum the per-slab column sums of X into the bias gradient's up to three segments (round 2 ran these as two launches per product:
+// 133 of the step's launches)
+__global__ void reduce_tn_kernel(float* __restrict__ out, const float* __restrict__ slabs, int nslab, size_t n4, size_t slab_stride4, int nb_slab,
+                                 const float* __restrict__ xpart, int N1, TnColsum dst) {
+  if ((int)blockIdx.x >= nb_slab) {
+    const int n = (blockIdx.x - nb_slab) * blockDim.x + threadIdx.x;
+    if (n >= N1) return;
+    float s = 0.f;
+    for (int z = 0; z < nslab; z++) s += xpart[(size_t)z * N1 + n];  // slab order: reproducible
+    float* d = dst.dst[n / dst.seg];
+    if (d) d[n % dst.seg] = s;
+    return;
+  }
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)nb_slab * blockDim.x) {
     const f32x4* p = (const f32x4*)slabs + i;
     f32x4 s = p[0];
     int z = 1;
-    for (; z + 3 < nslab; z += 4) {  // four slabs in flight; summed in slab order (reproducible)
+    for (; z + 3 < nslab; z += 4) {
       const f32x4 a = p[z * slab_stride4], b = p[(z + 1) * slab_stride4], c = p[(z + 2) * slab_stride4], d = p[(z + 3) * slab_stride4];
       s += a; s += b; s += c; s += d;
     }
@@ -794,16 +807,6 @@ size_t gemm_tn_workspace_bytes(int M, int N1, int N2) {
   return (s > 1 ? (((size_t)s * N1 * N2 * sizeof(float) + 255) & ~(size_t)255) : 0) + (size_t)s * N1 * sizeof(float);
 }
 
-// bias gradient: out segment k (seg columns each, up to 3 destinations, null = dropped) = sum over slabs of the column sums
-__global__ void reduce_xsum_kernel(const float* __restrict__ part, int nslab, int N1, TnColsum dst) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N1) return;
-  float s = 0.f;
-  for (int z = 0; z < nslab; z++) s += part[(size_t)z * N1 + n];  // slab order: reproducible
-  float* d = dst.dst[n / dst.seg];
-  if (d) d[n % dst.seg] = s;
-}
-
 int gemm_tn(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int M, int N1, int N2, float* out, void* ws, size_t ws_bytes, hipStream_t st,
             const TnColsum* colsum) {
   if (M <= 0 || N1 <= 0 || N2 <= 0) { set_error("gemm_tn: empty problem"); return SMBV_ERR_SHAPE; }
@@ -831,15 +834,12 @@ int gemm_tn(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int M, int N1, i
   }
   int rc = check_launch("gemm_tn");
   if (rc) return rc;
-  if (s > 1) {
+  if (s > 1 || colsum) {
     const size_t n4 = (size_t)N1 * N2 / 4;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((int)std::min<size_t>(2048, (n4 + 255) / 256)), dim3(256), 0, st, out, (const float*)ws, s, n4, n4);
-    rc = check_launch("reduce_slabs");
-    if (rc) return rc;
-  }
-  if (colsum) {
-    hipLaunchKernelGGL(reduce_xsum_kernel, dim3(cdiv(N1, 256)), dim3(256), 0, st, (const float*)xs, s, N1, *colsum);
-    rc = check_launch("reduce_xsum");
+    const int nb_slab = s > 1 ? (int)std::min<size_t>(2048, (n4 + 255) / 256) : 0, nb_x = colsum ? cdiv(N1, 256) : 0;
+    hipLaunchKernelGGL(reduce_tn_kernel, dim3(nb_slab + nb_x), dim3(256), 0, st, out, (const float*)ws, s, n4, n4, nb_slab, (const float*)xs, N1,
+                       colsum ? *colsum : TnColsum());
+    rc = check_launch("reduce_tn");
   }
   return rc;
 }

@@ -410,7 +410,7 @@ class SmbVideoMAEForPreTraining(PreTrainedModel):
         if st["step"] != self._fwd_count:
             raise _lib.SmbvError("smb_vision_amd: backward() after a later forward() reused the step workspace "
                                  "(one forward/backward pair at a time per model)")
-        _lib.detach_aliased_grads(self._ordered_params(), self._gflat)  # accumulation / zero_grad(set_to_none=False)
+        _lib.detach_aliased_grads(self._ordered_params(), self._gflat, self._goffs, self)  # accumulation / zero_grad(set_to_none=False)
         gscale = grad_loss.detach().to(torch.float32).reshape(1).contiguous()
         io = st["io"]
         io.grad_scale = gscale.data_ptr()

@@ -307,7 +307,7 @@ class SmbVJEPA2Model(PreTrainedModel):
         io = st["io"]
         io.d_pred = d_pred.data_ptr()
         _, ps, gs = self._structs
-        _lib.detach_aliased_grads(self._ordered_params(), self._gflat)  # accumulation / zero_grad(set_to_none=False)
+        _lib.detach_aliased_grads(self._ordered_params(), self._gflat, self._goffs, self)  # accumulation / zero_grad(set_to_none=False)
         self._gflat.zero_()  # rows of mask_tokens that were not selected keep a zero gradient
         stream = torch.cuda.current_stream().cuda_stream
         events, n_ev = None, 0

@@ -296,3 +296,27 @@ def test_rccl_collective_path_runs_on_hardware_at_world_size_one(which):
     assert res["backend"] == "nccl" and res["overlap"] and res["n_events"] >= 4 and res["n_buckets"] >= 3, res
     assert res["same"], "gradients changed through the world-size-1 averaging all-reduce"
     assert res["moved"] > 0.9 * res["n_params"], res
+
+
+def test_accumulation_keeps_gradient_addresses_and_the_optimizer_table_stable():
+    """under gradient accumulation the gradients a step hands to the optimizer live in ONE persistent accumulation arena (views at fixed
+    offsets), so SmbvAdamW builds its device-side chunk table once instead of every step."""
+    from smb_vision_amd.optim import SmbvAdamW
+    model = _mim_model(5)
+    opt = SmbvAdamW(model.parameters(), lr=1e-3, max_grad_norm=1.0)
+    builds = []
+    stock = opt._build
+    opt._build = lambda items: (builds.append(1), stock(items))[1]
+    ptrs = []
+    for step in range(3):
+        for mb in range(2):
+            pix, mask = _mim_batch(20 + 2 * step + mb)
+            (model(pixel_values=pix, bool_masked_pos=mask).loss / 2).backward()
+        ptrs.append([p.grad.data_ptr() for p in model.parameters()])
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    assert ptrs[0] == ptrs[1] == ptrs[2]
+    assert len(builds) == 1, builds
+    lo = model._gacc.data_ptr()
+    assert all(lo <= a < lo + model._gacc.numel() * 4 for a in ptrs[0])

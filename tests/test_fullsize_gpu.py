@@ -28,9 +28,10 @@ VIT_BASE = dict(image_size=512, num_frames=320, patch_size=16, tubelet_size=16, 
                 decoder_intermediate_size=1536)
 
 
-def _cmp_grads(named_grads, ref_grads, tol, cos_min, only=None):
-    worst = ("", 0.0, 1.0)
-    n_checked = 0
+def _cmp_grads(named_grads, ref_grads, tol, cos_min, only=None, label=""):
+    """Every tensor is measured before anything is asserted: a failure prints the twelve worst tensors, so that rounding noise (errors growing smoothly
+    towards the early layers) can be told from a kernel fault (one family of tensors far off)."""
+    rows = []
     for k, ref in ref_grads.items():
         if only is not None and not only(k):
             continue
@@ -42,11 +43,16 @@ def _cmp_grads(named_grads, ref_grads, tol, cos_min, only=None):
             continue
         r = float((g - ref).norm()) / n
         c = float((g.double() * ref.double()).sum() / (g.double().norm() * ref.double().norm()))
-        if r > worst[1]:
-            worst = (k, r, c)
-        assert r <= tol and c >= cos_min, (k, r, c)
-        n_checked += 1
-    return worst, n_checked
+        rows.append((r, c, k))
+    rows.sort(reverse=True)
+    bad = [x for x in rows if x[0] > tol or x[1] < cos_min]
+    if bad:
+        print(f"{label} gradient check: {len(bad)} of {len(rows)} tensors outside ({tol}, {cos_min}); worst:")
+        for r, c, k in rows[:12]:
+            print(f"   {k}: rel {r:.3e} cos {c:.6f}")
+    assert not bad, bad[:3]
+    worst = (rows[0][2], rows[0][0], rows[0][1]) if rows else ("", 0.0, 1.0)
+    return worst, len(rows)
 
 
 def test_mim_vit_base_512x512x320_step_matches_oracle():
@@ -143,6 +149,7 @@ def test_vjepa_vit_base_512x512x320_matches_oracle():
     pred = out.predictor_output.last_hidden_state.detach().cpu()
     grads = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
     loss = float(loss)
+    del out
 
     vo.SDPA = True
     try:
@@ -155,10 +162,20 @@ def test_vjepa_vit_base_512x512x320_matches_oracle():
         pred_ref = vo.predictor(leaf, cfg, enc_ref, [cm], [tm])
         tgt_ref = vo.apply_masks(enc_ref.detach(), [tm])          # target encoder == same weights, no grad
         ref_loss = torch.nn.functional.l1_loss(pred_ref, tgt_ref)
+        pred_ref.retain_grad()
         ref_loss.backward()
     finally:
         vo.SDPA = False
     ref_grads = {k: v.grad for k, v in leaf.items() if v.requires_grad and v.grad is not None}
+    # L1's upstream gradient is sign(pred - target) / n: where |pred - target| is below the bf16 noise of the forward the sign differs between the two
+    # programs, an O(1) change of that element which every upstream layer then sees.  To check the BACKWARD as the linear map it is, run it a second time
+    # with the ORACLE's upstream gradient (same weights, same forward): its gradients are compared at the tight bound, the loss-driven ones at a looser one.
+    model.zero_grad(set_to_none=True)
+    out2 = model(pixel_values_videos=inputs["pixel_values_videos"], context_mask=inputs["context_mask"], target_mask=inputs["target_mask"])
+    out2.predictor_output.last_hidden_state.backward(pred_ref.grad.to(out2.predictor_output.last_hidden_state.dtype).cuda())
+    torch.cuda.synchronize()
+    grads_lin = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
+    flips = float((torch.sign(pred - tgt_ref) != torch.sign(pred_ref.detach() - tgt_ref)).float().mean())
 
     def rms_rel(a, b):
         return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
@@ -167,8 +184,11 @@ def test_vjepa_vit_base_512x512x320_matches_oracle():
     assert e_rms <= 1.5e-2 and p_rms <= 1.5e-2, (e_rms, p_rms)
     assert abs(loss - float(ref_loss)) <= 5e-3 * float(ref_loss), (loss, float(ref_loss))
     # the selected mask-token row only; key biases are cancellation-dominated (tests/test_vjepa_gpu.py)
-    worst, n = _cmp_grads(grads, ref_grads, 5e-2, 0.998, only=lambda k: not k.endswith("attention.key.bias"))
-    kb, _ = _cmp_grads(grads, ref_grads, 2e-1, 0.97, only=lambda k: k.endswith("attention.key.bias"))
+    notkb = lambda k: not k.endswith("attention.key.bias")
+    worst, n = _cmp_grads(grads_lin, ref_grads, 5e-2, 0.998, only=notkb, label="V-JEPA (oracle's upstream gradient)")
+    kb, _ = _cmp_grads(grads_lin, ref_grads, 2e-1, 0.97, only=lambda k: k.endswith("attention.key.bias"), label="V-JEPA key biases")
+    worst_loss, _ = _cmp_grads(grads, ref_grads, 1.2e-1, 0.99, only=notkb, label="V-JEPA (own L1 sign pattern)")
+    print(f"full-size V-JEPA: sign(pred - target) differs on {flips:.2%} of the elements; loss-driven gradients worst {worst_loss}")
     assert n >= 360                                  # 15 tensors x (12 predictor + 12 encoder layers) + embeddings / norms / head (key biases: below)
     missing = [k for k, _ in model.named_parameters() if k not in ref_grads and k != "predictor.embeddings.mask_tokens"]
     assert not missing, missing
