@@ -53,7 +53,8 @@ int smbv_last_error(char* buf, size_t len);               /* copies the thread's
  * arithmetic (process-wide, not thread-safe; 0 = the shipped selection).  Bits: 32 register-staged GEMMs; 256 first-generation 128x128 NT
  * GEMM everywhere / 131072 second-generation ring NT GEMM everywhere (default: by shape); 512 four-slot ring; 262144 ring with 64-deep K slices; 1024 no mixed-tile NT launches (all tiles 128 x 128); 2048 attention forward with the guarded sweep only (no optimistic first sweep); 8192 attention dQ and dK/dV on
  * one stream; 16384 weight- and input-gradient GEMMs on one stream; 32768 / 65536 TN tile selection; bits 20-23 GEMM ablation (timing only); 1<<24 attention forward on the plain (tile, head, batch) grid instead of the
- * XCD-aware block order; 1<<25 attention backward kernels on the XCD-aware block order. */
+ * XCD-aware block order; 1<<25 attention backward kernels on the XCD-aware block order; bits 26-28 start-up stagger
+ * units of the attention kernels (forward default 2, backward 0), 1<<29 no stagger. */
 void smbv_debug_set_variant(int bits);
 
 /* ---- per-op entry points (also what the parity tests call) ------------------------------------------------------ */
@@ -288,6 +289,12 @@ typedef struct smbv_vjepa_cfg {
   int n_masks;                     /* number of (context, target) mask pairs in the lists handed to VJEPA2Model.forward (0 or 1 = one pair).  apply_masks
                                       (modeling_vjepa.py:542-556) concatenates them along the batch: the predictor runs on P = n_masks * B sequences, sequence
                                       m * B + b pairing volume b with mask pair m; every per-sequence array below then has P rows instead of B */
+  int enc_needed;                  /* 0 or N: the encoder's output is produced for every token (the reference's forward).  0 < enc_needed < N: the caller has
+                                      ordered every volume's tokens (all_idx / enc_pos) so that the ones whose encoder OUTPUT it consumes come first - the
+                                      context tokens for the online model, the target tokens for the frozen target encoder (run_vjepa.py:118-131 reads nothing
+                                      else) - and the LAST encoder block computes queries, projection and MLP for those enc_needed rows only (keys / values: all
+                                      N tokens; exact for the rows produced, as the last MIM decoder block).  enc_out and the rows ctx_idx names are then
+                                      COMPACT: [B * enc_needed, d], row b * enc_needed + j.  Needs n_masks <= 1 */
 } smbv_vjepa_cfg;
 
 /* fp32 tensors of one VJEPA2Layer: norm1, attention.{query,key,value,proj}.{weight,bias}, norm2, mlp.{fc1,fc2} */
@@ -308,7 +315,7 @@ typedef struct smbv_vjepa_tensors {
 
 typedef struct smbv_vjepa_io {
   const float* pixel_values;       /* fp32 [B,T,1,H,W] */
-  const int32_t* all_idx;          /* int32 [B,N] = 0..N-1 per volume (brick ids) */
+  const int32_t* all_idx;          /* int32 [B,N] brick (token) id of every encoder row: 0..N-1 per volume in the natural order, any permutation of it otherwise */
   const int32_t* ctx_idx;          /* int32 [P,Nctx] ROW of enc_out ([B*N] rows) each context token comes from: b * N + token id; distinct within a sequence */
   const int32_t* tgt_idx;          /* int32 [P,Ntgt] target token ids (not read by the library: the caller's target_hidden_state gather uses them) */
   const int32_t* pred_pos;         /* int32 [P,Nctx+Ntgt] position ids of the predictor sequence, sorted (modeling_vjepa.py:718-719) */
@@ -319,6 +326,8 @@ typedef struct smbv_vjepa_io {
   float* enc_out;                  /* out: fp32 [B*N, d] last_hidden_state (after encoder.layernorm) */
   float* pred_out;                 /* out: fp32 [P*Ntgt, d] predictor_output.last_hidden_state (NULL: encoder only = skip_predictor) */
   const float* d_pred;             /* backward: fp32 [P*Ntgt, d] gradient w.r.t. pred_out */
+  const int32_t* enc_pos;          /* int32 [B,N] RoPE position id of every encoder row, or NULL = row index within the volume (the natural order).  With a
+                                      permuted token order (enc_needed) this is all_idx: attention is permutation-equivariant once RoPE takes explicit ids */
 } smbv_vjepa_io;
 
 size_t smbv_vjepa_workspace_bytes(const smbv_vjepa_cfg* cfg);

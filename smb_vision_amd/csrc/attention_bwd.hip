@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int r = l & 31, h2 = l >> 5;
   int tile_x = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
-  if (xcd_order) xcd_block_order((S + 127) / 128, H, tile_x, head, b);
+  stagger_by_wave_slot((xcd_order >> 8) & 0xff);
+  if (xcd_order & 1) xcd_block_order((S + 127) / 128, H, tile_x, head, b);
   const size_t row0 = (size_t)b * S;
   const int key = tile_x * 128 + w * 32 + r;
   const int hoff = head * DH;
@@ -360,7 +361,8 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int r = l & 31, h2 = l >> 5;
   int tile_x = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
-  if (xcd_order) xcd_block_order((Sq + 127) / 128, H, tile_x, head, b);
+  stagger_by_wave_slot((xcd_order >> 8) & 0xff);
+  if (xcd_order & 1) xcd_block_order((Sq + 127) / 128, H, tile_x, head, b);
   const size_t row0 = (size_t)b * S;
   const int q = tile_x * 128 + w * 32 + r;
   const int hoff = head * DH;
@@ -565,9 +567,10 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     ForkJoin* fj; hipStream_t st;
     ~Join() { if (fj) stream_edge(fj, fj->join, fj->side, st); }
   } join{fj, st};
-  const int xo = (g_variant & (1 << 25)) ? 1 : 0;  // A/B: XCD-aware block order (smbv_common.h xcd_block_order) - measured null for the backward pair (tools/attn_ab.py 0 33554432), off
-  const dim3 gkv = xo ? dim3(cdiv(S, 128) * H * B) : dim3(cdiv(S, 128), H, B);
-  const dim3 gq = xo ? dim3(cdiv(Sq, 128) * H * B) : dim3(cdiv(Sq, 128), H, B);
+  const int xo = ((g_variant & (1 << 25)) ? 1 : 0) | (((g_variant >> 26) & 7) << 8);  // bits 26-28: start-up stagger units (A/B)
+  const bool xgrid = xo & 1;  // A/B: XCD-aware block order (smbv_common.h xcd_block_order) - measured null for the backward pair (tools/attn_ab.py 0 33554432), off
+  const dim3 gkv = xgrid ? dim3(cdiv(S, 128) * H * B) : dim3(cdiv(S, 128), H, B);
+  const dim3 gq = xgrid ? dim3(cdiv(Sq, 128) * H * B) : dim3(cdiv(Sq, 128), H, B);
   if (parts & 2) {
     if (Dh == 64) hipLaunchKernelGGL((attn_dkv2_kernel<128, 64>), gkv, dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale, xo);
     else hipLaunchKernelGGL((attn_dkv2_kernel<128, 32>), gkv, dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale, xo);

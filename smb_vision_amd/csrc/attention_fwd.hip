@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restr
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int r = l & 31, h2 = l >> 5;
   int tile_x = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
-  if (xcd_order) xcd_block_order((Sq + 127) / 128, H, tile_x, head, b);
+  stagger_by_wave_slot((xcd_order >> 8) & 0xff);
+  if (xcd_order & 1) xcd_block_order((Sq + 127) / 128, H, tile_x, head, b);
   const size_t row0 = (size_t)b * S;
   const int q = tile_x * 128 + w * 32 + r;
   const int hoff = head * DH;
@@ -284,8 +285,12 @@ int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf1
   if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 3)) { set_error("attention_fwd: bad shape B=%d S=%d H=%d ld=%d ldo=%d", B, S, H, ld, ldo); return SMBV_ERR_SHAPE; }
   if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || ((uintptr_t)O & 7)) { set_error("attention_fwd: alignment"); return SMBV_ERR_ALIGN; }
   if ((size_t)(S + 512) * ld * 2 >= (1ull << 31)) { set_error("attention_fwd: one sequence spans %zu bytes of the QKV matrix; the LDS-DMA offsets are 32-bit", (size_t)S * ld * 2); return SMBV_ERR_SHAPE; }
-  const int xo = (g_variant & (1 << 24)) ? 0 : 1;  // XCD-aware block order (smbv_common.h xcd_block_order): -1..3 % at every shape (tools/attn_ab.py); bit 24 = plain grid
-  const dim3 grid = xo ? dim3(cdiv(Sq, 128) * H * B) : dim3(cdiv(Sq, 128), H, B);
+  // start-up stagger by SIMD wave slot (smbv_common.h): 2 x 512 clocks per slot; -1 % (head_dim 64) .. -3 % (head_dim 32) for the forward, null for the backward
+  // kernels (profiles/r03_attn_stagger_ab.txt); bits 26-28 override the units, bit 29 switches it off
+  const int stag = (g_variant & (1 << 29)) ? 0 : (((g_variant >> 26) & 7) ? ((g_variant >> 26) & 7) : 2);
+  const int xo = ((g_variant & (1 << 24)) ? 0 : 1) | (stag << 8);
+  const bool xgrid = xo & 1;  // XCD-aware block order (smbv_common.h xcd_block_order): -1..3 % at every shape (tools/attn_ab.py); bit 24 = plain grid
+  const dim3 grid = xgrid ? dim3(cdiv(Sq, 128) * H * B) : dim3(cdiv(Sq, 128), H, B);
   if (Dh == 64) hipLaunchKernelGGL(attn_fwd3_kernel<64>, grid, dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale, (g_variant & 2048) ? 1 : 0, xo);
   else hipLaunchKernelGGL(attn_fwd3_kernel<32>, grid, dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale, (g_variant & 2048) ? 1 : 0, xo);
   return check_launch("attention_fwd");

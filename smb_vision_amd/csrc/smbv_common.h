@@ -131,6 +131,15 @@ __device__ __forceinline__ void xcd_block_order(int nt, int heads, int& tile, in
   b = g / (nt * heads);
 }
 
+// A/B experiment (MI355X guide, 'Two waves per SIMD' item 9): blocks that share a CU start together and run the same program, i.e. their waves reach
+// their matrix chains, their LDS bursts and their VALU blocks in lockstep.  Waves in SIMD wave slot k (HW_ID bits 3:0) sleep k * units * 512 clocks
+// once at kernel entry; the block's waves sit in the same slot of four SIMDs, so a block is delayed as a whole.
+__device__ __forceinline__ void stagger_by_wave_slot(int units) {
+  if (units <= 0) return;
+  const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 7;  // HW_REG_HW_ID[3:0]
+  for (unsigned i = 0; i < slot * (unsigned)units; i++) __builtin_amdgcn_s_sleep(8);
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace smbv

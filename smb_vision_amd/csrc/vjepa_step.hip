@@ -29,10 +29,12 @@ struct VjepaWs {
 
 static BlockDims venc_dims(const smbv_vjepa_cfg& c, const smbv_vjepa_io* io) {
   BlockDims d; d.rows = (size_t)c.B * c.N; d.w = c.d; d.ff = c.ff; d.B = c.B; d.S = c.N; d.H = c.heads; d.Dh = c.d / c.heads; d.eps = c.ln_eps;
-  d.rope_grid = c.W / c.ps; d.pos = nullptr; d.rope_table = io ? io->rope_enc : nullptr;
+  d.rope_grid = c.W / c.ps; d.pos = io ? io->enc_pos : nullptr; d.rope_table = io ? io->rope_enc : nullptr;
   return d;
 }
 static inline int vmasks(const smbv_vjepa_cfg& c) { return c.n_masks > 1 ? c.n_masks : 1; }
+// rows of every volume whose last-block output is produced (0 = all: the last block is not ranged)
+static inline int vneed(const smbv_vjepa_cfg& c) { return (c.enc_needed > 0 && c.enc_needed < c.N) ? c.enc_needed : 0; }
 static inline int vpb(const smbv_vjepa_cfg& c) { return c.B * vmasks(c); }  // predictor sequences: mask pair m, volume b -> m * B + b
 static BlockDims vpred_dims(const smbv_vjepa_cfg& c, const smbv_vjepa_io* io) {
   const int Sp = c.Nctx + c.Ntgt;
@@ -50,6 +52,7 @@ static BlockPtrs vblock(const smbv_block_ptrs& p) {
 static int vcheck(const smbv_vjepa_cfg& c) {
   if (c.struct_bytes != (int)sizeof(smbv_vjepa_cfg)) { set_error("vjepa: cfg.struct_bytes = %d, this library's smbv_vjepa_cfg is %d bytes (binding built against another ABI: check smbv_version())", c.struct_bytes, (int)sizeof(smbv_vjepa_cfg)); return SMBV_ERR_ARG; }
   if (c.n_masks < 0 || c.n_masks > 64) { set_error("vjepa: n_masks %d out of range", c.n_masks); return SMBV_ERR_SHAPE; }
+  if (c.enc_needed < 0 || c.enc_needed > c.N || (c.enc_needed > 0 && c.enc_needed < c.N && c.n_masks > 1)) { set_error("vjepa: enc_needed %d out of range (0..N; with one mask pair only)", c.enc_needed); return SMBV_ERR_SHAPE; }
   if (c.B <= 0 || c.layers <= 0 || c.players < 0 || c.layers > SMBV_MAX_LAYERS || c.players > SMBV_MAX_LAYERS) { set_error("vjepa: bad batch/layer counts"); return SMBV_ERR_SHAPE; }
   if (c.ps <= 0 || c.ts <= 0 || c.T % c.ts || c.H % c.ps || c.W % c.ps || (c.ps & 3) || c.H != c.W) { set_error("vjepa: volume %dx%dx%d vs tubelet %d / patch %d (square crops only)", c.T, c.H, c.W, c.ts, c.ps); return SMBV_ERR_SHAPE; }
   const int N = (c.T / c.ts) * (c.H / c.ps) * (c.W / c.ps);
@@ -99,12 +102,21 @@ static void vcarve(const smbv_vjepa_cfg& c, void* base, VjepaWs& w) {
   BwdNeeds nd;
   bwd_scratch_requirements(de, nd);
   bwd_scratch_requirements(dp, nd);
+  if (vneed(c)) {  // the ranged last block runs its MLP / projection products on B * enc_needed rows: their slab counts differ from the full-size ones
+    BlockDims dr = de;
+    dr.rows = (size_t)c.B * vneed(c);
+    bwd_scratch_requirements(dr, nd);
+  }
   auto tn = [&](size_t M, int n1, int n2) { nd.scratch = std::max(nd.scratch, gemm_tn_workspace_bytes((int)M, n1, n2)); };
   tn(Re, c.d, K); tn(Rc, c.pd, c.d); tn(Rt, c.d, c.pd);
   nd.scratch = std::max(nd.scratch, colsum_workspace_bytes((int)std::max(Re, Rp), std::max(std::max(c.d, c.pd), K)));
   carve_bwd_scratch(cv, w.sc, nd);
   w.sc.gath0 = nullptr;
   w.sc.gath1 = nullptr;
+  if (vneed(c) && c.B > 1) {  // gathered copies of the ranged rows (block.hip: contiguous without them only for B == 1)
+    w.sc.gath0 = cv.take<bf16_t>((size_t)c.B * vneed(c) * c.d);
+    w.sc.gath1 = cv.take<bf16_t>((size_t)c.B * vneed(c) * c.d);
+  }
   w.total = (cv.off + 255) & ~(size_t)255;
 }
 
@@ -149,12 +161,17 @@ static int vjepa_forward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, c
     GemmEpi e; e.bias = p.pe_b; e.out_f32 = W.x[0]; e.ld_of = c.d;
     RC(gemm_nt(W.a_patch, K, W.pe_w, K, (int)Re, c.d, K, e, st));
   }
+  // enc_needed: the caller put the tokens whose encoder output it consumes first; the last block then works on those queries only and the final
+  // LayerNorm / enc_out / W.enc_ln are compact [B * need, d]
+  const int need = vneed(c);
+  if (need && de.padded()) { set_error("vjepa_forward: enc_needed with head-padded encoder widths is not supported"); return SMBV_ERR_SHAPE; }
   for (int l = 0; l < c.layers; l++) {
     if (l == prep_join_layer) RC(prep_side.end(st));
-    RC(layer_fwd(vblock(p.enc[l]), W.enc[l], de, W.sc, W.x[l], W.x[l + 1], nullptr, 0, 0, st));
+    RC(layer_fwd(vblock(p.enc[l]), W.enc[l], de, W.sc, W.x[l], W.x[l + 1], nullptr, l == c.layers - 1 ? need : 0, 0, st));
   }
   if (prep_join_layer >= c.layers) RC(prep_side.end(st));
-  RC(layernorm_fwd(W.x[c.layers], p.enc_ln_w, p.enc_ln_b, W.enc_ln, W.enc_mean, W.enc_rstd, (int)Re, c.d, c.ln_eps, 0, 0, 0, st, io.enc_out));
+  if (need) RC(layernorm_fwd(W.x[c.layers], p.enc_ln_w, p.enc_ln_b, W.enc_ln, W.enc_mean, W.enc_rstd, c.B * need, c.d, c.ln_eps, need, c.N, 0, st, io.enc_out));
+  else RC(layernorm_fwd(W.x[c.layers], p.enc_ln_w, p.enc_ln_b, W.enc_ln, W.enc_mean, W.enc_rstd, (int)Re, c.d, c.ln_eps, 0, 0, 0, st, io.enc_out));
   if (!with_pred) return SMBV_OK;
   // predictor: context rows -> Linear(d -> pd) -> their slots of the position-sorted sequence; target slots <- mask token
   RC(gather_rows_idx_bf16(W.enc_ln, W.ctx_bf, io.ctx_idx, (long)Rc, (int)Rc, 0, c.d, st));  // ctx_idx holds absolute rows of enc_out
@@ -236,11 +253,14 @@ static int vjepa_backward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, 
     RC(scatter_rows_idx_bf16(W.d_encctx, W.d_lnfull, io.ctx_idx, per, (int)per, 0, c.d, st));
     for (int m = 1; m < vmasks(c); m++) RC(scatter_add_rows_idx_bf16(W.d_encctx + (size_t)m * per * c.d, W.d_lnfull, io.ctx_idx + (size_t)m * per, per, c.d, st));
   }
-  RC(layernorm_bwd(W.d_lnfull, W.x[c.layers], W.enc_mean, W.enc_rstd, p.enc_ln_w, nullptr, W.g0, W.gb0, gr.enc_ln_w, gr.enc_ln_b, (int)Re, c.d, 0, 0, 0,
-                   W.sc.scratch, W.sc.scratch_bytes, st));
+  const int need = vneed(c);
+  if (need) RC(layernorm_bwd(W.d_lnfull, W.x[c.layers], W.enc_mean, W.enc_rstd, p.enc_ln_w, nullptr, W.g0, W.gb0, gr.enc_ln_w, gr.enc_ln_b, c.B * need, c.d, need, c.N, 0,
+                             W.sc.scratch, W.sc.scratch_bytes, st));   // compact dy / statistics, gradients written at the tokens' rows of the full layout
+  else RC(layernorm_bwd(W.d_lnfull, W.x[c.layers], W.enc_mean, W.enc_rstd, p.enc_ln_w, nullptr, W.g0, W.gb0, gr.enc_ln_w, gr.enc_ln_b, (int)Re, c.d, 0, 0, 0,
+                        W.sc.scratch, W.sc.scratch_bytes, st));
   RC(mark());  // [players+2] encoder.layernorm
   for (int l = c.layers - 1; l >= 0; l--) {
-    RC(layer_bwd(vblock(p.enc[l]), vblock(gr.enc[l]), W.enc[l], de, W.sc, W.x[l], W.g0, W.gb0, W.g1, W.gb1, 0, 0, st));
+    RC(layer_bwd(vblock(p.enc[l]), vblock(gr.enc[l]), W.enc[l], de, W.sc, W.x[l], W.g0, W.gb0, W.g1, W.gb1, l == c.layers - 1 ? need : 0, 0, st));
     RC(mark());  // [players+3 ..] encoder layers, last first
   }
   // patch embedding

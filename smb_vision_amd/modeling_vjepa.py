@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import copy
 import ctypes as C
+import os
 import weakref
 from dataclasses import dataclass
 from typing import List, Optional
@@ -252,22 +253,42 @@ class SmbVJEPA2Model(PreTrainedModel):
         return [self._gflat[o:o + p.numel()].view(p.shape) for p, o in zip(self._ordered_params(), self._goffs)]
 
     # -- the step ------------------------------------------------------------------------------------------------------
-    def _index_plumbing(self, cms, tms, device):
+    def _index_plumbing(self, cms, tms, device, needed=None):
         """Sorted predictor sequences (modeling_vjepa.py:718-719).  ``cms`` / ``tms``: the mask lists; ``apply_masks`` (:542-556) concatenates
         their elements along the batch, so predictor sequence m * B + b pairs volume b with mask pair m.  Returns the arrays of
-        ``smbv_vjepa_io``: absolute encoder rows of the context tokens, sorted positions, and the slot of every context / target token."""
+        ``smbv_vjepa_io``: absolute encoder rows of the context tokens, sorted positions, and the slot of every context / target token.
+
+        ``needed`` ("context" / "target", one mask pair): the encoder's token order is permuted so that the tokens whose encoder output the caller
+        consumes come first (ascending ids), the others after them (``smbv_vjepa_cfg.enc_needed``); RoPE then takes explicit position ids.  The
+        rows ``ctx_idx`` names, and ``need_rows`` (where each consumed token sits), are rows of the COMPACT encoder output [B * enc_needed, d]."""
         B, N = cms[0].shape[0], self.num_patches
-        all_idx = torch.arange(N, device=device, dtype=torch.int32).repeat(B, 1).contiguous()
         cm, tm = torch.cat(cms, dim=0), torch.cat(tms, dim=0)           # [M*B, Nctx], [M*B, Ntgt]
         pos = torch.cat([cm, tm], dim=1)
         order = torch.argsort(pos, dim=1, stable=True)
         rev = torch.argsort(order, dim=1, stable=True)
         n_ctx = cm.shape[1]
         vol = torch.arange(B, device=device).repeat(len(cms)).unsqueeze(1)  # sequence -> volume it reads
-        return dict(all_idx=all_idx, ctx_idx=(cm + vol * N).to(torch.int32).contiguous(), tgt_idx=tm.to(torch.int32).contiguous(),
-                    pred_pos=torch.gather(pos, 1, order).to(torch.int32).contiguous(), ctx_slot=rev[:, :n_ctx].to(torch.int32).contiguous(),
-                    tgt_slot=rev[:, n_ctx:].to(torch.int32).contiguous(), n_masks=len(cms),
-                    ctx_tok=[c.to(torch.int32).contiguous() for c in cms], tgt_tok=[t.to(torch.int32).contiguous() for t in tms])
+        out = dict(tgt_idx=tm.to(torch.int32).contiguous(), pred_pos=torch.gather(pos, 1, order).to(torch.int32).contiguous(),
+                   ctx_slot=rev[:, :n_ctx].to(torch.int32).contiguous(), tgt_slot=rev[:, n_ctx:].to(torch.int32).contiguous(), n_masks=len(cms),
+                   ctx_tok=[c.to(torch.int32).contiguous() for c in cms], tgt_tok=[t.to(torch.int32).contiguous() for t in tms],
+                   enc_needed=0, enc_pos=None, need_rows=None)
+        if needed is None:
+            out["all_idx"] = torch.arange(N, device=device, dtype=torch.int32).repeat(B, 1).contiguous()
+            out["ctx_idx"] = (cm + vol * N).to(torch.int32).contiguous()
+            return out
+        sel = cm if needed == "context" else tm                         # [B, n] token ids whose encoder output is consumed (one mask pair)
+        n = sel.shape[1]
+        rest = torch.ones(B, N, dtype=torch.int8, device=device)
+        rest.scatter_(1, sel, 0)                                        # 0 = consumed, 1 = not; a stable sort puts the consumed ids first, both ascending
+        perm = torch.argsort(rest, dim=1, stable=True)                  # encoder row j of a volume holds token perm[j]
+        rank = torch.argsort(perm, dim=1)                               # token id -> its encoder row (rows of consumed tokens are < n)
+        row0 = torch.arange(B, device=device).unsqueeze(1) * n
+        out["all_idx"] = perm.to(torch.int32).contiguous()
+        out["enc_pos"] = out["all_idx"]
+        out["enc_needed"] = n
+        out["need_rows"] = torch.gather(rank, 1, sel).to(torch.int32).contiguous()       # [B, n] row inside the volume's compact block
+        out["ctx_idx"] = (torch.gather(rank, 1, cm) + row0).to(torch.int32).contiguous() if needed == "context" else (cm + vol * N).to(torch.int32).contiguous()
+        return out
 
     def _run_forward(self, pix, idx, with_pred):
         lib = _lib.load()
@@ -276,16 +297,17 @@ class SmbVJEPA2Model(PreTrainedModel):
         n_ctx, n_tgt = idx["ctx_idx"].shape[1], idx["tgt_idx"].shape[1]
         cfg = self._cfg_struct(B, n_ctx, n_tgt)
         cfg.n_masks = idx["n_masks"]
+        cfg.enc_needed = idx["enc_needed"]
         need = lib.smbv_vjepa_workspace_bytes(C.byref(cfg))
         if need == 0:
             raise ValueError("smbv_vjepa_workspace_bytes: " + _lib.last_error())
-        key = (B, n_ctx, n_tgt, idx["n_masks"], dev)
+        key = (B, n_ctx, n_tgt, idx["n_masks"], idx["enc_needed"], dev)
         if self._ws is None or self._ws_key != key or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
             self._ws_key = key
         d = self.config.hidden_size
-        enc_out = torch.empty(B, self.num_patches, d, dtype=torch.float32, device=dev)
+        enc_out = torch.empty(B, idx["enc_needed"] or self.num_patches, d, dtype=torch.float32, device=dev)
         pred_out = torch.empty(B * idx["n_masks"], n_tgt, d, dtype=torch.float32, device=dev) if with_pred else None
         io = _lib.VjepaIO()
         io.pixel_values = pix.data_ptr()
@@ -293,6 +315,7 @@ class SmbVJEPA2Model(PreTrainedModel):
             setattr(io, k, idx[k].data_ptr())
         io.rope_enc, io.rope_pred = self._rope[0].data_ptr(), self._rope[1].data_ptr()
         io.enc_out, io.pred_out, io.d_pred = enc_out.data_ptr(), (pred_out.data_ptr() if with_pred else None), None
+        io.enc_pos = idx["enc_pos"].data_ptr() if idx["enc_pos"] is not None else None
         _, ps, gs = self._structs
         stream = torch.cuda.current_stream().cuda_stream
         _lib.check(lib.smbv_vjepa_forward(C.byref(cfg), C.byref(ps), C.byref(io), self._ws.data_ptr(), self._ws.numel(), stream), "smbv_vjepa_forward")
@@ -349,7 +372,13 @@ class SmbVJEPA2Model(PreTrainedModel):
 
     def forward(self, pixel_values_videos: torch.Tensor, context_head_mask=None, context_mask: Optional[List[torch.Tensor]] = None,
                 target_head_mask=None, target_mask: Optional[List[torch.Tensor]] = None, skip_predictor: bool = False, output_attentions=None,
-                output_hidden_states=None, **kwargs):
+                output_hidden_states=None, smbv_needed: Optional[str] = None, **kwargs):
+        """``smbv_needed`` (not in the reference's signature; default None = the reference's forward): "context" - the caller consumes
+        ``predictor_output`` / ``masked_hidden_state`` only (the online model inside ``VJEPATrainer.compute_loss``, run_vjepa.py:118-124), "target" - it
+        consumes ``target_hidden_state`` only (the frozen target encoder, :126-131).  The last encoder block then computes only the rows those outputs
+        are made of (``smbv_vjepa_cfg.enc_needed``); ``last_hidden_state`` and the other gather are ``None``.  What IS returned equals the
+        unrestricted forward's output up to summation order (the encoder's tokens are processed in a permuted order: same products, sums in another
+        order), tests/test_vjepa_gpu.py."""
         if pixel_values_videos is None:
             raise ValueError("You have to specify pixel_values_videos")
         if output_attentions or output_hidden_states or context_head_mask is not None or target_head_mask is not None:
@@ -378,17 +407,28 @@ class SmbVJEPA2Model(PreTrainedModel):
                 raise ValueError("all context masks (and all target masks) must keep the same number of tokens: apply_masks concatenates them "
                                  "along the batch (modeling_vjepa.py:542-556)")
             params = self._ensure_device_state(dev)
-            idx = self._index_plumbing(cms, tms, dev)
+            if smbv_needed not in (None, "context", "target"):
+                raise ValueError("smbv_needed must be None, 'context' or 'target'")
+            sel = {"context": cms, "target": tms}.get(smbv_needed)
+            native_heads = (c.hidden_size // c.num_attention_heads) in (32, 64)  # (head-padded encoder widths: the ranged block is not built for them)
+            if smbv_needed is not None and (len(cms) != 1 or sel[0].shape[1] >= N or not native_heads or (smbv_needed == "target" and not skip_predictor)):
+                smbv_needed = None  # mask lists, a mask that keeps every token, or a predictor that needs the context rows: the unrestricted forward
+            idx = self._index_plumbing(cms, tms, dev, smbv_needed)
             with_pred = not skip_predictor
             if torch.is_grad_enabled() and with_pred and any(p.requires_grad for p in params):
                 enc_out, pred_out = _VJEPAFn.apply(weakref.ref(self), pix, idx, with_pred, *params)
             else:
                 enc_out, pred_out, _ = self._run_forward(pix, idx, with_pred)
             # apply_masks(sequence_output, masks) (:1150-1158): one HBM-rate row gather per mask, concatenated along the batch
-            masked = torch.cat([gather_rows(enc_out.detach(), c) for c in idx["ctx_tok"]], dim=0)
-            target = torch.cat([gather_rows(enc_out.detach(), t) for t in idx["tgt_tok"]], dim=0)
+            if smbv_needed is None:
+                masked = torch.cat([gather_rows(enc_out.detach(), c) for c in idx["ctx_tok"]], dim=0)
+                target = torch.cat([gather_rows(enc_out.detach(), t) for t in idx["tgt_tok"]], dim=0)
+                last = enc_out
+            else:  # the encoder output is compact [B, enc_needed, d]: the consumed tokens, in ascending id order; need_rows = where each mask entry sits
+                got = gather_rows(enc_out.detach(), idx["need_rows"])
+                masked, target, last = (got, None, None) if smbv_needed == "context" else (None, got, None)
         pred = SmbVJEPA2PredictorOutput(last_hidden_state=pred_out, target_hidden_state=target) if with_pred else None
-        return SmbVJEPA2ModelOutput(last_hidden_state=enc_out, masked_hidden_state=masked, target_hidden_state=target, predictor_output=pred)
+        return SmbVJEPA2ModelOutput(last_hidden_state=last, masked_hidden_state=masked, target_hidden_state=target, predictor_output=pred)
 
 
 def gather_rows(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
@@ -467,12 +507,15 @@ def make_target_encoder(model: SmbVJEPA2Model) -> SmbVJEPA2Model:
 
 def vjepa_loss(model, target_encoder, momentum_encoder, inputs):
     """VJEPATrainer.compute_loss (run_vjepa.py:110-141): online forward, frozen target forward, L1, EMA update — in that order."""
+    # (smbv_needed: compute_loss reads predictor_output from the online model and target_hidden_state from the target encoder, nothing else -
+    #  the last encoder block of each then only works on the rows those are made of; SMBV_VJEPA_FULL_ENCODER=1 keeps the unrestricted forward)
+    full = os.environ.get("SMBV_VJEPA_FULL_ENCODER", "0") == "1"
     out = model(pixel_values_videos=inputs["pixel_values_videos"], context_mask=inputs["context_mask"], target_mask=inputs["target_mask"],
-                skip_predictor=False)
+                skip_predictor=False, smbv_needed=None if full else "context")
     pred = out.predictor_output.last_hidden_state
     with torch.no_grad():
         tgt = target_encoder(pixel_values_videos=inputs["pixel_values_videos"], context_mask=inputs["context_mask"],
-                             target_mask=inputs["target_mask"], skip_predictor=True).target_hidden_state
+                             target_mask=inputs["target_mask"], skip_predictor=True, smbv_needed=None if full else "target").target_hidden_state
     loss = l1_loss(pred, tgt)
     if momentum_encoder is not None:
         momentum_encoder.update(model)

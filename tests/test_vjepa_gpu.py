@@ -98,10 +98,15 @@ def test_vjepa_step_matches_reference_golden():
     pix = blob["in.pixel_values_videos"].cuda()
     cm, tm = blob["in.context_mask"].cuda(), blob["in.target_mask"].cuda()
     inputs = {"pixel_values_videos": pix, "context_mask": [cm], "target_mask": [tm]}
-    loss, out = vjepa_loss(model, target, None, inputs)
+    loss, out = vjepa_loss(model, target, None, inputs)   # (the harness path: last encoder blocks restricted to the consumed rows, smbv_needed)
     loss.backward()
     torch.cuda.synchronize()
-    assert rel(out.last_hidden_state.cpu(), blob["out.last_hidden_state"]) < 3e-2
+    assert out.last_hidden_state is None and out.target_hidden_state is None
+    with torch.no_grad():
+        full = model(pixel_values_videos=pix, context_mask=[cm], target_mask=[tm])   # the reference's forward: every output
+    assert rel(full.last_hidden_state.cpu(), blob["out.last_hidden_state"]) < 3e-2
+    assert rel(full.predictor_output.last_hidden_state.cpu(), blob["out.predictor"]) < 3e-2
+    assert rel(out.masked_hidden_state.cpu(), full.masked_hidden_state.cpu()) < 2e-3
     assert rel(out.predictor_output.last_hidden_state.detach().cpu(), blob["out.predictor"]) < 3e-2
     with torch.no_grad():
         tgt = target(pixel_values_videos=pix, context_mask=[cm], target_mask=[tm], skip_predictor=True)
@@ -274,3 +279,51 @@ def test_vjepa_mask_lists_match_the_reference_shapes_and_the_oracle():
         model(pixel_values_videos=pix.cuda(), context_mask=[cms[0].cuda()], target_mask=[t.cuda() for t in tms])
     with pytest.raises(ValueError):
         model(pixel_values_videos=pix.cuda(), context_mask=[cms[0].cuda(), cms[1][:, :10].cuda()], target_mask=[t.cuda() for t in tms])
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_vjepa_restricted_last_encoder_block_equals_the_full_forward(B, monkeypatch):
+    """smbv_needed / smbv_vjepa_cfg.enc_needed: with the encoder's tokens permuted to [consumed | others] (RoPE on explicit ids) the
+    last encoder block computes the consumed rows only.  Loss, predictor output, the target encoder's target rows and EVERY gradient must equal the
+    unrestricted step's up to summation order (the permutation reorders keys and tokens: same products, other order of the fp32 sums - bf16 roundings
+    flip on single elements): outputs 2e-3 of scale, gradients ||d|| <= 1e-2 ||g||."""
+    from smb_vision_amd.modeling_vjepa import make_target_encoder, vjepa_loss
+    blob, c = load("vjepa_tiny")
+    p_on = {k[6:]: v for k, v in blob.items() if k.startswith("param.")}
+    p_tg = {k[7:]: v for k, v in blob.items() if k.startswith("tparam.")}
+    model = build(c, p_on)
+    target = make_target_encoder(build(c, p_tg))
+    g = torch.Generator().manual_seed(3)
+    pix = torch.rand(B, c["frames_per_clip"], 1, c["crop_size"], c["crop_size"], generator=g).cuda()
+    n = (c["frames_per_clip"] // c["tubelet_size"]) * (c["crop_size"] // c["patch_size"]) ** 2
+    perm = torch.randperm(n, generator=g)
+    cm = perm[: n // 3][None].repeat(B, 1).cuda()                    # NOT sorted: the mask order must not matter
+    tm = perm[n // 3:].sort().values[None].repeat(B, 1).cuda()
+    inputs = {"pixel_values_videos": pix, "context_mask": [cm], "target_mask": [tm]}
+
+    def step(full):
+        monkeypatch.setenv("SMBV_VJEPA_FULL_ENCODER", "1" if full else "0")
+        model.zero_grad(set_to_none=True)
+        loss, out = vjepa_loss(model, target, None, inputs)
+        loss.backward()
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            tgt = target(pixel_values_videos=pix, context_mask=[cm], target_mask=[tm], skip_predictor=True, smbv_needed=None if full else "target").target_hidden_state
+        return float(loss), out.predictor_output.last_hidden_state.detach().clone(), out.masked_hidden_state.clone(), tgt.clone(), \
+            {k: p.grad.detach().clone() for k, p in model.named_parameters()}, out
+
+    l0, p0, m0, t0, g0, o0 = step(True)
+    l1, p1, m1, t1, g1, o1 = step(False)
+    assert o0.last_hidden_state is not None and o1.last_hidden_state is None
+    assert abs(l0 - l1) <= 1e-4 * abs(l0), (l0, l1)
+    assert rel(p1, p0) < 2e-3 and rel(m1, m0) < 2e-3 and rel(t1, t0) < 2e-3, (rel(p1, p0), rel(m1, m0), rel(t1, t0))
+    worst = ("", 0.0)
+    for k in g0:
+        nrm = float(g0[k].norm())
+        if nrm < 1e-10:
+            assert float(g1[k].norm()) < 1e-6, k
+            continue
+        r = float((g1[k] - g0[k]).norm()) / nrm
+        worst = max(worst, (k, r), key=lambda t: t[1])
+        assert r < (5e-2 if k.endswith("attention.key.bias") else 1e-2), (k, r)
+    print(f"restricted last encoder block, B={B}: loss {l1:.6f} vs {l0:.6f}, worst gradient difference {worst}")
