@@ -326,6 +326,9 @@ typedef struct smbv_vjepa_io {
   float* enc_out;                  /* out: fp32 [B*N, d] last_hidden_state (after encoder.layernorm) */
   float* pred_out;                 /* out: fp32 [P*Ntgt, d] predictor_output.last_hidden_state (NULL: encoder only = skip_predictor) */
   const float* d_pred;             /* backward: fp32 [P*Ntgt, d] gradient w.r.t. pred_out */
+  const float* d_enc;              /* backward, optional: fp32 [B*N, d] gradient w.r.t. enc_out (VJEPA2Model's last_hidden_state and the mask gathers taken from it,
+                                      modeling_vjepa.py:1137-1163).  With d_pred == NULL the predictor is skipped (its gradients are left untouched: zero them).
+                                      Not with enc_needed */
   const int32_t* enc_pos;          /* int32 [B,N] RoPE position id of every encoder row, or NULL = row index within the volume (the natural order).  With a
                                       permuted token order (enc_needed) this is all_idx: attention is permutation-equivariant once RoPE takes explicit ids */
 } smbv_vjepa_io;

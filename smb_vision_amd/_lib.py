@@ -99,7 +99,7 @@ class VjepaTensors(C.Structure):
 
 class VjepaIO(C.Structure):
     _fields_ = [(n, c_f) for n in ("pixel_values", "all_idx", "ctx_idx", "tgt_idx", "pred_pos", "ctx_slot", "tgt_slot", "rope_enc", "rope_pred", "enc_out",
-                                   "pred_out", "d_pred", "enc_pos")]
+                                   "pred_out", "d_pred", "d_enc", "enc_pos")]
 
 
 _SIGS = {

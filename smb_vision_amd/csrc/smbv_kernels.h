@@ -90,6 +90,7 @@ int rope3d(bf16_t* qkv, int ld, int k_off, long rows, int S, int H, int hs, int 
            hipStream_t st);
 int gather_rows_idx_bf16(const bf16_t* src, bf16_t* dst, const int* idx, long nidx, int per_batch, long src_batch_rows, int D, hipStream_t st);
 int scatter_rows_idx_bf16(const bf16_t* src, bf16_t* dst, const int* idx, long nidx, int per_batch, long dst_batch_rows, int D, hipStream_t st);
+int add_f32_into_bf16(bf16_t* dst, const float* src, size_t n, hipStream_t st);  // dst += src
 int scatter_add_rows_idx_bf16(const bf16_t* src, bf16_t* dst, const int* idx, long nidx, int D, hipStream_t st);  // dst[idx[r]] += src[r], idx = absolute rows
 int gather_rows_idx_f32(const float* src, float* dst, const int* idx, long nidx, int per_batch, long src_batch_rows, int D, hipStream_t st);
 int scatter_rows_idx_f32(const float* src, float* dst, const int* idx, long nidx, int per_batch, long dst_batch_rows, int D, hipStream_t st);

@@ -82,6 +82,22 @@ __global__ void rows_idx_add_bf16_kernel(const bf16_t* __restrict__ src, bf16_t*
   }
 }
 
+// dst (bf16) += src (fp32), elementwise, n % 8 == 0
+__global__ void add_f32_into_bf16_kernel(bf16_t* __restrict__ dst, const float* __restrict__ src, size_t n8) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const u32x4 d = ((const u32x4*)dst)[i];
+    const f32x4 a = ((const f32x4*)src)[2 * i], b = ((const f32x4*)src)[2 * i + 1];
+    const u32x4 o = {pack_bf16(bf_lo(d[0]) + a[0], bf_hi(d[0]) + a[1]), pack_bf16(bf_lo(d[1]) + a[2], bf_hi(d[1]) + a[3]),
+                     pack_bf16(bf_lo(d[2]) + b[0], bf_hi(d[2]) + b[1]), pack_bf16(bf_lo(d[3]) + b[2], bf_hi(d[3]) + b[3])};
+    ((u32x4*)dst)[i] = o;
+  }
+}
+int add_f32_into_bf16(bf16_t* dst, const float* src, size_t n, hipStream_t st) {
+  if ((n & 7) || (((uintptr_t)dst | (uintptr_t)src) & 15)) { set_error("add_f32_into_bf16: n %% 8 / alignment"); return SMBV_ERR_ALIGN; }
+  hipLaunchKernelGGL(add_f32_into_bf16_kernel, dim3((int)std::min<size_t>(2048, (n / 8 + 255) / 256)), dim3(256), 0, st, dst, src, n / 8);
+  return check_launch("add_f32_into_bf16");
+}
+
 int scatter_add_rows_idx_bf16(const bf16_t* src, bf16_t* dst, const int* idx, long nidx, int D, hipStream_t st) {
   if (nidx <= 0 || (D & 7) || (((uintptr_t)src | (uintptr_t)dst) & 15)) { set_error("scatter_add_rows_idx_bf16: bad shape/alignment"); return SMBV_ERR_SHAPE; }
   hipLaunchKernelGGL(rows_idx_add_bf16_kernel, dim3(nidx), dim3(64), 0, st, src, dst, idx, D / 8);

@@ -206,11 +206,15 @@ static int vjepa_backward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, 
   VjepaWs W;
   vcarve(c, ws, W);
   if (!ws || ws_bytes < W.total || ((uintptr_t)ws & 255)) { set_error("vjepa_backward: workspace too small or misaligned"); return SMBV_ERR_WORKSPACE; }
-  if (!io.d_pred || !io.tgt_slot || !io.ctx_slot || !io.ctx_idx) { set_error("vjepa_backward: null io pointer"); return SMBV_ERR_ARG; }
+  const bool with_pred = io.d_pred != nullptr;
+  if (!with_pred && !io.d_enc) { set_error("vjepa_backward: neither d_pred nor d_enc"); return SMBV_ERR_ARG; }
+  if (with_pred && (!io.tgt_slot || !io.ctx_slot || !io.ctx_idx)) { set_error("vjepa_backward: null io pointer"); return SMBV_ERR_ARG; }
+  if (io.d_enc && vneed(c)) { set_error("vjepa_backward: d_enc with enc_needed (the full encoder output was not produced)"); return SMBV_ERR_ARG; }
   const int K = c.ts * c.ps * c.ps;
   const BlockDims de = venc_dims(c, &io), dp = vpred_dims(c, &io);
   const size_t Re = de.rows, Rp = dp.rows, Rc = (size_t)vpb(c) * c.Nctx, Rt = (size_t)vpb(c) * c.Ntgt;
   const int Sp = c.Nctx + c.Ntgt;
+  if (with_pred) {
   // predictor.proj
   RC(cast_f32_bf16(io.d_pred, W.dpred_bf, Rt * c.d, st));
   {
@@ -244,15 +248,21 @@ static int vjepa_backward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, 
     RC(gemm_nt(W.d_ctx, c.pd, W.pemb_t, c.pd, (int)Rc, c.d, c.pd, e, st));
   }
   RC(mark());  // [players+1] mask tokens + predictor_embeddings
+  } else {
+    for (int i = 0; i < c.players + 2; i++) RC(mark());  // the predictor's gradient groups: untouched by this call (the caller zeroed them)
+  }
   // encoder.layernorm: only the context tokens receive gradient
   HIPRC(hipMemsetAsync(W.d_lnfull, 0, Re * c.d * sizeof(bf16_t), st));
   // mask pair 0 scatters, the others add on top (apply_masks' autograd sums the pairs that read the same encoder row); rows are distinct
   // inside a pair, the launches are stream-ordered: no atomics, reproducible
-  {
+  if (with_pred) {
     const long per = (long)c.B * c.Nctx;
     RC(scatter_rows_idx_bf16(W.d_encctx, W.d_lnfull, io.ctx_idx, per, (int)per, 0, c.d, st));
     for (int m = 1; m < vmasks(c); m++) RC(scatter_add_rows_idx_bf16(W.d_encctx + (size_t)m * per * c.d, W.d_lnfull, io.ctx_idx + (size_t)m * per, per, c.d, st));
   }
+  // gradient that reached the encoder output directly (last_hidden_state, masked / target_hidden_state): added on top, rounded to the bf16 the
+  // LayerNorm backward takes its dy in
+  if (io.d_enc) RC(add_f32_into_bf16(W.d_lnfull, io.d_enc, Re * c.d, st));
   const int need = vneed(c);
   if (need) RC(layernorm_bwd(W.d_lnfull, W.x[c.layers], W.enc_mean, W.enc_rstd, p.enc_ln_w, nullptr, W.g0, W.gb0, gr.enc_ln_w, gr.enc_ln_b, c.B * need, c.d, need, c.N, 0,
                              W.sc.scratch, W.sc.scratch_bytes, st));   // compact dy / statistics, gradients written at the tokens' rows of the full layout

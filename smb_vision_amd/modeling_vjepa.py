@@ -118,11 +118,11 @@ class _VJEPAFn(torch.autograd.Function):
     def backward(ctx, d_enc, d_pred):
         model = ctx.model_ref()
         n = len(model._table)
-        if d_enc is not None:
-            raise NotImplementedError("smb_vision_amd: gradients through last_hidden_state are not implemented (the V-JEPA loss only uses predictor_output)")
-        if d_pred is None:
+        if d_enc is None and d_pred is None:
             return (None,) * (4 + n)
-        return (None, None, None, None, *model._run_backward(ctx.st, d_pred))
+        if d_enc is not None and ctx.st["cfg"].enc_needed:
+            raise _lib.SmbvError("smb_vision_amd: gradients through the encoder output need the unrestricted forward (smbv_needed=None)")
+        return (None, None, None, None, *model._run_backward(ctx.st, d_pred, d_enc))
 
 
 class SmbVJEPA2Model(PreTrainedModel):
@@ -322,13 +322,17 @@ class SmbVJEPA2Model(PreTrainedModel):
         self._fwd_count += 1
         return enc_out, pred_out, dict(cfg=cfg, io=io, step=self._fwd_count, keep=(pix, idx, enc_out, pred_out))
 
-    def _run_backward(self, st, d_pred):
+    def _run_backward(self, st, d_pred, d_enc=None):
         lib = _lib.load()
         if st["step"] != self._fwd_count:
             raise _lib.SmbvError("smb_vision_amd: backward() after a later forward() reused the step workspace")
-        d_pred = d_pred.detach().to(torch.float32).contiguous()
         io = st["io"]
-        io.d_pred = d_pred.data_ptr()
+        if d_pred is not None:
+            d_pred = d_pred.detach().to(torch.float32).contiguous()
+        if d_enc is not None:   # gradient through last_hidden_state / masked_hidden_state / target_hidden_state (modeling_vjepa.py:1137-1163)
+            d_enc = d_enc.detach().to(torch.float32).contiguous()
+        io.d_pred = d_pred.data_ptr() if d_pred is not None else None
+        io.d_enc = d_enc.data_ptr() if d_enc is not None else None
         _, ps, gs = self._structs
         _lib.detach_aliased_grads(self._ordered_params(), self._gflat, self._goffs, self)  # accumulation / zero_grad(set_to_none=False)
         self._gflat.zero_()  # rows of mask_tokens that were not selected keep a zero gradient
@@ -415,14 +419,16 @@ class SmbVJEPA2Model(PreTrainedModel):
                 smbv_needed = None  # mask lists, a mask that keeps every token, or a predictor that needs the context rows: the unrestricted forward
             idx = self._index_plumbing(cms, tms, dev, smbv_needed)
             with_pred = not skip_predictor
-            if torch.is_grad_enabled() and with_pred and any(p.requires_grad for p in params):
+            if torch.is_grad_enabled() and any(p.requires_grad for p in params):
                 enc_out, pred_out = _VJEPAFn.apply(weakref.ref(self), pix, idx, with_pred, *params)
+                if not with_pred:
+                    pred_out = None
             else:
                 enc_out, pred_out, _ = self._run_forward(pix, idx, with_pred)
             # apply_masks(sequence_output, masks) (:1150-1158): one HBM-rate row gather per mask, concatenated along the batch
-            if smbv_needed is None:
-                masked = torch.cat([gather_rows(enc_out.detach(), c) for c in idx["ctx_tok"]], dim=0)
-                target = torch.cat([gather_rows(enc_out.detach(), t) for t in idx["tgt_tok"]], dim=0)
+            if smbv_needed is None:   # (differentiable like the reference's: _GatherRowsFn scatters the gradient back into the encoder output's)
+                masked = torch.cat([_GatherRowsFn.apply(enc_out, c) for c in idx["ctx_tok"]], dim=0)
+                target = torch.cat([_GatherRowsFn.apply(enc_out, t) for t in idx["tgt_tok"]], dim=0)
                 last = enc_out
             else:  # the encoder output is compact [B, enc_needed, d]: the consumed tokens, in ascending id order; need_rows = where each mask entry sits
                 got = gather_rows(enc_out.detach(), idx["need_rows"])
@@ -439,6 +445,26 @@ def gather_rows(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     _lib.check(lib.smbv_gather_rows_idx_f32(x.data_ptr(), out.data_ptr(), idx.data_ptr(), idx.numel(), idx.shape[1], N, D,
                                             torch.cuda.current_stream().cuda_stream), "smbv_gather_rows_idx_f32")
     return out
+
+
+class _GatherRowsFn(torch.autograd.Function):
+    """apply_masks with its autograd: rows of a mask are distinct, so the backward is a plain row scatter into zeros (no atomics)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.shape = x.shape
+        return gather_rows(x.detach(), idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, N, D = ctx.shape
+        out = torch.zeros(B, N, D, dtype=torch.float32, device=g.device)
+        g = g.detach().to(torch.float32).contiguous()
+        _lib.check(_lib.load().smbv_scatter_rows_idx_f32(g.data_ptr(), out.data_ptr(), idx.data_ptr(), idx.numel(), idx.shape[1], N, D,
+                                                         torch.cuda.current_stream().cuda_stream), "smbv_scatter_rows_idx_f32")
+        return out, None
 
 
 class _L1Fn(torch.autograd.Function):
