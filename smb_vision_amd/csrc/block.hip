@@ -2,6 +2,7 @@
 #include "block.h"
 
 namespace smbv {
+extern int g_variant;
 
 void carve_layer(Carver& c, LayerWs& L, const BlockDims& d, const LayerWs* share_acts) {
   const size_t w = d.w, wa = d.wa(), ff = d.ff, rows = d.rows;
@@ -221,15 +222,20 @@ int layer_bwd(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDi
       RC(map_copy_f32(gr.proj_w, sc.gpad, (size_t)w * w, d.Dh, 64, side.st));
     }
   }
+  bool delta_fused = false;
   {
     GemmEpi e; e.out_bf16 = sc.d_o; e.ld_ob = wa;
     if (ranged) { e.out_bf16 = sc.d_o + (size_t)qoff * wa; e.grp_in = Sq; e.grp_out = S; }
+    // delta = rowsum(dO * O) per (token, head) comes out of this product's epilogue (gemm.hip) instead of a launch of its own in attention_bwd
+    e.dot_with = L.attn_o + (ranged ? (size_t)qoff * wa : 0); e.ld_dot = wa; e.dot_dh = d.slot(); e.dot_rows = ranged ? Sq : S; e.dot_out = sc.delta;
+    if (!(g_variant & 4096) && gemm_nt_rowdot_ok(w, w, Mq, wa, w, e)) delta_fused = true;
+    else { e.dot_with = nullptr; e.dot_out = nullptr; }
     RC(gemm_nt(g2c, w, L.proj_t, w, Mq, wa, w, e, st));
   }
   // ---- attention (dQ exists only for the ranged queries; dK/dV for every token) ----
   if (ranged) HIPRC(hipMemsetAsync(sc.d_qkv, 0, (size_t)M * 3 * wa * sizeof(bf16_t), st));
   RC(attention_bwd(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, sc.d_o, wa, L.lse, sc.delta, sc.d_qkv, sc.d_qkv + wa, sc.d_qkv + 2 * wa, 3 * wa, B,
-                   S, H, d.slot(), d.scale(), 7, Sq, qoff, st));
+                   S, H, d.slot(), d.scale(), delta_fused ? 6 : 7, Sq, qoff, st));
   if (d.rope_grid > 0) RC(rope3d(sc.d_qkv, 3 * wa, wa, M, S, H, d.slot(), d.Dh, d.rope_grid, d.pos, d.rope_table, 1, st));
   // ---- QKV ----
   // (the three products forked above had the whole attention backward to finish: joining them here costs nothing and makes every later

@@ -167,6 +167,7 @@ __device__ __forceinline__ void epilogue_rows32(float* ws, const f32x4 (&a0)[4],
       const int r = it * 8 + r8;
       const int m = mbase + r;
       f32x4 v0 = *(const f32x4*)(ws + r * LDW + c8 * 8), v1 = *(const f32x4*)(ws + r * LDW + c8 * 8 + 4);
+      float dot = 0.f;
       if (m < M && ncol) {
         size_t orow = (size_t)m;
         if (e.grp_in > 0) orow = (size_t)(m / e.grp_in) * e.grp_out + (m % e.grp_in);
@@ -202,7 +203,19 @@ __device__ __forceinline__ void epilogue_rows32(float* ws, const f32x4 (&a0)[4],
         if (e.out_bf16) {
           u32x4 p = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
           *(u32x4*)(e.out_bf16 + orow * e.ld_ob + n) = p;
+          if (e.dot_out) {  // this lane's 8 columns of the row-dot (the bf16-rounded outputs, as a reader of the stored matrix would see them)
+            const u32x4 o = *(const u32x4*)(e.dot_with + orow * e.ld_dot + n);
+#pragma unroll
+            for (int q = 0; q < 4; q++) dot += bf_lo(o[q]) * bf_lo(p[q]) + bf_hi(o[q]) * bf_hi(p[q]);
+          }
         }
+      }
+      if (e.dot_out) {  // (wave-uniform) the 8 lanes of a row hold its 64 columns: one head of 64 or two heads of 32
+        dot += __shfl_xor(dot, 1, 64);
+        dot += __shfl_xor(dot, 2, 64);
+        if (e.dot_dh == 64) dot += __shfl_xor(dot, 4, 64);
+        if (m < M && ncol && (c8 & (e.dot_dh / 8 - 1)) == 0)
+          e.dot_out[((size_t)(m / e.dot_rows) * (e.dot_heads) + n / e.dot_dh) * e.dot_rows + m % e.dot_rows] = dot;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -326,6 +339,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(const bf16_t* __res
   }
 }
 
+// the row-dot by-product lives in the LDS-staged epilogue of the LDS-DMA kernel (a wave's 64 output columns = whole heads)
+static bool nt_dma_ok(int lda, int ldb, int M, int N, int K, const GemmEpi& e) {
+  return (K % BK == 0) && (N % 8 == 0) && (!e.out_bf16 || ((e.ld_ob & 7) == 0 && ((uintptr_t)e.out_bf16 & 15) == 0)) &&
+         (!e.aux_pre || ((e.ld_aux & 7) == 0 && ((uintptr_t)e.aux_pre & 15) == 0)) &&
+         (!e.dgelu_pre || ((e.ld_pre & 7) == 0 && ((uintptr_t)e.dgelu_pre & 15) == 0)) && ((size_t)M * lda * 2 < (1ull << 31)) && ((size_t)N * ldb * 2 < (1ull << 31));
+}
+bool gemm_nt_rowdot_ok(int lda, int ldb, int M, int N, int K, const GemmEpi& e) {
+  const bool ring_shape = K <= 768 && N >= 1024;
+  const bool ring = gemm_nt_ring_ok(lda, ldb, M, N, K, e) && !(g_variant & 256) && (ring_shape || (g_variant & 131072));
+  return !ring && !(g_variant & 32) && nt_dma_ok(lda, ldb, M, N, K, e) && e.out_bf16 && (N % 64) == 0 && (e.ld_dot & 7) == 0;
+}
+
 int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt: empty problem M=%d N=%d K=%d", M, N, K); return SMBV_ERR_SHAPE; }
   if ((K & 7) || (lda & 7) || (ldb & 7) || (N & 3)) { set_error("gemm_nt: K,lda,ldb must be multiples of 8 and N of 4 (K=%d lda=%d ldb=%d N=%d)", K, lda, ldb, N); return SMBV_ERR_SHAPE; }
@@ -341,10 +366,11 @@ int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, in
   const bool ring_shape = K <= 768 && N >= 1024;
   if (gemm_nt_ring_ok(lda, ldb, M, N, K, e) && !(g_variant & 256) && (ring_shape || (g_variant & 131072)))
     return gemm_nt_ring(A, lda, B, ldb, M, N, K, e, (g_variant & 262144) ? 64 : ((g_variant & 512) ? 4 : 3), st, (g_variant >> 20) & 15);
+  if (e.dot_out && (!e.dot_with || (e.dot_dh != 64 && e.dot_dh != 32) || e.dot_rows <= 0 || ((uintptr_t)e.dot_with & 15) || !gemm_nt_rowdot_ok(lda, ldb, M, N, K, e))) {
+    set_error("gemm_nt: row-dot by-product not available for this product (check gemm_nt_rowdot_ok first)"); return SMBV_ERR_ARG;
+  }
   const int tm = cdiv(M, BM), tn = cdiv(N, BN);
-  const bool dma_ok = (K % BK == 0) && (N % 8 == 0) && (!e.out_bf16 || ((e.ld_ob & 7) == 0 && ((uintptr_t)e.out_bf16 & 15) == 0)) &&
-                      (!e.aux_pre || ((e.ld_aux & 7) == 0 && ((uintptr_t)e.aux_pre & 15) == 0)) &&
-                      (!e.dgelu_pre || ((e.ld_pre & 7) == 0 && ((uintptr_t)e.dgelu_pre & 15) == 0)) && ((size_t)M * lda * 2 < (1ull << 31)) && ((size_t)N * ldb * 2 < (1ull << 31));
+  const bool dma_ok = nt_dma_ok(lda, ldb, M, N, K, e);
   if (dma_ok && !(g_variant & 32)) {
     // mixed-tile launch (see the kernel): grids of 256 < T <= 384 tiles whose N is a whole number of tiles; the full rows are what 512 block slots leave
     int full_rows = tm;
@@ -357,7 +383,9 @@ int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, in
       if (fr < tm) full_rows = fr;
     }
     const int blocks = full_rows * tn + (tm - full_rows) * tn * 2;
-    hipLaunchKernelGGL(gemm_nt_dma_kernel, dim3(blocks), dim3(256), 0, st, A, lda, B, ldb, M, N, K, tm, tn, full_rows, e, (g_variant & 64) ? 1 : ((g_variant & 128) ? 2 : 0));
+    GemmEpi ee = e;
+    ee.dot_heads = e.dot_out ? N / e.dot_dh : 0;
+    hipLaunchKernelGGL(gemm_nt_dma_kernel, dim3(blocks), dim3(256), 0, st, A, lda, B, ldb, M, N, K, tm, tn, full_rows, ee, (g_variant & 64) ? 1 : ((g_variant & 128) ? 2 : 0));
     return check_launch("gemm_nt_dma");
   }
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(tm * tn), dim3(256), 0, st, A, lda, B, ldb, M, N, K, tm, e);

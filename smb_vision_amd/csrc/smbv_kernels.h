@@ -25,7 +25,17 @@ struct GemmEpi {
   float* out_f32 = nullptr;
   int ld_of = 0;
   int grp_in = 0, grp_out = 0;      // output row remap: (m / grp_in) * grp_out + m % grp_in   (0 = identity)
+  // row-dot by-product (the LDS-DMA kernel only, gemm_nt_rowdot_ok): dot_out[((m / dot_rows) * heads + n / dot_dh) * dot_rows + m % dot_rows] =
+  // sum over the dot_dh columns of head n / dot_dh of bf16(out)[m, n] * dot_with[orow(m) * ld_dot + n]   (heads = N / dot_dh; dot_dh 64 or 32).
+  // With out = dO (the attention output's gradient) and dot_with = O this is flash attention's delta = rowsum(dO * O), which the attention backward
+  // otherwise computes in a launch of its own (attn_delta_kernel, 16 launches per MIM step)
+  const bf16_t* dot_with = nullptr;
+  int ld_dot = 0;
+  float* dot_out = nullptr;
+  int dot_dh = 64, dot_rows = 0;
+  int dot_heads = 0;                // (filled in by gemm_nt: N / dot_dh)
 };
+bool gemm_nt_rowdot_ok(int lda, int ldb, int M, int N, int K, const GemmEpi& e);
 
 int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, hipStream_t st);
 // second-generation NT kernel (gemm_nt_ring.hip): 256 x 128 tiles, LDS ring of K slices, register epilogue; gemm_nt dispatches to it

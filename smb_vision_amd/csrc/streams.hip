@@ -18,8 +18,16 @@ ForkJoin* fork_join_for_current_device() {
   std::lock_guard<std::mutex> lk(mu);
   ForkJoin& f = table[dev];
   if (!f.ready) {
-    if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipStreamCreateWithFlags(&f.wside, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    // A/B (variant bit 30): the side streams at the LOWEST priority the device offers, so that the caller's stream - the critical path - wins the block
+    // dispatcher whenever both have work ready (default: equal priorities)
+    int lo = 0, hi = 0;
+    if ((g_variant & (1 << 30)) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
+      if (hipStreamCreateWithPriority(&f.side, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
+      if (hipStreamCreateWithPriority(&f.wside, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
+    } else {
+      if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+      if (hipStreamCreateWithFlags(&f.wside, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    }
     hipEvent_t* ev[4] = {&f.fork, &f.join, &f.wfork, &f.wjoin};
     for (auto e : ev)
       if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return nullptr;

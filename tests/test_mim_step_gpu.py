@@ -194,3 +194,40 @@ def test_gradient_checkpointing_recompute_is_bitwise_identical_and_smaller():
             assert torch.equal(res[0][2][k], other[2][k]), k
     assert sizes[1] < 0.8 * sizes[0] and sizes[2] == sizes[0]     # "auto" keeps activations resident when they fit (they do here); the
     # per-block bf16 weight copies stay, so a 4+3-layer toy shrinks by a quarter (ViT-base at 512x512x320: 5.3 GB -> 1.3 GB)
+
+
+def test_delta_from_the_projection_epilogue_equals_the_standalone_launch():
+    """Round 3: delta = rowsum(dO * O) is a by-product of the out-projection input-gradient product's epilogue (gemm.hip, GemmEpi.dot_*) instead of
+    attn_delta_kernel's own launch (debug bit 4096 restores it).  Same bf16 operands, same products: the two steps' gradients must agree to fp32
+    summation order - on a config with a ranged last decoder block, two heads and ragged tiles."""
+    import ctypes
+    from transformers import VideoMAEConfig
+    from smb_vision_amd import _lib
+    from smb_vision_amd.masking import MaskGenerator
+    from smb_vision_amd.modeling_videomae import SmbVideoMAEForPreTraining
+    c = dict(image_size=96, num_frames=48, patch_size=16, tubelet_size=16, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+             decoder_hidden_size=128, decoder_num_hidden_layers=2, decoder_num_attention_heads=2, decoder_intermediate_size=256)
+    torch.manual_seed(0)
+    model = SmbVideoMAEForPreTraining(VideoMAEConfig(num_channels=1, **c)).cuda().train()
+    np.random.seed(1)
+    gen = MaskGenerator(96, 48, 16, 16, 0.6)
+    mask = torch.stack([gen(), gen()]).cuda()
+    pix = torch.rand(2, 48, 1, 96, 96, generator=torch.Generator().manual_seed(2)).cuda()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+
+    def grads(variant):
+        raw.smbv_debug_set_variant(variant)
+        try:
+            model.zero_grad(set_to_none=True)
+            out = model(pixel_values=pix, bool_masked_pos=mask)
+            out.loss.backward()
+            torch.cuda.synchronize()
+            return float(out.loss), [p.grad.detach().clone() for p in model.parameters()]
+        finally:
+            raw.smbv_debug_set_variant(0)
+
+    l0, g0 = grads(0)
+    l1, g1 = grads(4096)
+    assert l0 == l1
+    for (k, _), a, b in zip(model.named_parameters(), g0, g1):
+        assert float((a - b).norm()) <= 2e-3 * float(b.norm()) + 1e-9, k
