@@ -112,23 +112,23 @@ static int mim_forward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const s
   {
     PrepList pl;
     pl.cast(p.pe_w, W.pe_w, c.d, K);
+    for (int l = 0; l < c.layers; l++) RC(prep_layer(pl, to_block(p.enc[l]), W.enc[l], de, st));
     pl.cast(p.e2d_w, W.e2d, c.dd, c.d);
     pl.tcast(p.e2d_w, W.e2d_t, c.dd, c.d, c.dd);
+    for (int l = 0; l < c.dlayers; l++) RC(prep_layer(pl, to_block(p.dec[l]), W.dec[l], dd, st));
     pl.cast(p.head_w, W.head, K, c.dd);
     pl.tcast(p.head_w, W.head_t, K, c.dd, K);
-    for (int l = 0; l < c.layers; l++) RC(prep_layer(pl, to_block(p.enc[l]), W.enc[l], de, st));
-    for (int l = 0; l < c.dlayers; l++) RC(prep_layer(pl, to_block(p.dec[l]), W.dec[l], dd, st));
-    // the first launch (64 jobs: patch embedding, encoder_to_decoder, head and the first blocks) is needed at once; the others run on the library's side
-    // stream beside the brick gather, the patch-embedding product and the blocks whose copies the first launch made, and are joined in front of the
-    // first block whose jobs they hold (0.34 ms of HBM-bound casts off the critical path; head-padded configurations keep everything on `st`:
-    // prep_layer's zero fills are ordered on it)
-    const int njobs = (int)pl.jobs.size(), first = std::min(njobs, 64);
+    // Only what the first kernels read goes ahead of them on `st`: the patch-embedding weight and the first block's copies (17 jobs, ~30 us; round 2 put
+    // the first 64 jobs there, 113 us of the critical path).  Everything else - in the order the forward reaches it - runs on the library's side stream
+    // beside the brick gather, the patch-embedding product and the first block, and is joined in front of the second block (0.3 ms of HBM-bound casts
+    // against ~0.5 ms of main-stream work; head-padded configurations keep everything on `st`: prep_layer's zero fills are ordered on it)
+    const int njobs = (int)pl.jobs.size(), first = std::min(njobs, 1 + (int)layer_prep_job_count(de));
     const bool split = njobs > first && !de.padded() && !dd.padded();
     RC(prep_weights(pl.jobs.data(), split ? first : njobs, st));
     if (split) {
       RC(prep_side.begin(st));
       RC(prep_weights(pl.jobs.data() + first, njobs - first, prep_side.st));
-      prep_join_layer = std::max(0, (first - 5) / 16);  // 5 model-level jobs, then 16 per un-padded block, in program order
+      prep_join_layer = 1;
       // the target statistics depend on the volume and the mask only: same side stream, long done when the loss needs them
       RC(brick_stats(io.pixel_values, io.mask_idx, (int)Rm, c.Nmask, W.bmean, W.brinv, c.T, c.H, c.W, c.ts, c.ps, prep_side.st));
     }

@@ -145,14 +145,15 @@ static int vjepa_forward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, c
       pl.tcast(p.pproj_w, W.pproj_t, c.d, c.pd, c.d);
       for (int l = 0; l < c.players; l++) RC(prep_layer(pl, vblock(p.pred[l]), W.pred[l], dp, st));
     }
-    // as in mim_step.hip: the first launch (64 jobs) on `st`, the others on the side stream beside the brick gather and the first encoder blocks
-    const int njobs = (int)pl.jobs.size(), first = std::min(njobs, 64);
+    // as in mim_step.hip: what the first kernels read (patch-embedding weight + the first block's copies) on `st`, the rest on the side stream beside the
+    // brick gather, the patch-embedding product and the first block, joined in front of the second block
+    const int njobs = (int)pl.jobs.size(), first = std::min(njobs, 1 + (int)layer_prep_job_count(de));
     const bool split = njobs > first && !de.padded() && !(with_pred && dp.padded());
     RC(prep_weights(pl.jobs.data(), split ? first : njobs, st));
     if (split) {
       RC(prep_side.begin(st));
       RC(prep_weights(pl.jobs.data() + first, njobs - first, prep_side.st));
-      prep_join_layer = std::max(0, (first - 1) / 16);  // 1 model-level job, then 16 per un-padded block, in program order
+      prep_join_layer = 1;
     }
   }
   // encoder over all N tokens: Conv3d patch embedding (+bias, no position table: RoPE instead), L blocks, final LayerNorm
