@@ -104,23 +104,23 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // top "everyone has left the previous tile", after sub-tile 2 "the new tile has landed"), so the last sub-tile prefetches across
 // the tile seam as well and the staging costs no registers.
 template <int QT, int DH>
-__global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                           const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO,
-                                                           int ldo, const float* __restrict__ LSE, const float* __restrict__ delta,
-                                                           bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int ldd, int S, int Sq, int qoff,
-                                                           int H, float scale, int xcd_order) {
+struct DkvLds { static constexpr int BUF = 2 * QT * 2 * DH + 2 * QT * 4, BYTES = 2 * BUF; };
+
+// one key-owner block: keys 128 tile_x .. + 127 of (batch b, head); smem: DkvLds<QT, DH>::BYTES, 16-byte aligned
+template <int QT, int DH>
+__device__ __forceinline__ void attn_dkv2_block(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO,
+                                                int ldo, const float* __restrict__ LSE, const float* __restrict__ delta,
+                                                bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int ldd, int S, int Sq, int qoff,
+                                                int H, float scale, const int tile_x, const int head, const int b, unsigned char* smem) {
   static_assert(QT == 128, "the mid-iteration hand-over is written for 4 sub-tiles");
   static_assert(DH == 64 || DH == 32, "head widths with a native build");
   constexpr int NS = QT / 32;
   constexpr int KS = DH / 16, DT = DH / 32, RB = 2 * DH;  // QK^T-type k-steps, 32-channel output tiles, LDS row bytes
   constexpr int NPC = 32 * RB / 1024;                     // LDS-DMA pieces per wave and image (32 rows)
-  constexpr int BUF = 2 * QT * RB + 2 * QT * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+  constexpr int BUF = DkvLds<QT, DH>::BUF;
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int r = l & 31, h2 = l >> 5;
-  int tile_x = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
-  stagger_by_wave_slot((xcd_order >> 8) & 0xff);
-  if (xcd_order & 1) xcd_block_order((S + 127) / 128, H, tile_x, head, b);
   const size_t row0 = (size_t)b * S;
   const int key = tile_x * 128 + w * 32 + r;
   const int hoff = head * DH;
@@ -338,6 +338,20 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
 }
 
 
+template <int QT, int DH>
+__global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                           const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO,
+                                                           int ldo, const float* __restrict__ LSE, const float* __restrict__ delta,
+                                                           bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int ldd, int S, int Sq, int qoff,
+                                                           int H, float scale, int xcd_order) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DkvLds<QT, DH>::BYTES];
+  int tile_x = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  stagger_by_wave_slot((xcd_order >> 8) & 0xff);
+  if (xcd_order & 1) xcd_block_order((S + 127) / 128, H, tile_x, head, b);
+  attn_dkv2_block<QT, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale, tile_x, head, b, smem);
+}
+
+
 // Hand-phased, rotated form of attn_dq_kernel (same arithmetic and accumulation order: bitwise identical results).  Steady state,
 // per 32-key sub-tile j, three dependent chains of 4 MFMAs, each with the other sub-tile's VALU work and the LDS reads of a LATER
 // chain in its gaps:
@@ -348,21 +362,22 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
 // before body 3 "tile T is dead", after which tile T+2 is requested into its buffer).  The pipeline's last body runs its A and C
 // chains on a stale sub-tile; their results are never used.
 template <int KT, int DH>
-__global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                          const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO, int ldo,
-                                                          const float* __restrict__ LSE, const float* __restrict__ delta,
-                                                          bf16_t* __restrict__ dQ, int ldd, int S, int Sq, int qoff, int H, float scale, int xcd_order) {
+struct DqLds { static constexpr int BUF = 2 * KT * 2 * DH, BYTES = 2 * BUF; };
+
+// one query-owner block: queries 128 tile_x .. + 127 of the range of (batch b, head); smem: DqLds<KT, DH>::BYTES, 16-byte aligned
+template <int KT, int DH>
+__device__ __forceinline__ void attn_dq2_block(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                               const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO, int ldo,
+                                               const float* __restrict__ LSE, const float* __restrict__ delta,
+                                               bf16_t* __restrict__ dQ, int ldd, int S, int Sq, int qoff, int H, float scale,
+                                               const int tile_x, const int head, const int b, unsigned char* smem) {
   static_assert(KT == 128, "bodies are unrolled for 4 sub-tiles per tile");
   static_assert(DH == 64 || DH == 32, "head widths with a native build");
   constexpr int KS = DH / 16, DT = DH / 32, RB = 2 * DH;  // QK^T-type k-steps, 32-channel output tiles, LDS row bytes
   constexpr int NPC = 32 * RB / 1024;                     // LDS-DMA pieces per wave and image (32 rows)
-  constexpr int BUF = 2 * KT * RB;  // K image | V image
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+  constexpr int BUF = DqLds<KT, DH>::BUF;  // K image | V image
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int r = l & 31, h2 = l >> 5;
-  int tile_x = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
-  stagger_by_wave_slot((xcd_order >> 8) & 0xff);
-  if (xcd_order & 1) xcd_block_order((Sq + 127) / 128, H, tile_x, head, b);
   const size_t row0 = (size_t)b * S;
   const int q = tile_x * 128 + w * 32 + r;
   const int hoff = head * DH;
@@ -535,6 +550,64 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
   }
 }
 
+template <int KT, int DH>
+__global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                          const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO, int ldo,
+                                                          const float* __restrict__ LSE, const float* __restrict__ delta,
+                                                          bf16_t* __restrict__ dQ, int ldd, int S, int Sq, int qoff, int H, float scale, int xcd_order) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DqLds<KT, DH>::BYTES];
+  int tile_x = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  stagger_by_wave_slot((xcd_order >> 8) & 0xff);
+  if (xcd_order & 1) xcd_block_order((Sq + 127) / 128, H, tile_x, head, b);
+  attn_dq2_block<KT, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile_x, head, b, smem);
+}
+
+// ---- the pair as ONE launch with the two kinds of blocks mixed on every CU --------------------------------------------------------------------------
+// Launched separately (dK/dV on the caller's stream, dQ forked beside it), the two grids do not really run side by side: the first kernel's blocks
+// take both slots of every CU, the second kernel's blocks enter as those drain, and a CU mostly holds two blocks of the SAME kernel - two key-owner
+// blocks each asking the LDS port for 96 cycles per wave and sub-tile.  Here a block learns its CU (HW_ID / XCC_ID), draws a per-CU ticket and takes
+// the role the ticket's parity names - the CU's two resident blocks are then one of each kind whenever both kinds have tiles left - and claims the next
+// tile of that role from a device-side queue (or of the other role once its own is exhausted).  Which block computes which tile does not change a single
+// bit of the result: every tile's arithmetic is self-contained.
+struct PairState {            // one slot of the library's device-side scheduling state, zeroed by a memset node in front of every launch
+  unsigned head[2];           // next unclaimed tile: [0] key-owner tiles, [1] query-owner tiles
+  unsigned pad[14];
+  unsigned cu_ticket[2048];   // arrival counter per CU, indexed by (XCC id, SE id, SH id, CU id): 3 + 3 + 1 + 4 bits
+};
+__device__ PairState g_pair_state[8];
+
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, int ld,
+                                                               const bf16_t* __restrict__ dO, int ldo, const float* __restrict__ LSE,
+                                                               const float* __restrict__ delta, bf16_t* __restrict__ dQ, bf16_t* __restrict__ dK,
+                                                               bf16_t* __restrict__ dV, int ldd, int B, int S, int Sq, int qoff, int H, float scale, int slot) {
+  constexpr int LDS = DkvLds<128, DH>::BYTES > DqLds<128, DH>::BYTES ? DkvLds<128, DH>::BYTES : DqLds<128, DH>::BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS];
+  PairState& ps = g_pair_state[slot];
+  const unsigned n_kv = (unsigned)(((S + 127) / 128) * H * B), n_q = (unsigned)(((Sq + 127) / 128) * H * B);
+  int* bc = (int*)smem;  // (the decision travels through LDS before any tile data does)
+  if (threadIdx.x == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15;  // HW_REG_XCC_ID
+    const unsigned cu = ((xcc & 7) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15);
+    unsigned role = atomicAdd(&ps.cu_ticket[cu], 1u) & 1u;
+    unsigned tile = atomicAdd(&ps.head[role], 1u);
+    if (tile >= (role ? n_q : n_kv)) { role ^= 1u; tile = atomicAdd(&ps.head[role], 1u); }
+    bc[0] = (int)role;
+    bc[1] = (int)tile;
+  }
+  __syncthreads();
+  const int role = bc[0], tile = bc[1];
+  __syncthreads();  // everybody has read the decision before the tile data overwrites it
+  if (role == 0) {
+    const int nt = (S + 127) / 128;
+    attn_dkv2_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
+  } else {
+    const int nt = (Sq + 127) / 128;
+    attn_dq2_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
+  }
+}
+
 int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
                   float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st) {
   if (Sq <= 0) { Sq = S; qoff = 0; }
@@ -550,6 +623,19 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     else hipLaunchKernelGGL(attn_delta_kernel<32>, dim3(cdiv(pairs * 4, 256)), dim3(256), 0, st, O, dO, ldo, delta, B, S, Sq, qoff, H);
     rc = check_launch("attn_delta");
     if (rc) return rc;
+  }
+  // A/B (debug bit 524288): the pair as one launch with mixed block roles (attn_bwd_pair_kernel)
+  if ((parts & 6) == 6 && (g_variant & 524288)) {
+    static int next_slot = 0;
+    const int slot = next_slot;
+    next_slot = (next_slot + 1) & 7;
+    PairState* base = nullptr;
+    HIPRC(hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_pair_state)));
+    HIPRC(hipMemsetAsync(base + slot, 0, sizeof(PairState), st));
+    const int blocks = (cdiv(S, 128) + cdiv(Sq, 128)) * H * B;
+    if (Dh == 64) hipLaunchKernelGGL((attn_bwd_pair_kernel<64>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot);
+    else hipLaunchKernelGGL((attn_bwd_pair_kernel<32>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot);
+    return check_launch("attn_bwd_pair");
   }
   // dK/dV and dQ are independent (disjoint outputs, shared read-only inputs).  Their grids rarely fill a whole number of
   // block rounds (encoder: 672 blocks on 512 slots), so when both are requested they are forked onto two streams and run
