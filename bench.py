@@ -14,7 +14,7 @@ prints ONE JSON line (the task contract):
                         memory through smb_vision_amd.feed.VolumeFeeder (copy stream + device-side ScaleIntensityRange / pad / crop / permute) and
                         a NEW mask from the bit-exact MaskGenerator with host-built token lists; same barrier protocol.  PCIe-inclusive, therefore
                         reported beside `value`, never as it.
-  roofline              dominant kernel = the decoder attention backward (attn_dkv2_kernel running beside attn_dq2_kernel, S = 20,480, 6 heads),
+  roofline              dominant kernel = the decoder attention backward (attn_bwd_pair_kernel: key-owner and query-owner blocks in ONE launch, S = 20,480, 6 heads),
                         timed with HIP events on its launch stream: `frac` counts the ALGORITHMIC five products (S, dP, dV, dK, dQ: 10 S^2 Dh H FLOP),
                         `executed_frac` the seven products the two kernels execute (dQ's kernel recomputes S and dP); `dkv` is the dK/dV kernel alone;
                         `step` the whole-step figure (18.46 TFLOP algorithmic fwd+bwd per volume).  Peak 2.5 PFLOP/s dense bf16.
@@ -75,7 +75,7 @@ def build(rank, device, cfg_kw):
 
 def kernel_roofline(device, iters=20, warm=10):
     """Decoder attention backward at the bench shape, timed with HIP events on the stream it is launched on: the dK/dV kernel alone, the dQ
-    kernel alone, and the pair as the step runs it (dQ forked onto the library's side stream and joined back before the second event)."""
+    kernel alone, and the pair as the step runs it (one launch with the two kinds of blocks mixed per CU, attention_bwd.hip)."""
     from smb_vision_amd import ops
     B, S, H = 1, 20480, 6
     w = H * 64
@@ -511,7 +511,7 @@ def main():
             except Exception:
                 pass
             pair_s = kr["pair"] * 1e-3
-            line["roofline"] = {"bound": "mfma", "kernel": "decoder attention backward: attn_dkv2_kernel beside attn_dq2_kernel (S=20480, H=6, Dh=64)",
+            line["roofline"] = {"bound": "mfma", "kernel": "decoder attention backward: attn_bwd_pair_kernel - key-owner (dK/dV) and query-owner (dQ) blocks mixed per CU in one launch (S=20480, H=6, Dh=64)",
                                 "achieved": 5 * unit / pair_s / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 5 * unit / pair_s / 1e12 / MFMA_PEAK_TFLOPS,
                                 "executed_frac": 7 * unit / pair_s / 1e12 / MFMA_PEAK_TFLOPS, "traffic": traffic, "launch_ms": kr["pair"],
                                 "flop_per_launch": 5 * unit, "executed_flop_per_launch": 7 * unit,

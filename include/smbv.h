@@ -53,7 +53,7 @@ int smbv_last_error(char* buf, size_t len);               /* copies the thread's
  * arithmetic (process-wide, not thread-safe; 0 = the shipped selection).  Bits: 32 register-staged GEMMs; 256 first-generation 128x128 NT
  * GEMM everywhere / 131072 second-generation ring NT GEMM everywhere (default: by shape); 512 four-slot ring; 262144 ring with 64-deep K slices; 1024 no mixed-tile NT launches (all tiles 128 x 128); 2048 attention forward with the guarded sweep only (no optimistic first sweep); 4096 delta = rowsum(dO * O) by its own launch instead of the
  * out-projection input-gradient epilogue; 8192 attention dQ and dK/dV on
- * one stream; 16384 weight- and input-gradient GEMMs on one stream; 32768 / 65536 TN tile selection; bits 20-23 GEMM ablation (timing only); 1<<24 attention forward on the plain (tile, head, batch) grid instead of the
+ * one stream (with 524288); 524288 attention backward as two launches (dK/dV, dQ) instead of the one mixed-role launch; 16384 weight- and input-gradient GEMMs on one stream; 32768 / 65536 TN tile selection; bits 20-23 GEMM ablation (timing only); 1<<24 attention forward on the plain (tile, head, batch) grid instead of the
  * XCD-aware block order; 1<<25 attention backward kernels on the XCD-aware block order; bits 26-28 start-up stagger
  * units of the attention kernels (forward default 2, backward 0), 1<<29 no stagger; 1<<30 the library's side streams at the lowest priority (read once, when
  * they are created). */

@@ -624,8 +624,9 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     rc = check_launch("attn_delta");
     if (rc) return rc;
   }
-  // A/B (debug bit 524288): the pair as one launch with mixed block roles (attn_bwd_pair_kernel)
-  if ((parts & 6) == 6 && (g_variant & 524288)) {
+  // both products: ONE launch with mixed block roles (attn_bwd_pair_kernel: -1.3 % encoder, -2.9 % decoder, -3.7 % at head_dim 32, -6.4 % at S = 20,480 x
+  // 12 heads against the two launches side by side, bitwise the same gradients: tools/attn_pair_ab.py); debug bit 524288 keeps the two launches
+  if ((parts & 6) == 6 && !(g_variant & 524288)) {
     static int next_slot = 0;
     const int slot = next_slot;
     next_slot = (next_slot + 1) & 7;

@@ -17,3 +17,5 @@ for _ in range(3):
     torch.cuda.synchronize()
     ops.attention_bwd(qkv, O, dO, lse, 1, S, H, parts=4, out=out)
     torch.cuda.synchronize()
+    ops.attention_bwd(qkv, O, dO, lse, 1, S, H, parts=6, out=out)   # the shipped form: one launch, mixed block roles (attn_bwd_pair_kernel)
+    torch.cuda.synchronize()

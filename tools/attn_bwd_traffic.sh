@@ -19,20 +19,19 @@ def collect(sub, counter):
             if r.get("Counter_Name") != counter:
                 continue
             k = r["Kernel_Name"]
-            for name in ("attn_dkv2_kernel", "attn_dq2_kernel"):
+            for name in ("attn_dkv2_kernel", "attn_dq2_kernel", "attn_bwd_pair_kernel"):
                 if name in k:
                     vals.setdefault(name, []).append(float(r["Counter_Value"]))
     return vals
 fetch, write = collect("fetch", "FETCH_SIZE"), collect("write", "WRITE_SIZE")
 res = {"unit_note": "rocprofv3 FETCH_SIZE / WRITE_SIZE are reported in kilobytes; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B)", "kernels": {}}
-tot = 0.0
-for name in ("attn_dkv2_kernel", "attn_dq2_kernel"):
+for name in ("attn_dkv2_kernel", "attn_dq2_kernel", "attn_bwd_pair_kernel"):
     f = sorted(fetch.get(name, [0]))[len(fetch.get(name, [0])) // 2] * 1024 * 2
     w = sorted(write.get(name, [0]))[len(write.get(name, [0])) // 2] * 1024
     res["kernels"][name] = {"fetch_bytes": f, "write_bytes": w, "launches_seen": len(fetch.get(name, []))}
-    tot += f + w
-res["traffic_bytes_per_launch"] = tot
-res["what"] = "decoder attention backward (S=20480, H=6): dK/dV kernel + dQ kernel, fabric-side bytes per launch pair"
+pk = res["kernels"]["attn_bwd_pair_kernel"]
+res["traffic_bytes_per_launch"] = pk["fetch_bytes"] + pk["write_bytes"]
+res["what"] = "decoder attention backward (S=20480, H=6): attn_bwd_pair_kernel (the shipped single launch), fabric-side bytes per launch; the two standalone kernels beside it"
 json.dump(res, open(dst, "w"), indent=1)
 print(json.dumps(res))
 PY
