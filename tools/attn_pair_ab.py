@@ -1,11 +1,11 @@
 """The attention backward pair as ONE launch with per-CU mixed block roles (variant 0, the default) against two launches on two streams (variant 524288): interleaved
-rounds in one process, bitwise comparison of the gradients, at the step's shapes.  usage: attn_pair_ab.py"""
+rounds in one process, bitwise comparison of the gradients, at the step's shapes.  usage: attn_pair_ab.py [variant bits ...]   (16 = resident-balance role policy)"""
 import sys, os, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from smb_vision_amd import ops, _lib
 lib = _lib.load()
-variants = [0, 524288]
+variants = [int(a) for a in sys.argv[1:]] or [0, 524288]
 ROUNDS, ITERS = 9, 6
 def t_of(fn):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
