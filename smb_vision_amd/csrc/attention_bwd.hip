@@ -580,7 +580,7 @@ template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, int ld,
                                                                const bf16_t* __restrict__ dO, int ldo, const float* __restrict__ LSE,
                                                                const float* __restrict__ delta, bf16_t* __restrict__ dQ, bf16_t* __restrict__ dK,
-                                                               bf16_t* __restrict__ dV, int ldd, int B, int S, int Sq, int qoff, int H, float scale, int slot, int policy) {
+                                                               bf16_t* __restrict__ dV, int ldd, int B, int S, int Sq, int qoff, int H, float scale, int slot) {
   constexpr int LDS = DkvLds<128, DH>::BYTES > DqLds<128, DH>::BYTES ? DkvLds<128, DH>::BYTES : DqLds<128, DH>::BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS];
   PairState& ps = g_pair_state[slot];
@@ -590,26 +590,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __r
     const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
     const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15;  // HW_REG_XCC_ID
     const unsigned cu = ((xcc & 7) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15);
-    unsigned role;
-    if (policy == 0) {
-      role = atomicAdd(&ps.cu_ticket[cu], 1u) & 1u;  // arrivals on a CU alternate
-    } else {  // A/B: balance what is RESIDENT on the CU (key-owner blocks minus query-owner blocks; every block undoes its count when it ends)
-      const int old = atomicAdd((int*)&ps.cu_ticket[cu], 1);
-      role = 0;
-      if (old > 0) { atomicAdd((int*)&ps.cu_ticket[cu], -2); role = 1; }
-    }
+    // arrivals on a CU alternate (balancing what is RESIDENT on the CU instead - a counter every block undoes when it ends - measured the same:
+    // profiles/r03_attn_pair_ab.txt)
+    unsigned role = atomicAdd(&ps.cu_ticket[cu], 1u) & 1u;
     unsigned tile = atomicAdd(&ps.head[role], 1u);
-    if (tile >= (role ? n_q : n_kv)) {
-      if (policy) atomicAdd((int*)&ps.cu_ticket[cu], role ? 2 : -2);
-      role ^= 1u;
-      tile = atomicAdd(&ps.head[role], 1u);
-    }
+    if (tile >= (role ? n_q : n_kv)) { role ^= 1u; tile = atomicAdd(&ps.head[role], 1u); }
     bc[0] = (int)role;
     bc[1] = (int)tile;
-    bc[2] = (int)cu;
   }
   __syncthreads();
-  const int role = bc[0], tile = bc[1], my_cu = bc[2];
+  const int role = bc[0], tile = bc[1];
   __syncthreads();  // everybody has read the decision before the tile data overwrites it
   if (role == 0) {
     const int nt = (S + 127) / 128;
@@ -618,7 +608,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __r
     const int nt = (Sq + 127) / 128;
     attn_dq2_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
   }
-  if (policy && threadIdx.x == 0) atomicAdd((int*)&ps.cu_ticket[my_cu], role ? 1 : -1);
 }
 
 int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
@@ -647,8 +636,8 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     HIPRC(hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_pair_state)));
     HIPRC(hipMemsetAsync(base + slot, 0, sizeof(PairState), st));
     const int blocks = (cdiv(S, 128) + cdiv(Sq, 128)) * H * B;
-    if (Dh == 64) hipLaunchKernelGGL((attn_bwd_pair_kernel<64>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot, (g_variant & 16) ? 1 : 0);
-    else hipLaunchKernelGGL((attn_bwd_pair_kernel<32>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot, (g_variant & 16) ? 1 : 0);
+    if (Dh == 64) hipLaunchKernelGGL((attn_bwd_pair_kernel<64>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot);
+    else hipLaunchKernelGGL((attn_bwd_pair_kernel<32>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot);
     return check_launch("attn_bwd_pair");
   }
   // dK/dV and dQ are independent (disjoint outputs, shared read-only inputs).  Their grids rarely fill a whole number of
