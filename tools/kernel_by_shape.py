@@ -28,7 +28,7 @@ def union(pred):
             cur_e = max(cur_e, e)
     if cur_e is not None: tot += cur_e - cur_s
     return tot / 1e6 / steps
-fam = {"attention backward (dkv2 | dq2 | delta)": lambda n: "attn_dkv" in n or "attn_dq" in n or "attn_delta" in n, "attention forward": lambda n: "attn_fwd" in n,
+fam = {"attention backward (pair | dkv2 | dq2 | delta)": lambda n: "attn_bwd_pair" in n or "attn_dkv" in n or "attn_dq" in n or "attn_delta" in n, "attention forward": lambda n: "attn_fwd" in n,
        "GEMMs (nt | tn | reduce_tn)": lambda n: "gemm_" in n or "reduce_tn" in n or "reduce_slabs" in n or "reduce_xsum" in n, "NT GEMMs": lambda n: "gemm_nt" in n,
        "TN GEMMs + reductions": lambda n: "gemm_tn" in n or "reduce_tn" in n or "reduce_slabs" in n or "reduce_xsum" in n,
        "LayerNorm (fwd | bwd | reduce_cols)": lambda n: "ln_" in n or "reduce_cols" in n, "optimizer + weight preparation": lambda n: "adamw" in n or "sqnorm" in n or "prep_weights" in n,
