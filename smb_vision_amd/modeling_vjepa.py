@@ -531,17 +531,45 @@ def make_target_encoder(model: SmbVJEPA2Model) -> SmbVJEPA2Model:
     return t
 
 
+_TARGET_STREAMS = {}
+
+
+def _target_stream(device):
+    key = (device.type, device.index)
+    if key not in _TARGET_STREAMS:
+        _TARGET_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _TARGET_STREAMS[key]
+
+
 def vjepa_loss(model, target_encoder, momentum_encoder, inputs):
     """VJEPATrainer.compute_loss (run_vjepa.py:110-141): online forward, frozen target forward, L1, EMA update — in that order."""
     # (smbv_needed: compute_loss reads predictor_output from the online model and target_hidden_state from the target encoder, nothing else -
     #  the last encoder block of each then only works on the rows those are made of; SMBV_VJEPA_FULL_ENCODER=1 keeps the unrestricted forward)
     full = os.environ.get("SMBV_VJEPA_FULL_ENCODER", "0") == "1"
+    # The frozen target encoder's forward does not depend on the online forward (its weights are last step's EMA): it is enqueued on a second stream
+    # so that the two forwards' kernels run side by side and fill each other's partial last rounds (an encoder's attention grid is 2.5 rounds of block
+    # slots at S = 20,480 x 12 heads); SMBV_VJEPA_SERIAL_TARGET=1 keeps it behind the online forward on the caller's stream
+    pix = inputs["pixel_values_videos"]
+    cur = torch.cuda.current_stream(pix.device) if pix.is_cuda else None
+    side = None if (cur is None or os.environ.get("SMBV_VJEPA_SERIAL_TARGET", "0") == "1") else _target_stream(pix.device)
+
+    def run_target():
+        with torch.no_grad():
+            return target_encoder(pixel_values_videos=pix, context_mask=inputs["context_mask"], target_mask=inputs["target_mask"], skip_predictor=True,
+                                  smbv_needed=None if full else "target").target_hidden_state
+
+    if side is not None:
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            tgt = run_target()
     out = model(pixel_values_videos=inputs["pixel_values_videos"], context_mask=inputs["context_mask"], target_mask=inputs["target_mask"],
                 skip_predictor=False, smbv_needed=None if full else "context")
     pred = out.predictor_output.last_hidden_state
-    with torch.no_grad():
-        tgt = target_encoder(pixel_values_videos=inputs["pixel_values_videos"], context_mask=inputs["context_mask"],
-                             target_mask=inputs["target_mask"], skip_predictor=True, smbv_needed=None if full else "target").target_hidden_state
+    if side is not None:
+        cur.wait_stream(side)
+        tgt.record_stream(cur)
+    else:
+        tgt = run_target()
     loss = l1_loss(pred, tgt)
     if momentum_encoder is not None:
         momentum_encoder.update(model)
