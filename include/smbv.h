@@ -297,6 +297,10 @@ typedef struct smbv_vjepa_cfg {
                                       else) - and the LAST encoder block computes queries, projection and MLP for those enc_needed rows only (keys / values: all
                                       N tokens; exact for the rows produced, as the last MIM decoder block).  enc_out and the rows ctx_idx names are then
                                       COMPACT: [B * enc_needed, d], row b * enc_needed + j.  Needs n_masks <= 1 */
+  int pred_tgt_first;              /* 1: the caller placed the target tokens in slots 0 .. Ntgt-1 of every predictor sequence (tgt_slot < Ntgt, ctx_slot >= Ntgt;
+                                      any order is the same function: pred_pos carries the positions, modeling_vjepa.py:718-746 sorts and unsorts).  The predictor's
+                                      output is read at the target tokens only (:737-738), so its LAST block then computes those Ntgt rows only.  0: slots in any
+                                      order (e.g. the reference's position-sorted one), every block over all Nctx + Ntgt rows */
 } smbv_vjepa_cfg;
 
 /* fp32 tensors of one VJEPA2Layer: norm1, attention.{query,key,value,proj}.{weight,bias}, norm2, mlp.{fc1,fc2} */

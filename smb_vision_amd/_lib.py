@@ -82,7 +82,7 @@ class AdamHyper(C.Structure):
 
 class VjepaCfg(_Cfg):
     _fields_ = [(n, C.c_int) for n in ("struct_bytes", "B", "T", "H", "W", "ps", "ts", "N", "Nctx", "Ntgt", "d", "heads", "ff", "layers", "pd", "pheads", "pff", "players")] + \
-               [("ln_eps", C.c_float), ("n_masks", C.c_int), ("enc_needed", C.c_int)]
+               [("ln_eps", C.c_float), ("n_masks", C.c_int), ("enc_needed", C.c_int), ("pred_tgt_first", C.c_int)]
 
 
 BLOCK_FIELDS = ("ln1_w", "ln1_b", "q_w", "k_w", "v_w", "q_b", "k_b", "v_b", "proj_w", "proj_b", "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")

@@ -35,6 +35,8 @@ static BlockDims venc_dims(const smbv_vjepa_cfg& c, const smbv_vjepa_io* io) {
 static inline int vmasks(const smbv_vjepa_cfg& c) { return c.n_masks > 1 ? c.n_masks : 1; }
 // rows of every volume whose last-block output is produced (0 = all: the last block is not ranged)
 static inline int vneed(const smbv_vjepa_cfg& c) { return (c.enc_needed > 0 && c.enc_needed < c.N) ? c.enc_needed : 0; }
+// rows of every predictor sequence the last predictor block computes (0 = all): the target slots when the caller put them first
+static inline int vpneed(const smbv_vjepa_cfg& c) { const int dh = c.pd / c.pheads; return (c.pred_tgt_first && c.Nctx > 0 && (dh == 64 || dh == 32)) ? c.Ntgt : 0; }
 static inline int vpb(const smbv_vjepa_cfg& c) { return c.B * vmasks(c); }  // predictor sequences: mask pair m, volume b -> m * B + b
 static BlockDims vpred_dims(const smbv_vjepa_cfg& c, const smbv_vjepa_io* io) {
   const int Sp = c.Nctx + c.Ntgt;
@@ -107,15 +109,22 @@ static void vcarve(const smbv_vjepa_cfg& c, void* base, VjepaWs& w) {
     dr.rows = (size_t)c.B * vneed(c);
     bwd_scratch_requirements(dr, nd);
   }
+  if (vpneed(c)) {
+    BlockDims dr = dp;
+    dr.rows = (size_t)vpb(c) * vpneed(c);
+    bwd_scratch_requirements(dr, nd);
+  }
   auto tn = [&](size_t M, int n1, int n2) { nd.scratch = std::max(nd.scratch, gemm_tn_workspace_bytes((int)M, n1, n2)); };
   tn(Re, c.d, K); tn(Rc, c.pd, c.d); tn(Rt, c.d, c.pd);
   nd.scratch = std::max(nd.scratch, colsum_workspace_bytes((int)std::max(Re, Rp), std::max(std::max(c.d, c.pd), K)));
   carve_bwd_scratch(cv, w.sc, nd);
   w.sc.gath0 = nullptr;
   w.sc.gath1 = nullptr;
-  if (vneed(c) && c.B > 1) {  // gathered copies of the ranged rows (block.hip: contiguous without them only for B == 1)
-    w.sc.gath0 = cv.take<bf16_t>((size_t)c.B * vneed(c) * c.d);
-    w.sc.gath1 = cv.take<bf16_t>((size_t)c.B * vneed(c) * c.d);
+  {  // gathered copies of the ranged rows (block.hip: contiguous without them only for one sequence)
+    size_t ge = 0;
+    if (vneed(c) && c.B > 1) ge = std::max(ge, (size_t)c.B * vneed(c) * c.d);
+    if (vpneed(c) && vpb(c) > 1) ge = std::max(ge, (size_t)vpb(c) * vpneed(c) * c.pd);
+    if (ge) { w.sc.gath0 = cv.take<bf16_t>(ge); w.sc.gath1 = cv.take<bf16_t>(ge); }
   }
   w.total = (cv.off + 255) & ~(size_t)255;
 }
@@ -182,10 +191,13 @@ static int vjepa_forward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, c
   }
   RC(scatter_rows_idx_f32(W.ctx_emb, W.xp[0], io.ctx_slot, (long)Rc, c.Nctx, Sp, c.pd, st));
   RC(fill_rows_idx_f32(W.xp[0], p.mask_token, io.tgt_slot, (long)Rt, c.Ntgt, Sp, c.pd, st));
-  for (int l = 0; l < c.players; l++) RC(layer_fwd(vblock(p.pred[l]), W.pred[l], dp, W.sc, W.xp[l], W.xp[l + 1], nullptr, 0, 0, st));
-  RC(layernorm_fwd(W.xp[c.players], p.pred_ln_w, p.pred_ln_b, W.pred_ln, W.pred_mean, W.pred_rstd, (int)Rp, c.pd, c.ln_eps, 0, 0, 0, st));
+  // pred_tgt_first: the target tokens sit in slots 0 .. Ntgt-1; the last block computes those rows only, the final LayerNorm output is compact [P * Ntgt, pd]
+  const int pneed = vpneed(c);
+  for (int l = 0; l < c.players; l++) RC(layer_fwd(vblock(p.pred[l]), W.pred[l], dp, W.sc, W.xp[l], W.xp[l + 1], nullptr, l == c.players - 1 ? pneed : 0, 0, st));
+  if (pneed) RC(layernorm_fwd(W.xp[c.players], p.pred_ln_w, p.pred_ln_b, W.pred_ln, W.pred_mean, W.pred_rstd, vpb(c) * pneed, c.pd, c.ln_eps, pneed, Sp, 0, st));
+  else RC(layernorm_fwd(W.xp[c.players], p.pred_ln_w, p.pred_ln_b, W.pred_ln, W.pred_mean, W.pred_rstd, (int)Rp, c.pd, c.ln_eps, 0, 0, 0, st));
   // unsort + keep the target tokens (:737-738) == gather the target slots; then proj (pd -> d)
-  RC(gather_rows_idx_bf16(W.pred_ln, W.tgt_bf, io.tgt_slot, (long)Rt, c.Ntgt, Sp, c.pd, st));
+  RC(gather_rows_idx_bf16(W.pred_ln, W.tgt_bf, io.tgt_slot, (long)Rt, c.Ntgt, pneed ? pneed : Sp, c.pd, st));
   {
     GemmEpi e; e.bias = p.pproj_b; e.out_f32 = io.pred_out; e.ld_of = c.d;
     RC(gemm_nt(W.tgt_bf, c.pd, W.pproj, c.pd, (int)Rt, c.d, c.pd, e, st));
@@ -227,13 +239,16 @@ static int vjepa_backward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, 
     RC(gemm_nt(W.dpred_bf, c.d, W.pproj_t, c.d, (int)Rt, c.pd, c.d, e, st));
   }
   // predictor.layernorm: only the target slots receive gradient
+  const int pneed = vpneed(c);
   HIPRC(hipMemsetAsync(W.d_lnfull, 0, Rp * c.pd * sizeof(bf16_t), st));
-  RC(scatter_rows_idx_bf16(W.d_tgt, W.d_lnfull, io.tgt_slot, (long)Rt, c.Ntgt, Sp, c.pd, st));
-  RC(layernorm_bwd(W.d_lnfull, W.xp[c.players], W.pred_mean, W.pred_rstd, p.pred_ln_w, nullptr, W.g0, W.gb0, gr.pred_ln_w, gr.pred_ln_b, (int)Rp, c.pd, 0,
-                   0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
+  RC(scatter_rows_idx_bf16(W.d_tgt, W.d_lnfull, io.tgt_slot, (long)Rt, c.Ntgt, pneed ? pneed : Sp, c.pd, st));
+  if (pneed) RC(layernorm_bwd(W.d_lnfull, W.xp[c.players], W.pred_mean, W.pred_rstd, p.pred_ln_w, nullptr, W.g0, W.gb0, gr.pred_ln_w, gr.pred_ln_b, vpb(c) * pneed, c.pd,
+                              pneed, Sp, 0, W.sc.scratch, W.sc.scratch_bytes, st));   // compact dy / statistics; gradients land at the slots' rows of the full layout
+  else RC(layernorm_bwd(W.d_lnfull, W.xp[c.players], W.pred_mean, W.pred_rstd, p.pred_ln_w, nullptr, W.g0, W.gb0, gr.pred_ln_w, gr.pred_ln_b, (int)Rp, c.pd, 0,
+                        0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
   RC(mark());  // [0] predictor.proj + predictor.layernorm
   for (int l = c.players - 1; l >= 0; l--) {
-    RC(layer_bwd(vblock(p.pred[l]), vblock(gr.pred[l]), W.pred[l], dp, W.sc, W.xp[l], W.g0, W.gb0, W.g1, W.gb1, 0, 0, st));
+    RC(layer_bwd(vblock(p.pred[l]), vblock(gr.pred[l]), W.pred[l], dp, W.sc, W.xp[l], W.g0, W.gb0, W.g1, W.gb1, l == c.players - 1 ? pneed : 0, 0, st));
     RC(mark());  // [1 .. players] predictor layers, last first
   }
   // predictor input: mask-token gradient = sum over the target slots; context slots flow into predictor_embeddings

@@ -264,9 +264,13 @@ class SmbVJEPA2Model(PreTrainedModel):
         B, N = cms[0].shape[0], self.num_patches
         cm, tm = torch.cat(cms, dim=0), torch.cat(tms, dim=0)           # [M*B, Nctx], [M*B, Ntgt]
         pos = torch.cat([cm, tm], dim=1)
-        order = torch.argsort(pos, dim=1, stable=True)
-        rev = torch.argsort(order, dim=1, stable=True)
         n_ctx = cm.shape[1]
+        # Slots of the predictor sequence.  The reference sorts the tokens by position and unsorts the output (modeling_vjepa.py:718-746); with RoPE on
+        # explicit position ids any order is the same function.  Targets first (by position), then the context (by position): the predictor's output is
+        # read at the target tokens only, so its last block works on slots 0 .. Ntgt-1 alone (smbv_vjepa_cfg.pred_tgt_first).
+        key = pos + torch.cat([torch.full_like(cm, N), torch.zeros_like(tm)], dim=1)
+        order = torch.argsort(key, dim=1, stable=True)
+        rev = torch.argsort(order, dim=1, stable=True)
         vol = torch.arange(B, device=device).repeat(len(cms)).unsqueeze(1)  # sequence -> volume it reads
         out = dict(tgt_idx=tm.to(torch.int32).contiguous(), pred_pos=torch.gather(pos, 1, order).to(torch.int32).contiguous(),
                    ctx_slot=rev[:, :n_ctx].to(torch.int32).contiguous(), tgt_slot=rev[:, n_ctx:].to(torch.int32).contiguous(), n_masks=len(cms),
@@ -298,6 +302,7 @@ class SmbVJEPA2Model(PreTrainedModel):
         cfg = self._cfg_struct(B, n_ctx, n_tgt)
         cfg.n_masks = idx["n_masks"]
         cfg.enc_needed = idx["enc_needed"]
+        cfg.pred_tgt_first = 1   # _index_plumbing puts the target slots first
         need = lib.smbv_vjepa_workspace_bytes(C.byref(cfg))
         if need == 0:
             raise ValueError("smbv_vjepa_workspace_bytes: " + _lib.last_error())
