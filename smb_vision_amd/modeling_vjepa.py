@@ -302,7 +302,7 @@ class SmbVJEPA2Model(PreTrainedModel):
         cfg = self._cfg_struct(B, n_ctx, n_tgt)
         cfg.n_masks = idx["n_masks"]
         cfg.enc_needed = idx["enc_needed"]
-        cfg.pred_tgt_first = 1   # _index_plumbing puts the target slots first
+        cfg.pred_tgt_first = 0 if os.environ.get("SMBV_VJEPA_PRED_FULL", "0") == "1" else 1   # _index_plumbing puts the target slots first (A/B switch)
         need = lib.smbv_vjepa_workspace_bytes(C.byref(cfg))
         if need == 0:
             raise ValueError("smbv_vjepa_workspace_bytes: " + _lib.last_error())
