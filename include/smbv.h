@@ -17,11 +17,12 @@
  *   - stream-ordered; callable from any host thread (autograd's backward thread included), but the step / block / attention-backward entry
  *     points fork onto the per-device side streams below and are NOT safe to run from two host threads on the SAME device at once (the library
  *     serialises the fork / join bookkeeping with a per-device mutex; the side streams themselves are shared);
- *   - state inside the library: the immutable code object; a thread-local error string; per device, ONE private non-blocking side
- *     stream and a few events created on first use and kept for the life of the process (attention backward runs its dQ and dK/dV
- *     kernels side by side, the block backward its weight-gradient products beside the input-gradient ones; everything forked is
- *     joined back into `stream` before the call returns); and the kernel-selection word of smbv_debug_set_variant() below (0 unless
- *     a tuning tool sets it).  Nothing else persists between calls.
+ *   - state inside the library: the immutable code object; a thread-local error string; per device, two private non-blocking side streams and a
+ *     few events created on first use and kept for the life of the process (the block backward runs its weight-gradient products beside the
+ *     input-gradient ones, the step forwards their weight casts beside the first kernels; everything forked is joined back into `stream` before the
+ *     call returns); a 64-KiB `__device__` array of scheduling words for the attention backward (eight slots used round-robin, the slot of a launch
+ *     is zeroed by a memset node on `stream` in front of it: block roles and tile queues of attn_bwd_pair_kernel - never results); and the
+ *     kernel-selection word of smbv_debug_set_variant() below (0 unless a tuning tool sets it).  Nothing else persists between calls.
  */
 #ifndef SMBV_H
 #define SMBV_H

@@ -16,3 +16,6 @@ print(f"total kernel time {tot/1e6/4:.2f} ms per step (4 steps)")
 for r in rows[:26]:
     print(f'{int(r["TotalDurationNs"])/1e6/4:8.3f} ms/step  {int(r["Calls"])/4:7.1f} calls/step  {float(r["AverageNs"])/1e3:9.1f} us avg  {r["Name"][:90]}')
 PY
+TRACE=$(find "$OUT" -name "*kernel_trace.csv" | head -1)
+python3 "$ROOT/tools/kernel_by_shape.py" "$TRACE" 4 > "$ROOT/gpurun_out/${TAG}_vjepa_kernel_by_shape.txt" || true
+head -40 "$ROOT/gpurun_out/${TAG}_vjepa_kernel_by_shape.txt"; tail -9 "$ROOT/gpurun_out/${TAG}_vjepa_kernel_by_shape.txt"
