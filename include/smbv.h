@@ -20,8 +20,8 @@
  *   - state inside the library: the immutable code object; a thread-local error string; per device, two private non-blocking side streams and a
  *     few events created on first use and kept for the life of the process (the block backward runs its weight-gradient products beside the
  *     input-gradient ones, the step forwards their weight casts beside the first kernels; everything forked is joined back into `stream` before the
- *     call returns); a 64-KiB `__device__` array of scheduling words for the attention backward (eight slots used round-robin, the slot of a launch
- *     is zeroed by a memset node on `stream` in front of it: block roles and tile queues of attn_bwd_pair_kernel - never results; attention-backward
+ *     call returns); a 64-KiB `__device__` array of scheduling words for the attention backward (eight slots used round-robin; a launch's last
+ *     block hands its slot back zeroed: block roles and tile queues of attn_bwd_pair_kernel - never results; attention-backward
  *     calls of one device are therefore expected on ONE stream at a time, as the step functions issue them); and the
  *     kernel-selection word of smbv_debug_set_variant() below (0 unless a tuning tool sets it).  Nothing else persists between calls.
  */

@@ -569,10 +569,11 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
 // the role the ticket's parity names - the CU's two resident blocks are then one of each kind whenever both kinds have tiles left - and claims the next
 // tile of that role from a device-side queue (or of the other role once its own is exhausted).  Which block computes which tile does not change a single
 // bit of the result: every tile's arithmetic is self-contained.
-struct PairState {            // one slot of the library's device-side scheduling state, zeroed by a memset node in front of every launch
-  unsigned head[2];           // next unclaimed tile: [0] key-owner tiles, [1] query-owner tiles
-  unsigned pad[14];
-  unsigned cu_ticket[2048];   // arrival counter per CU, indexed by (XCC id, SE id, SH id, CU id): 3 + 3 + 1 + 4 bits
+struct PairState {            // one slot of the library's device-side scheduling state (zero at module load; every launch leaves its slot as it found it)
+  unsigned head[2];           // next unclaimed tile: [0] key-owner tiles, [1] query-owner tiles - reset by the launch's last block
+  unsigned done;              // blocks of the running launch that have ended
+  unsigned pad[13];
+  unsigned cu_ticket[2048];   // arrival counter per CU, indexed by (XCC id, SE id, SH id, CU id): 3 + 3 + 1 + 4 bits - free-running, only its parity is used
 };
 __device__ PairState g_pair_state[8];
 
@@ -608,6 +609,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __r
     const int nt = (Sq + 127) / 128;
     attn_dq2_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
   }
+  // the block that ends last (every other block has claimed its tile long ago) hands the slot back zeroed: no memset node in front of the next launch
+  // (a fill kernel of ~8 us on the critical path, 16 per MIM step)
+  if (threadIdx.x == 0 && atomicAdd(&ps.done, 1u) == gridDim.x - 1) {
+    ps.head[0] = 0;
+    ps.head[1] = 0;
+    ps.done = 0;
+  }
 }
 
 int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
@@ -632,9 +640,6 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     static int next_slot = 0;
     const int slot = next_slot;
     next_slot = (next_slot + 1) & 7;
-    PairState* base = nullptr;
-    HIPRC(hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_pair_state)));
-    HIPRC(hipMemsetAsync(base + slot, 0, sizeof(PairState), st));
     const int blocks = (cdiv(S, 128) + cdiv(Sq, 128)) * H * B;
     if (Dh == 64) hipLaunchKernelGGL((attn_bwd_pair_kernel<64>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot);
     else hipLaunchKernelGGL((attn_bwd_pair_kernel<32>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot);
