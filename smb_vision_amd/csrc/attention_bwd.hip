@@ -573,7 +573,7 @@ struct PairState {            // one slot of the library's device-side schedulin
   unsigned head[2];           // next unclaimed tile: [0] key-owner tiles, [1] query-owner tiles - reset by the launch's last block
   unsigned done;              // blocks of the running launch that have ended
   unsigned pad[13];
-  unsigned cu_ticket[2048];   // arrival counter per CU, indexed by (XCC id, SE id, SH id, CU id): 3 + 3 + 1 + 4 bits - free-running, only its parity is used
+  unsigned cu_ticket[2048];   // arrival counter per CU, indexed by (XCC id, SE id, SH id, CU id): 3 + 3 + 1 + 4 bits - reset by the launch's last block
 };
 __device__ PairState g_pair_state[8];
 
@@ -611,10 +611,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __r
   }
   // the block that ends last (every other block has claimed its tile long ago) hands the slot back zeroed: no memset node in front of the next launch
   // (a fill kernel of ~8 us on the critical path, 16 per MIM step)
-  if (threadIdx.x == 0 && atomicAdd(&ps.done, 1u) == gridDim.x - 1) {
-    ps.head[0] = 0;
-    ps.head[1] = 0;
-    ps.done = 0;
+  __syncthreads();  // (the block's waves are done with the LDS the flag below travels through)
+  if (threadIdx.x == 0) bc[0] = atomicAdd(&ps.done, 1u) == gridDim.x - 1 ? 1 : 0;
+  __syncthreads();
+  if (bc[0]) {
+    if (threadIdx.x == 0) { ps.head[0] = 0; ps.head[1] = 0; ps.done = 0; }
+    for (int i = threadIdx.x; i < 2048; i += 256) ps.cu_ticket[i] = 0;   // every launch starts with "first arrival on a CU = key-owner block"
   }
 }
 
