@@ -324,6 +324,45 @@ def vit_large_leg(device, steps=4, warmup=2):
     return dt / steps * 1e3
 
 
+def reference_class_on_gpu(device, steps=3, warmup=2):
+    """The reference's model class on the SAME GPU, for scale (a diagnostic beside the metric; nothing of it is on the product path):
+    transformers.VideoMAEForPreTraining (src/run_mim.py:13-21) on the bench workload under bf16 autocast (the Trainer's --bf16) with torch clip + fused
+    AdamW, once with PyTorch-ROCm's own scaled_dot_product_attention ("sdpa": what the reference stack runs on an MI355X; flash-attn is not installed)
+    and once with only the attention swapped for the HIP kernels through transformers' attention registry ("smbv", smb_vision_amd/attention_plugin.py)."""
+    from transformers import VideoMAEConfig, VideoMAEForPreTraining
+    from smb_vision_amd.masking import MaskGenerator
+    from smb_vision_amd import attention_plugin
+    attention_plugin.register()
+    np.random.seed(42)
+    mask = MaskGenerator(512, 320, 32, 16, 0.65)().unsqueeze(0).to(device)
+    pix = torch.rand(1, 320, 1, 512, 512, generator=torch.Generator().manual_seed(1234)).to(device)
+    res = {}
+    for impl in ("sdpa", attention_plugin.NAME):
+        torch.manual_seed(42)
+        m = VideoMAEForPreTraining(VideoMAEConfig(**VIT_BASE, attn_implementation=impl)).to(device).train()
+        opt = torch.optim.AdamW(m.parameters(), lr=1.5e-4, betas=(0.9, 0.95), weight_decay=0.05, fused=True)
+        last = {}
+
+        def step():
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = m(pixel_values=pix, bool_masked_pos=mask)
+            out.loss.backward()
+            torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            last["loss"] = out.loss.detach()
+
+        for _ in range(warmup):
+            step()
+        dt = timed_region(step, steps, 1, device)
+        res[impl] = dict(ms_per_step=dt / steps * 1e3, loss=float(last["loss"]))
+        del m, opt
+        torch.cuda.empty_cache()
+    res["what"] = ("transformers.VideoMAEForPreTraining on this GPU, bf16 autocast, fwd + loss + bwd + torch clip + fused AdamW: 'sdpa' = PyTorch-ROCm's "
+                   "attention, 'smbv' = the same class with only the attention swapped for the HIP kernels via the attention registry")
+    return res
+
+
 def timed_region(step, steps, world, device):
     """EXACTLY `steps` steps between barrier + synchronize on both sides; returns the max over ranks of the elapsed seconds."""
     import torch.distributed as dist
@@ -353,7 +392,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--no-feed", action="store_true", help="skip the second timed region (new volume + mask per step through the VolumeFeeder)")
-    ap.add_argument("--no-extra-configs", action="store_true", help="skip config.vjepa_ms_per_step / config.vit_large_fp8_recompute_ms_per_step")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip config.vjepa_ms_per_step / config.vit_large_fp8_recompute_ms_per_step / config.reference_class_on_gpu")
     ap.add_argument("--no-reference-class", action="store_true", help="skip cpu_baseline.reference_class (transformers.VideoMAEForPreTraining on the host cores)")
     ap.add_argument("--no-trainer", action="store_true", help="skip config.trainer_ms_per_step (the HF-Trainer harness at full size)")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward only (diagnostic; not the metric)")
@@ -541,6 +580,10 @@ def main():
                                                    what="BASELINE.json config 5's model on one GPU: ViT-large MIM, fp8 e4m3 attention forward + per-layer recompute")
             except Exception as e:
                 line["config"]["vit_large_fp8_recompute_ms_per_step"], line["config"]["vit_large_error"] = None, repr(e)
+            try:
+                line["config"]["reference_class_on_gpu"] = reference_class_on_gpu(device)
+            except Exception as e:
+                line["config"]["reference_class_on_gpu"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and not args.tiny:
             try:
                 line["cpu_baseline"] = cpu_baseline(cpu_threads())

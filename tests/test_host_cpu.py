@@ -259,3 +259,23 @@ def test_cfg_struct_size_guard_and_abi_major():
     e = _lib.EncoderCfg()
     e.struct_bytes = 0
     assert lib.smbv_encoder_workspace_bytes(ctypes.byref(e)) == 0 and "struct_bytes" in _lib.last_error()
+
+
+def test_attention_plugin_registers_and_refuses_cpu():
+    """smb_vision_amd/attention_plugin.py: the name lands in transformers' attention registry (the reference's dispatch point,
+    src/models/vjepa/modeling_vjepa.py:345-364) and a model built with it fails loudly without a GPU - no CPU fallback."""
+    import torch
+    from transformers import VideoMAEConfig, VideoMAEForPreTraining
+    from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
+    from smb_vision_amd import attention_plugin
+    name = attention_plugin.register()
+    assert ALL_ATTENTION_FUNCTIONS[name] is attention_plugin.smbv_attention
+    cfg = VideoMAEConfig(image_size=32, patch_size=16, num_channels=1, num_frames=32, tubelet_size=16, hidden_size=128, num_hidden_layers=1,
+                         num_attention_heads=2, intermediate_size=256, decoder_num_attention_heads=2, decoder_hidden_size=128,
+                         decoder_num_hidden_layers=1, decoder_intermediate_size=256, attn_implementation=name)
+    model = VideoMAEForPreTraining(cfg)
+    mask = torch.zeros(1, 8, dtype=torch.bool)
+    mask[0, :5] = True
+    import pytest
+    with pytest.raises(RuntimeError, match="MI355X"):
+        model(pixel_values=torch.rand(1, 32, 1, 32, 32), bool_masked_pos=mask)
