@@ -14,6 +14,7 @@
 #include "smbv_common.h"
 #include "smbv_kernels.h"
 #include "block.h"
+#include <atomic>
 #include <type_traits>
 
 namespace smbv {
@@ -596,6 +597,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __r
     unsigned role = atomicAdd(&ps.cu_ticket[cu], 1u) & 1u;
     unsigned tile = atomicAdd(&ps.head[role], 1u);
     if (tile >= (role ? n_q : n_kv)) { role ^= 1u; tile = atomicAdd(&ps.head[role], 1u); }
+    // (the grid has exactly one block per tile, so the second queue cannot be exhausted as well; a block that found it so would idle, not run a tile twice)
+    if (tile >= (role ? n_q : n_kv)) role = 2u;
     bc[0] = (int)role;
     bc[1] = (int)tile;
   }
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __r
   if (role == 0) {
     const int nt = (S + 127) / 128;
     attn_dkv2_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
-  } else {
+  } else if (role == 1) {
     const int nt = (Sq + 127) / 128;
     attn_dq2_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
   }
@@ -639,9 +642,8 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
   // both products: ONE launch with mixed block roles (attn_bwd_pair_kernel: -1.3 % encoder, -2.9 % decoder, -3.7 % at head_dim 32, -6.4 % at S = 20,480 x
   // 12 heads against the two launches side by side, bitwise the same gradients: tools/attn_pair_ab.py); debug bit 524288 keeps the two launches
   if ((parts & 6) == 6 && !(g_variant & 524288)) {
-    static int next_slot = 0;
-    const int slot = next_slot;
-    next_slot = (next_slot + 1) & 7;
+    static std::atomic<unsigned> next_slot{0};   // consecutive launches use different slots; one stream at a time per device (include/smbv.h)
+    const int slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) & 7u);
     const int blocks = (cdiv(S, 128) + cdiv(Sq, 128)) * H * B;
     if (Dh == 64) hipLaunchKernelGGL((attn_bwd_pair_kernel<64>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot);
     else hipLaunchKernelGGL((attn_bwd_pair_kernel<32>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot);

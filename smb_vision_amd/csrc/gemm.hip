@@ -516,6 +516,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
 
 // TN with LDS-DMA staging (N1, N2 multiples of 128): 4 rows x 256 B per wave-instruction; the 32-byte-column XOR swizzle is
 // applied to the per-lane source address; rows beyond this split's token range read as zeros through the buffer bounds check.
+// (Round 3: the same kernel with 32-token slices through a four-slot ring - three slices in flight behind a counted vmcnt, one barrier per slice -
+// measured 0..12 % SLOWER at every shape of the step, profiles/r03_gemm_tn_ring_ab.txt: with two blocks per CU the other block's MFMAs already cover
+// a step's copy, and the ring doubles the barriers.  Not kept.)
 __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y, int ldy,
                                                              int M, int N1, int N2, float* __restrict__ out, int ldo, int tiles_1,
                                                              int mchunk, size_t slab_stride, float* __restrict__ xsum) {
@@ -801,6 +804,11 @@ __global__ void reduce_tn_kernel(float* __restrict__ out, const float* __restric
     const f32x4* p = (const f32x4*)slabs + i;
     f32x4 s = p[0];
     int z = 1;
+    for (; z + 7 < nslab; z += 8) {   // eight slabs in flight: the pass is bound by load latency, not by bytes 
+      const f32x4 a = p[z * slab_stride4], b = p[(z + 1) * slab_stride4], c = p[(z + 2) * slab_stride4], d = p[(z + 3) * slab_stride4];
+      const f32x4 e = p[(z + 4) * slab_stride4], f = p[(z + 5) * slab_stride4], g = p[(z + 6) * slab_stride4], h = p[(z + 7) * slab_stride4];
+      s += a; s += b; s += c; s += d; s += e; s += f; s += g; s += h;
+    }
     for (; z + 3 < nslab; z += 4) {
       const f32x4 a = p[z * slab_stride4], b = p[(z + 1) * slab_stride4], c = p[(z + 2) * slab_stride4], d = p[(z + 3) * slab_stride4];
       s += a; s += b; s += c; s += d;
