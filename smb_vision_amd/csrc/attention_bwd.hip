@@ -1,16 +1,17 @@
 // Fused multi-head self-attention backward (flash-style recompute from LSE), head_dim 64 and 32 (template parameter DH).
 // Autograd of src/models/videomae/modeling_videomae.py:196-223 (softmax(QK^T*scale) V).
 //
-// Three launches, no float atomics (bitwise reproducible):
-//   attn_delta   delta[q] = sum_d dO[q,d] * O[q,d]
-//   attn_dkv     key-owner: a block owns 128 keys (4 waves x 32 keys, key on the MFMA lane), sweeps the query tiles;
+// No float atomics (bitwise reproducible).  Two kinds of blocks, launched together as ONE grid (attn_bwd_pair_kernel, below):
+//   key-owner    (attn_dkv2_block) a block owns 128 keys (4 waves x 32 keys, key on the MFMA lane), sweeps the query tiles;
 //                S = Q K^T and dP = dO V^T come out with the key on the lane and the query in the registers, so P and dS
 //                are directly the B operands of dV^T += dO^T P and dK^T += Q^T dS (A operands by ds_read_b64_tr_b16
 //                from the same row-major Q / dO LDS image the row reads use).
-//   attn_dq      query-owner: a block owns 128 queries (query on the lane), sweeps the key tiles;
+//   query-owner  (attn_dq2_block) a block owns 128 queries (query on the lane), sweeps the key tiles;
 //                S^T = K Q^T, dP^T = V dO^T, dS^T is the B operand of dQ^T += K^T dS^T (A operand by tr-read of K).
-// The split costs 7 MFMA products instead of 5 but needs no cross-workgroup reduction at all (a dQ accumulated with
-// float atomics would be bound by the ~1.3 TB/s atomic rate at S = 20,480: see DESIGN.md).
+// delta[q] = sum_d dO[q,d] * O[q,d] comes from the out-projection's input-gradient epilogue in the block backward (gemm.hip) or from
+// attn_delta_kernel (parts bit 0).  The split costs 7 MFMA products instead of 5 but needs no cross-workgroup reduction at all (a dQ
+// accumulated with float atomics would be bound by the ~1.3 TB/s atomic rate at S = 20,480; an ordered hand-off needs every key block
+// of a head resident at once, which at head_dim 64 does not fit the register file: DESIGN.md section 4).
 #include "smbv_common.h"
 #include "smbv_kernels.h"
 #include "block.h"
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 #define SG_DSR 0x100
 #define SG_TRANS 0x400
 
-// Hand-phased form of attn_dkv_kernel (same arithmetic, same accumulation order, bitwise identical results).  Per 32-query sub-tile
+// The key-owner block, hand-phased (round 1's plain-loop kernel, removed, gave bitwise the same results).  Per 32-query sub-tile
 // the 16 MFMAs run as four dependent chains of 4 and every LDS fragment is read one chain (>= 128 matrix-pipe cycles) before the
 // MFMA that consumes it, so no matrix instruction waits on an LDS round trip:
 //   chain 1  S'  = Q K^T - lse     | reads: dO^T fragments (for chain 3)
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv2_kernel(const bf16_t* __restr
 }
 
 
-// Hand-phased, rotated form of attn_dq_kernel (same arithmetic and accumulation order: bitwise identical results).  Steady state,
+// The query-owner block, hand-phased and rotated (round 1's plain-loop kernel, removed, gave bitwise the same results).  Steady state,
 // per 32-key sub-tile j, three dependent chains of 4 MFMAs, each with the other sub-tile's VALU work and the LDS reads of a LATER
 // chain in its gaps:
 //   chain A  S'^T(j+1) = K Q^T - lse     | dS(j) = P(j) * dP'(j), convert          | reads: V rows of j+1

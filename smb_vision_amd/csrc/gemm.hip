@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
 // 32-token slices (96 KiB) in flight: 8 waves (2 x 4), each 128 x 64 of the output, slices [32 tokens][512 B] of X and of Y
 // through a ring of four LDS slots filled by LDS-DMA hidden from hipcc (smbv_common.h), one counted vmcnt + one barrier per slice, fragments
 // by ds_read_b64_tr_b16 (same 32-byte-column XOR swizzle as the 128 kernel; 512-B rows keep its bank pattern).  The token range is split
-// into slabs so that tiles x slabs fills one round of 256 blocks; slabs are summed by reduce_slabs_kernel in slab order.
+// into slabs so that tiles x slabs fills one round of 256 blocks; slabs are summed by reduce_tn_kernel in slab order.
 __global__ __launch_bounds__(512, 1) void gemm_tn_256_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y, int ldy,
                                                               int M, int N1, int N2, float* __restrict__ out, int ldo, int tiles_1,
                                                               int mchunk, size_t slab_stride, float* __restrict__ xsum) {

@@ -1,5 +1,5 @@
 """The attention backward pair as ONE launch with per-CU mixed block roles (variant 0, the default) against two launches on two streams (variant 524288): interleaved
-rounds in one process, bitwise comparison of the gradients, at the step's shapes.  usage: attn_pair_ab.py [variant bits ...]   (16 = resident-balance role policy)"""
+rounds in one process, bitwise comparison of the gradients, at the step's shapes.  usage: attn_pair_ab.py [variant bits ...]"""
 import sys, os, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
