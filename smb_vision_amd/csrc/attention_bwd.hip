@@ -552,7 +552,223 @@ __device__ __forceinline__ void attn_dq2_block(const bf16_t* __restrict__ Q, con
   }
 }
 
+// The query-owner block on v_mfma_f32_16x16x32_bf16 (round 3, the shipped one): a lane is (query n = l & 15 of a 16-query tile, contraction group
+// g = l >> 4); an S'^T / dP'^T tile (key tile kj, query tile qi) holds keys 16 kj + 4 g + e, so the two key tiles' dS^T accumulators of one query tile,
+// converted, are the B operand (contraction index 8 g + j <-> key 4 g + j | 16 + 4 g + j - 4) of dQ^T += K^T dS^T, whose A operand is two
+// ds_read_b64_tr_b16 blocks of K rows 4 g .. and 16 + 4 g ...  Same rotated three-chain pipeline, K / V ring and products as attn_dq2_block (the
+// 32x32x16 form, debug bit 2), twice the MFMA instructions, 203 instead of 226 registers.  Why: the chip holds a higher clock on the 16x16x32 shape
+// (an accumulator register is written once per 64 FLOP instead of once per 32; tools/probe/mfma_shape_probe.hip), at more cycles.  Measured in the
+// step, where the attention launches follow low-power kernels and cycles count for more than in a back-to-back loop: -0.1 ms MIM, -0.9 ms V-JEPA
+// for this block; the key-owner block re-tiled the same way was 4 % faster back to back on random operands and 0.15-0.3 ms SLOWER in the step, and
+// stays on 32x32x16 (profiles/r03_mfma_shape.txt).
 template <int KT, int DH>
+__device__ __forceinline__ void attn_dq3_block(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                               const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO, int ldo,
+                                               const float* __restrict__ LSE, const float* __restrict__ delta,
+                                               bf16_t* __restrict__ dQ, int ldd, int S, int Sq, int qoff, int H, float scale,
+                                               const int tile_x, const int head, const int b, unsigned char* smem) {
+  static_assert(KT == 128, "bodies are unrolled for 4 sub-tiles per tile");
+  static_assert(DH == 64 || DH == 32, "head widths with a native build");
+  constexpr int KK = DH / 32, DTN = DH / 16, RB = 2 * DH;
+  constexpr int NPC = 32 * RB / 1024;
+  constexpr int BUF = DqLds<KT, DH>::BUF;  // K image | V image
+  constexpr int N1 = 4 * KK, N3 = 2 * DTN;  // MFMAs per chain: S'^T / dP'^T and dQ^T
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int n = l & 15, g = l >> 4;
+  const size_t row0 = (size_t)b * S;
+  const int hoff = head * DH;
+  const float c = scale * 1.4426950408889634f;
+
+  // Q (pre-scaled) / dO operands: [query tile][contraction step]; lane: query 16 qi + n of the wave's 32, channels 32 kk + 8 g .. + 7
+  bf16x8 qf[2][KK], dof[2][KK];
+  f32x4 sinit[2], dinit[2];
+#pragma unroll
+  for (int qi = 0; qi < 2; qi++) {
+    const int q = tile_x * 128 + w * 32 + 16 * qi + n;
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) {
+      u32x4 a = {0, 0, 0, 0}, bb = {0, 0, 0, 0};
+      if (q < Sq) {
+        a = *(const u32x4*)(Q + (row0 + qoff + q) * ld + hoff + 32 * kk + 8 * g);
+        bb = *(const u32x4*)(dO + (row0 + qoff + q) * ldo + hoff + 32 * kk + 8 * g);
+      }
+      asm volatile("" : "+v"(bb));  // (consumed here so that hipcc waits for the load here, not with a vmcnt(0) inside the tile loop)
+      qf[qi][kk] = scale_frag(a, c);
+      dof[qi][kk] = __builtin_bit_cast(bf16x8, bb);
+    }
+    float nlse2 = -INFINITY, ndl = 0.f;
+    if (q < Sq) {
+      nlse2 = -LSE[((size_t)b * H + head) * Sq + q] * 1.4426950408889634f;
+      ndl = -delta[((size_t)b * H + head) * Sq + q];
+    }
+    asm volatile("" : "+v"(nlse2), "+v"(ndl));
+    sinit[qi] = (f32x4){nlse2, nlse2, nlse2, nlse2};
+    dinit[qi] = (f32x4){ndl, ndl, ndl, ndl};
+  }
+  f32x4 dqt[DTN][2];
+#pragma unroll
+  for (int dt = 0; dt < DTN; dt++)
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++) dqt[dt][qi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const i32x4 rsk = dma_rsrc(K + row0 * ld + hoff, (unsigned)(((size_t)(S - 1) * ld + DH) * 2));
+  const i32x4 rsv = dma_rsrc(V + row0 * ld + hoff, (unsigned)(((size_t)(S - 1) * ld + DH) * 2));
+  int og[NPC];
+#pragma unroll
+  for (int i = 0; i < NPC; i++) og[i] = dma_src_off<DH>(w, i, l, ld);
+  const unsigned lds_w = __builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem) + (t >> 6) * (32 * RB)));
+  auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
+    const unsigned dk_ = lds_w + (unsigned)buf * BUF, dv_ = dk_ + KT * RB;
+    const int ko = kt * KT * ld * 2;
+#pragma unroll
+    for (int i = 0; i < NPC; i++) {
+      dma16_hidden(rsk, dk_ + 1024 * i, og[i] + ko);
+      dma16_hidden(rsv, dv_ + 1024 * i, og[i] + ko);
+    }
+  };
+
+  const int qq = (l >> 2) & 3, pp = l & 3;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  // row fragments of sub-tile `sub`: [key tile kj][contraction step kk]; lane: key 16 kj + n, channels 32 kk + 8 g .. + 7
+  auto rows = [&](const unsigned char* img, int sub, bf16x8 (*f)[KK]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kj = 0; kj < 2; kj++)
+#pragma unroll
+      for (int kk = 0; kk < KK; kk++) f[kj][kk] = *(const bf16x8*)(img + swzr<DH>(32 * sub + 16 * kj + n, 4 * kk + g));
+  };
+  // transposed K fragments: channels 16 dt + n, contraction over keys {4 g .. + 3} and {16 + 4 g .. + 3} of the sub-tile
+  auto trk = [&](const unsigned char* img, int sub, bf16x8* f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int dt = 0; dt < DTN; dt++) {
+      const int kb = 32 * sub + 4 * g + qq;
+      const int c16 = 2 * dt + (pp >> 1);
+      const int sb8 = 8 * (pp & 1);
+      const s16x4 a0 = lds_read_tr16(img + swzr<DH>(kb, c16) + sb8);
+      const s16x4 a1 = lds_read_tr16(img + swzr<DH>(kb + 16, c16) + sb8);
+      const s16x8 aa = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      f[dt] = __builtin_bit_cast(bf16x8, aa);
+    }
+  };
+  struct Tiles { f32x4 v[2][2]; };  // [key tile kj][query tile qi]
+  auto chain_s = [&](Tiles& o, const bf16x8 (*a)[KK], const bf16x8 (*bq)[KK], const f32x4* init) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++)
+#pragma unroll
+      for (int kj = 0; kj < 2; kj++)
+#pragma unroll
+        for (int qi = 0; qi < 2; qi++)
+          o.v[kj][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kj][kk], bq[qi][kk], kk == 0 ? init[qi] : o.v[kj][qi], 0, 0, 0);
+  };
+
+  const int nt = (S + KT - 1) / KT;
+  stage(0, 0);
+  if (nt > 1) stage(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  bf16x8 ka[2][KK], va[2][KK], tk[DTN];
+  Tiles sA, sB, dp;
+  {
+    rows(smem, 0, ka);
+    rows(smem + KT * RB, 0, va);
+    chain_s(sA, ka, qf, sinit);
+    rows(smem, 1, ka);
+    trk(smem, 0, tk);
+    chain_s(dp, va, dof, dinit);
+#pragma unroll
+    for (int kj = 0; kj < 2; kj++)
+#pragma unroll
+      for (int qi = 0; qi < 2; qi++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) sA.v[kj][qi][e] = fast_exp2(sA.v[kj][qi][e]);
+  }
+  // one pipeline body: finishes sub-tile j (P in sC, dP' in dp, K^T fragments in tk) and starts j+1 (K rows in ka)
+  auto body = [&](Tiles& sC, Tiles& sN, const unsigned char* img1, int sub1, const unsigned char* img2, int sub2) __attribute__((always_inline)) {
+    bf16x8 dsf[2];
+    // ---- chain A: S'^T(j+1) | dS(j) = P(j) * dP'(j), convert | reads: V rows of j+1
+    chain_s(sN, ka, qf, sinit);
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++) {
+#pragma unroll
+      for (int kj = 0; kj < 2; kj++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) dp.v[kj][qi][e] *= sC.v[kj][qi][e];
+#pragma unroll
+      for (int e = 0; e < 4; e++) { dsf[qi][e] = (__bf16)dp.v[0][qi][e]; dsf[qi][4 + e] = (__bf16)dp.v[1][qi][e]; }
+    }
+    rows(img1 + KT * RB, sub1, va);
+#pragma unroll
+    for (int i = 0; i < N1; i++) {
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_VALU, 24 / N1, 0);
+      if (i < 2 * KK) __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- chain B: dQ^T += K^T dS^T(j) | exp2 of the first key tile of S'^T(j+1) | reads: K rows of j+2
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++)
+#pragma unroll
+      for (int dt = 0; dt < DTN; dt++) dqt[dt][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tk[dt], dsf[qi], dqt[dt][qi], 0, 0, 0);
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) { sN.v[0][qi][e] = fast_exp2(sN.v[0][qi][e]); asm volatile("" : "+v"(sN.v[0][qi][e])); }  // (pinned: hipcc otherwise sinks the last body's exps into the next iteration's head)
+    rows(img2, sub2, ka);
+#pragma unroll
+    for (int i = 0; i < N3; i++) {
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_TRANS, 8 / N3, 0);
+      if (i < 2 * KK) __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- chain C: dP'^T(j+1) | exp2 of the second key tile | reads: K^T fragments of j+1
+    chain_s(dp, va, dof, dinit);
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) { sN.v[1][qi][e] = fast_exp2(sN.v[1][qi][e]); asm volatile("" : "+v"(sN.v[1][qi][e])); }
+    trk(img1, sub1, tk);
+#pragma unroll
+    for (int i = 0; i < N1; i++) {
+      __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_TRANS, 8 / N1, 0);
+      __builtin_amdgcn_sched_group_barrier(SG_DSR, 2 * DTN / N1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto tile = [&](int kt, int cb) __attribute__((always_inline)) {
+    const unsigned char* cur = smem + cb * BUF;
+    const unsigned char* nxt = smem + (cb ^ 1) * BUF;
+    body(sA, sB, cur, 1, cur, 2);
+    body(sB, sA, cur, 2, cur, 3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt+1 (requested a whole tile ago) have landed
+    __syncthreads();                                  // ... everyone's have
+    body(sA, sB, cur, 3, nxt, 0);
+    __syncthreads();  // every wave is done with tile kt: its buffer takes tile kt+2
+    if (kt + 2 < nt) stage(cb, kt + 2);
+    body(sB, sA, nxt, 0, nxt, 1);
+  };
+  for (int kt = 0; kt < nt; kt += 2) {
+    tile(kt, 0);
+    if (kt + 1 < nt) tile(kt + 1, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+
+#pragma unroll
+  for (int qi = 0; qi < 2; qi++) {
+    const int q = tile_x * 128 + w * 32 + 16 * qi + n;
+    if (q < Sq) {
+      bf16_t* qp = dQ + (row0 + qoff + q) * ldd + hoff;
+#pragma unroll
+      for (int dt = 0; dt < DTN; dt++) {
+        const int d0 = 16 * dt + 4 * g;
+        u32x2 pk = {pack_bf16(dqt[dt][qi][0] * scale, dqt[dt][qi][1] * scale), pack_bf16(dqt[dt][qi][2] * scale, dqt[dt][qi][3] * scale)};
+        *(u32x2*)(qp + d0) = pk;
+      }
+    }
+  }
+}
+
+template <int KT, int DH, bool MFMA16>
 __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                           const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO, int ldo,
                                                           const float* __restrict__ LSE, const float* __restrict__ delta,
@@ -561,7 +777,8 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
   int tile_x = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
   stagger_by_wave_slot((xcd_order >> 8) & 0xff);
   if (xcd_order & 1) xcd_block_order((Sq + 127) / 128, H, tile_x, head, b);
-  attn_dq2_block<KT, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile_x, head, b, smem);
+  if constexpr (MFMA16) attn_dq3_block<KT, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile_x, head, b, smem);
+  else attn_dq2_block<KT, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile_x, head, b, smem);
 }
 
 // ---- the pair as ONE launch with the two kinds of blocks mixed on every CU --------------------------------------------------------------------------
@@ -579,7 +796,7 @@ struct PairState {            // one slot of the library's device-side schedulin
 };
 __device__ PairState g_pair_state[8];
 
-template <int DH>
+template <int DH, bool QMFMA16>
 __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, int ld,
                                                                const bf16_t* __restrict__ dO, int ldo, const float* __restrict__ LSE,
                                                                const float* __restrict__ delta, bf16_t* __restrict__ dQ, bf16_t* __restrict__ dK,
@@ -611,7 +828,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __r
     attn_dkv2_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
   } else if (role == 1) {
     const int nt = (Sq + 127) / 128;
-    attn_dq2_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
+    if constexpr (QMFMA16) attn_dq3_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
+    else attn_dq2_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
   }
   // the block that ends last (every other block has claimed its tile long ago) hands the slot back zeroed: no memset node in front of the next launch
   // (a fill kernel of ~8 us on the critical path, 16 per MIM step)
@@ -646,8 +864,11 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     static std::atomic<unsigned> next_slot{0};   // consecutive launches use different slots; one stream at a time per device (include/smbv.h)
     const int slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) & 7u);
     const int blocks = (cdiv(S, 128) + cdiv(Sq, 128)) * H * B;
-    if (Dh == 64) hipLaunchKernelGGL((attn_bwd_pair_kernel<64>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot);
-    else hipLaunchKernelGGL((attn_bwd_pair_kernel<32>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot);
+    const bool q16 = !(g_variant & 2);   // A/B: bit 1 = the query-owner block on the 32x32x16 MFMA (attn_dq2_block)
+    if (Dh == 64 && q16) hipLaunchKernelGGL((attn_bwd_pair_kernel<64, true>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot);
+    else if (Dh == 64) hipLaunchKernelGGL((attn_bwd_pair_kernel<64, false>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot);
+    else if (q16) hipLaunchKernelGGL((attn_bwd_pair_kernel<32, true>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot);
+    else hipLaunchKernelGGL((attn_bwd_pair_kernel<32, false>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot);
     return check_launch("attn_bwd_pair");
   }
   // dK/dV and dQ are independent (disjoint outputs, shared read-only inputs).  Their grids rarely fill a whole number of
@@ -677,8 +898,11 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     if (rc) return rc;
   }
   if (parts & 4) {
-    if (Dh == 64) hipLaunchKernelGGL((attn_dq2_kernel<128, 64>), gq, dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, xo);
-    else hipLaunchKernelGGL((attn_dq2_kernel<128, 32>), gq, dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, xo);
+    const bool q16 = !(g_variant & 2);
+    if (Dh == 64 && q16) hipLaunchKernelGGL((attn_dq2_kernel<128, 64, true>), gq, dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, xo);
+    else if (Dh == 64) hipLaunchKernelGGL((attn_dq2_kernel<128, 64, false>), gq, dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, xo);
+    else if (q16) hipLaunchKernelGGL((attn_dq2_kernel<128, 32, true>), gq, dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, xo);
+    else hipLaunchKernelGGL((attn_dq2_kernel<128, 32, false>), gq, dim3(256), 0, st_dq, Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, xo);
     rc = check_launch("attn_dq");
   }
   return rc;  // ~Join: `st` waits for the dQ kernel
