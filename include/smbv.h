@@ -52,7 +52,7 @@ typedef uint16_t smbv_bf16;
 int smbv_version(void);
 int smbv_last_error(char* buf, size_t len);               /* copies the thread's last error text; returns its length */
 /* Tuning / A-B hook used by tools/ and by the kernel-equivalence tests, NOT by the product path: selects alternative kernels for the same
- * arithmetic (process-wide, not thread-safe; 0 = the shipped selection).  Bits: 32 register-staged GEMMs; 256 first-generation 128x128 NT
+ * arithmetic (process-wide, not thread-safe; 0 = the shipped selection).  Bits: 2 attention backward query-owner blocks on the 32x32x16 MFMA (shipped: 16x16x32); 32 register-staged GEMMs; 256 first-generation 128x128 NT
  * GEMM everywhere / 131072 second-generation ring NT GEMM everywhere (default: by shape); 512 four-slot ring; 262144 ring with 64-deep K slices; 1024 no mixed-tile NT launches (all tiles 128 x 128); 2048 attention forward with the guarded sweep only (no optimistic first sweep); 4096 delta = rowsum(dO * O) by its own launch instead of the
  * out-projection input-gradient epilogue; 8192 attention dQ and dK/dV on
  * one stream (with 524288); 524288 attention backward as two launches (dK/dV, dQ) instead of the one mixed-role launch; 16384 weight- and input-gradient GEMMs on one stream; 32768 / 65536 TN tile selection; bits 20-23 GEMM ablation (timing only); 1<<24 attention forward on the plain (tile, head, batch) grid instead of the
