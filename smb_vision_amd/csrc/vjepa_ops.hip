@@ -12,47 +12,58 @@
 
 namespace smbv {
 
-// One thread per (token, head, pair).  qkv: bf16 [rows, ld]; q at column 0, k at column k_off; head stride hs (64 when padded).
+// One thread per (token, head, 16-byte chunk): 8 elements = 4 rotation pairs of q and the same 4 of k (one table lookup serves both).
+// qkv: bf16 [rows, ld]; q at column 0, k at column k_off; head stride hs (64 when padded); elements >= 3 * seg of a head pass through.
 // pos: int32 token position ids [rows] (null -> row % S).  table: fp32 [P][2][seg/2] cos|sin for positions 0..P-1.
-__global__ void rope3d_kernel(bf16_t* __restrict__ qkv, int ld, int k_off, long rows, int S, int H, int hs, int seg, int grid,
-                              const int* __restrict__ pos, const float* __restrict__ table, int transpose) {
-  const int npair = 3 * seg / 2;  // pairs per head
+// (Round 3: the first form - one thread per pair, 4-byte accesses - moved 1.7 TB/s; V-JEPA runs it 36 times per step.)
+__global__ __launch_bounds__(256) void rope3d_kernel(bf16_t* __restrict__ qkv, int ld, int k_off, long rows, int S, int H, int hs, int seg, int grid,
+                                                     const int* __restrict__ pos, const float* __restrict__ table, int transpose, int nchunk) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = rows * H * npair;
-  if (gid >= total) return;
-  const int pr = gid % npair;
-  const int h = (gid / npair) % H;
-  const long row = gid / ((long)npair * H);
+  const int tpr = H * nchunk;  // threads per token
+  const long row = gid / tpr;
+  if (row >= rows) return;
+  const int rem = (int)(gid - row * tpr);
+  const int h = rem / nchunk, ch = rem - h * nchunk;
   const int p = pos ? pos[row] : (int)(row % S);
   const int tpf = grid * grid;
   const int frame = p / tpf, height = (p - tpf * frame) / grid, width = (p - tpf * frame) - grid * height;
   const int half = seg >> 1;
-  const int axis = (2 * pr) / seg;                 // 0 frame, 1 height, 2 width
-  const int t0 = 2 * pr - axis * seg;              // element index of the pair's first element inside its segment
-  const int pid = axis == 0 ? frame : (axis == 1 ? height : width);
-  const float* tb = table + (size_t)pid * seg;     // [cos half | sin half]
-  const float c0 = tb[t0 % half], s0 = tb[half + t0 % half];
-  const float c1 = tb[(t0 + 1) % half], s1 = tb[half + (t0 + 1) % half];
-  const int col = h * hs + axis * seg + t0;
+  u32x4* pq = (u32x4*)(qkv + row * ld + h * hs + 8 * ch);
+  u32x4* pk = (u32x4*)(qkv + row * ld + k_off + h * hs + 8 * ch);
+  u32x4 q = *pq, k = *pk;
 #pragma unroll
-  for (int sec = 0; sec < 2; sec++) {
-    unsigned* ptr = (unsigned*)(qkv + row * ld + (sec ? k_off : 0) + col);
-    const unsigned u = *ptr;
-    const float x0 = bf_lo(u), x1 = bf_hi(u);
-    float y0, y1;
-    if (!transpose) { y0 = x0 * c0 - x1 * s0; y1 = x1 * c1 + x0 * s1; }   // out = x*cos + rot(x)*sin, rot = (-x1, x0)
-    else { y0 = x0 * c0 + x1 * s1; y1 = x1 * c1 - x0 * s0; }              // transposed map for the gradient
-    *ptr = pack_bf16(y0, y1);
+  for (int j = 0; j < 4; j++) {
+    const int e0 = 8 * ch + 2 * j;                   // the pair's first element inside the head
+    if (e0 >= 3 * seg) break;                        // pass-through tail (seg is even: a pair never straddles the end)
+    const int axis = e0 / seg;                       // 0 frame, 1 height, 2 width
+    const int t0 = e0 - axis * seg;                  // element index inside its segment
+    const int pid = axis == 0 ? frame : (axis == 1 ? height : width);
+    const float* tb = table + (size_t)pid * seg;     // [cos half | sin half]
+    const float c0 = tb[t0 % half], s0 = tb[half + t0 % half];
+    const float c1 = tb[(t0 + 1) % half], s1 = tb[half + (t0 + 1) % half];
+#pragma unroll
+    for (int sec = 0; sec < 2; sec++) {
+      const unsigned u = sec ? k[j] : q[j];
+      const float x0 = bf_lo(u), x1 = bf_hi(u);
+      float y0, y1;
+      if (!transpose) { y0 = x0 * c0 - x1 * s0; y1 = x1 * c1 + x0 * s1; }   // out = x*cos + rot(x)*sin, rot = (-x1, x0)
+      else { y0 = x0 * c0 + x1 * s1; y1 = x1 * c1 - x0 * s0; }              // transposed map for the gradient
+      if (sec) k[j] = pack_bf16(y0, y1); else q[j] = pack_bf16(y0, y1);
+    }
   }
+  *pq = q;
+  *pk = k;
 }
 
 int rope3d(bf16_t* qkv, int ld, int k_off, long rows, int S, int H, int hs, int Dh, int grid, const int* pos, const float* table, int transpose,
            hipStream_t st) {
   const int seg = 2 * ((Dh / 3) / 2);
   if (seg <= 0) return SMBV_OK;
-  if (rows <= 0 || H <= 0 || grid <= 0 || (ld & 1) || (k_off & 1) || (hs & 1) || !table) { set_error("rope3d: bad argument"); return SMBV_ERR_ARG; }
-  const long total = rows * H * (3 * seg / 2);
-  hipLaunchKernelGGL(rope3d_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, qkv, ld, k_off, rows, S, H, hs, seg, grid, pos, table, transpose);
+  if (rows <= 0 || H <= 0 || grid <= 0 || (ld & 7) || (k_off & 7) || (hs & 7) || !table || ((uintptr_t)qkv & 15)) { set_error("rope3d: bad argument"); return SMBV_ERR_ARG; }
+  const int nchunk = cdiv(3 * seg, 8);               // 16-byte chunks of a head that hold rotated elements (<= hs / 8)
+  if (8 * nchunk > hs) { set_error("rope3d: head slot %d narrower than the rotated width", hs); return SMBV_ERR_ARG; }
+  const long total = rows * H * nchunk;
+  hipLaunchKernelGGL(rope3d_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, qkv, ld, k_off, rows, S, H, hs, seg, grid, pos, table, transpose, nchunk);
   return check_launch("rope3d");
 }
 

@@ -49,6 +49,8 @@ def test_rope3d_matches_oracle(Dh, hs):
         got = x.float().cpu()[:, sec * wa:(sec + 1) * wa].view(B, S, H, hs)[..., :Dh]
         assert rel(got, ref) < 1e-2
     assert torch.equal(x.cpu()[:, 2 * wa:], qkv[:, 2 * wa:])  # v untouched
+    seg = 2 * ((Dh // 3) // 2)
+    assert torch.equal(x.cpu().view(B * S, 3, H, hs)[:, :2, :, 3 * seg:], qkv.view(B * S, 3, H, hs)[:, :2, :, 3 * seg:])  # pass-through tail of every head slot
     # transpose map == autograd of the forward map
     src = qkv.float()[:, :wa].view(B, S, H, hs)[..., :Dh].permute(0, 2, 1, 3).clone().requires_grad_(True)
     gy = torch.randn(B, H, S, Dh, generator=g)
@@ -63,6 +65,7 @@ def test_rope3d_matches_oracle(Dh, hs):
 
 def test_l1_and_ema_kernels():
     from smb_vision_amd.modeling_vjepa import MomentumEncoder, l1_loss
+    torch.manual_seed(7)
     p = torch.randn(3, 50, 64, device="cuda", requires_grad=True)
     t = torch.randn(3, 50, 64, device="cuda")
     loss = l1_loss(p, t)
@@ -77,7 +80,8 @@ def test_l1_and_ema_kernels():
     want = [0.9 * b.detach() + 0.1 * a.detach() for a, b in zip(q, k)]
     MomentumEncoder(k, 0.9).update(q)
     for w, b in zip(want, k):
-        assert torch.allclose(b, w, rtol=1e-6, atol=1e-7)
+        # operands reach |x| ~ 4.5 and the sum cancels: one rounding of each product is up to ulp(4)/2 = 2.4e-7 absolute whatever the result's size
+        assert torch.allclose(b, w, rtol=1e-6, atol=1e-6)
 
 
 def build(c, params):
