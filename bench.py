@@ -266,8 +266,15 @@ def vjepa_leg(device, world, rank, steps, warmup):
     pix = torch.rand(1, 320, 1, 512, 512, generator=torch.Generator(device=device).manual_seed(1 + rank), device=device)
     torch.manual_seed(7 + rank)
     item = VJEPAMaskGenerator(input_size=(320, 512, 512), patch_size=(16, 16, 16), pred_mask_scale=(0.2, 0.8), aspect_ratio=(0.3, 3.0), num_blocks=3)({})
-    cm, tm = item["context_mask"][None].to(device), item["target_mask"][None].to(device)
+    # what run_vjepa.collate_fn hands over next to the masks: the step's index arrays, built on the host (the DataLoader's workers in the harness)
+    from smb_vision_amd.modeling_vjepa import index_plumbing
+    cm_h, tm_h = item["context_mask"][None].long(), item["target_mask"][None].long()
+    to_dev = lambda d: {k: (v.to(device) if torch.is_tensor(v) else ([t.to(device) for t in v] if isinstance(v, list) else v)) for k, v in d.items()}
+    cm, tm = cm_h.to(device), tm_h.to(device)
     inputs = {"pixel_values_videos": pix, "context_mask": [cm], "target_mask": [tm]}
+    if os.environ.get("SMBV_VJEPA_DEVICE_PLUMBING", "0") != "1":
+        inputs["smbv_plumbing_context"] = to_dev(index_plumbing([cm_h], [tm_h], model.num_patches, "context"))
+        inputs["smbv_plumbing_target"] = to_dev(index_plumbing([cm_h], [tm_h], model.num_patches, "target"))
 
     def step():
         loss, _ = vjepa_loss(model, target, ema, inputs)

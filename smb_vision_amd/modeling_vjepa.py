@@ -45,6 +45,59 @@ class SmbVJEPA2ModelOutput(ModelOutput):
     predictor_output: Optional[SmbVJEPA2PredictorOutput] = None
 
 
+def index_plumbing(cms, tms, num_patches, needed=None):
+    """Sorted predictor sequences (modeling_vjepa.py:718-719).  Plain index arithmetic on whatever device the masks live on: ``run_vjepa.collate_fn``
+    runs it on the host, in the DataLoader's workers, and ships the result with the batch (``smbv_plumbing_*``), so that a step does not open with four
+    device sorts and ~60 tiny kernels; ``SmbVJEPA2Model.forward`` runs it on the device when no such arrays come with the call.
+
+    ``cms`` / ``tms``: the mask lists; ``apply_masks`` (:542-556) concatenates their elements along the batch, so predictor sequence m * B + b pairs volume b with mask pair m.  Returns the arrays of
+    ``smbv_vjepa_io``: absolute encoder rows of the context tokens, sorted positions, and the slot of every context / target token.
+
+    ``needed`` ("context" / "target", one mask pair): the encoder's token order is permuted so that the tokens whose encoder output the caller
+    consumes come first (ascending ids), the others after them (``smbv_vjepa_cfg.enc_needed``); RoPE then takes explicit position ids.  The
+    rows ``ctx_idx`` names, and ``need_rows`` (where each consumed token sits), are rows of the COMPACT encoder output [B * enc_needed, d]."""
+    B, N = cms[0].shape[0], num_patches
+    device = cms[0].device
+    cm, tm = torch.cat(cms, dim=0), torch.cat(tms, dim=0)           # [M*B, Nctx], [M*B, Ntgt]
+    pos = torch.cat([cm, tm], dim=1)
+    n_ctx = cm.shape[1]
+    # Slots of the predictor sequence.  The reference sorts the tokens by position and unsorts the output (modeling_vjepa.py:718-746); with RoPE on
+    # explicit position ids any order is the same function.  Targets first (by position), then the context (by position): the predictor's output is
+    # read at the target tokens only, so its last block works on slots 0 .. Ntgt-1 alone (smbv_vjepa_cfg.pred_tgt_first).
+    key = pos + torch.cat([torch.full_like(cm, N), torch.zeros_like(tm)], dim=1)
+    order = torch.argsort(key, dim=1, stable=True)
+    rev = torch.argsort(order, dim=1, stable=True)
+    vol = torch.arange(B, device=device).repeat(len(cms)).unsqueeze(1)  # sequence -> volume it reads
+    out = dict(tgt_idx=tm.to(torch.int32).contiguous(), pred_pos=torch.gather(pos, 1, order).to(torch.int32).contiguous(),
+               ctx_slot=rev[:, :n_ctx].to(torch.int32).contiguous(), tgt_slot=rev[:, n_ctx:].to(torch.int32).contiguous(), n_masks=len(cms),
+               ctx_tok=[c.to(torch.int32).contiguous() for c in cms], tgt_tok=[t.to(torch.int32).contiguous() for t in tms],
+               enc_needed=0, enc_pos=None, need_rows=None)
+    if needed is None:
+        out["all_idx"] = torch.arange(N, device=device, dtype=torch.int32).repeat(B, 1).contiguous()
+        out["ctx_idx"] = (cm + vol * N).to(torch.int32).contiguous()
+        return out
+    sel = cm if needed == "context" else tm                         # [B, n] token ids whose encoder output is consumed (one mask pair)
+    n = sel.shape[1]
+    rest = torch.ones(B, N, dtype=torch.int8, device=device)
+    rest.scatter_(1, sel, 0)                                        # 0 = consumed, 1 = not; a stable sort puts the consumed ids first, both ascending
+    perm = torch.argsort(rest, dim=1, stable=True)                  # encoder row j of a volume holds token perm[j]
+    rank = torch.argsort(perm, dim=1)                               # token id -> its encoder row (rows of consumed tokens are < n)
+    row0 = torch.arange(B, device=device).unsqueeze(1) * n
+    out["all_idx"] = perm.to(torch.int32).contiguous()
+    out["enc_pos"] = out["all_idx"]
+    out["enc_needed"] = n
+    out["need_rows"] = torch.gather(rank, 1, sel).to(torch.int32).contiguous()       # [B, n] row inside the volume's compact block
+    out["ctx_idx"] = (torch.gather(rank, 1, cm) + row0).to(torch.int32).contiguous() if needed == "context" else (cm + vol * N).to(torch.int32).contiguous()
+    return out
+
+
+def _plumbing_fits(pl, needed, cms, tms):
+    """A precomputed index_plumbing() result is used only if it was built for this call's restriction and mask shapes."""
+    want = 0 if needed is None else cms[0].shape[1] if needed == "context" else tms[0].shape[1]
+    return (int(pl.get("enc_needed", -1)) == want and int(pl.get("n_masks", -1)) == len(cms) and pl["ctx_slot"].shape == (len(cms) * cms[0].shape[0], cms[0].shape[1])
+            and pl["tgt_slot"].shape == (len(tms) * tms[0].shape[0], tms[0].shape[1]))
+
+
 _BLOCK = (("norm1.weight", "ln1_w", "w"), ("norm1.bias", "ln1_b", "w"),
           ("attention.query.weight", "q_w", "ww"), ("attention.query.bias", "q_b", "w"),
           ("attention.key.weight", "k_w", "ww"), ("attention.key.bias", "k_b", "w"),
@@ -254,45 +307,7 @@ class SmbVJEPA2Model(PreTrainedModel):
 
     # -- the step ------------------------------------------------------------------------------------------------------
     def _index_plumbing(self, cms, tms, device, needed=None):
-        """Sorted predictor sequences (modeling_vjepa.py:718-719).  ``cms`` / ``tms``: the mask lists; ``apply_masks`` (:542-556) concatenates
-        their elements along the batch, so predictor sequence m * B + b pairs volume b with mask pair m.  Returns the arrays of
-        ``smbv_vjepa_io``: absolute encoder rows of the context tokens, sorted positions, and the slot of every context / target token.
-
-        ``needed`` ("context" / "target", one mask pair): the encoder's token order is permuted so that the tokens whose encoder output the caller
-        consumes come first (ascending ids), the others after them (``smbv_vjepa_cfg.enc_needed``); RoPE then takes explicit position ids.  The
-        rows ``ctx_idx`` names, and ``need_rows`` (where each consumed token sits), are rows of the COMPACT encoder output [B * enc_needed, d]."""
-        B, N = cms[0].shape[0], self.num_patches
-        cm, tm = torch.cat(cms, dim=0), torch.cat(tms, dim=0)           # [M*B, Nctx], [M*B, Ntgt]
-        pos = torch.cat([cm, tm], dim=1)
-        n_ctx = cm.shape[1]
-        # Slots of the predictor sequence.  The reference sorts the tokens by position and unsorts the output (modeling_vjepa.py:718-746); with RoPE on
-        # explicit position ids any order is the same function.  Targets first (by position), then the context (by position): the predictor's output is
-        # read at the target tokens only, so its last block works on slots 0 .. Ntgt-1 alone (smbv_vjepa_cfg.pred_tgt_first).
-        key = pos + torch.cat([torch.full_like(cm, N), torch.zeros_like(tm)], dim=1)
-        order = torch.argsort(key, dim=1, stable=True)
-        rev = torch.argsort(order, dim=1, stable=True)
-        vol = torch.arange(B, device=device).repeat(len(cms)).unsqueeze(1)  # sequence -> volume it reads
-        out = dict(tgt_idx=tm.to(torch.int32).contiguous(), pred_pos=torch.gather(pos, 1, order).to(torch.int32).contiguous(),
-                   ctx_slot=rev[:, :n_ctx].to(torch.int32).contiguous(), tgt_slot=rev[:, n_ctx:].to(torch.int32).contiguous(), n_masks=len(cms),
-                   ctx_tok=[c.to(torch.int32).contiguous() for c in cms], tgt_tok=[t.to(torch.int32).contiguous() for t in tms],
-                   enc_needed=0, enc_pos=None, need_rows=None)
-        if needed is None:
-            out["all_idx"] = torch.arange(N, device=device, dtype=torch.int32).repeat(B, 1).contiguous()
-            out["ctx_idx"] = (cm + vol * N).to(torch.int32).contiguous()
-            return out
-        sel = cm if needed == "context" else tm                         # [B, n] token ids whose encoder output is consumed (one mask pair)
-        n = sel.shape[1]
-        rest = torch.ones(B, N, dtype=torch.int8, device=device)
-        rest.scatter_(1, sel, 0)                                        # 0 = consumed, 1 = not; a stable sort puts the consumed ids first, both ascending
-        perm = torch.argsort(rest, dim=1, stable=True)                  # encoder row j of a volume holds token perm[j]
-        rank = torch.argsort(perm, dim=1)                               # token id -> its encoder row (rows of consumed tokens are < n)
-        row0 = torch.arange(B, device=device).unsqueeze(1) * n
-        out["all_idx"] = perm.to(torch.int32).contiguous()
-        out["enc_pos"] = out["all_idx"]
-        out["enc_needed"] = n
-        out["need_rows"] = torch.gather(rank, 1, sel).to(torch.int32).contiguous()       # [B, n] row inside the volume's compact block
-        out["ctx_idx"] = (torch.gather(rank, 1, cm) + row0).to(torch.int32).contiguous() if needed == "context" else (cm + vol * N).to(torch.int32).contiguous()
-        return out
+        return index_plumbing(cms, tms, self.num_patches, needed)
 
     def _run_forward(self, pix, idx, with_pred):
         lib = _lib.load()
@@ -381,7 +396,7 @@ class SmbVJEPA2Model(PreTrainedModel):
 
     def forward(self, pixel_values_videos: torch.Tensor, context_head_mask=None, context_mask: Optional[List[torch.Tensor]] = None,
                 target_head_mask=None, target_mask: Optional[List[torch.Tensor]] = None, skip_predictor: bool = False, output_attentions=None,
-                output_hidden_states=None, smbv_needed: Optional[str] = None, **kwargs):
+                output_hidden_states=None, smbv_needed: Optional[str] = None, smbv_plumbing: Optional[dict] = None, **kwargs):
         """``smbv_needed`` (not in the reference's signature; default None = the reference's forward): "context" - the caller consumes
         ``predictor_output`` / ``masked_hidden_state`` only (the online model inside ``VJEPATrainer.compute_loss``, run_vjepa.py:118-124), "target" - it
         consumes ``target_hidden_state`` only (the frozen target encoder, :126-131).  The last encoder block then computes only the rows those outputs
@@ -422,7 +437,12 @@ class SmbVJEPA2Model(PreTrainedModel):
             native_heads = (c.hidden_size // c.num_attention_heads) in (32, 64)  # (head-padded encoder widths: the ranged block is not built for them)
             if smbv_needed is not None and (len(cms) != 1 or sel[0].shape[1] >= N or not native_heads or (smbv_needed == "target" and not skip_predictor)):
                 smbv_needed = None  # mask lists, a mask that keeps every token, or a predictor that needs the context rows: the unrestricted forward
-            idx = self._index_plumbing(cms, tms, dev, smbv_needed)
+            if smbv_plumbing is not None and _plumbing_fits(smbv_plumbing, smbv_needed, cms, tms):
+                # built by index_plumbing() ahead of the step (run_vjepa.collate_fn, on the host): only the uploads remain
+                idx = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else ([t.to(dev, non_blocking=True) for t in v] if isinstance(v, (list, tuple)) else v))
+                       for k, v in smbv_plumbing.items()}
+            else:
+                idx = self._index_plumbing(cms, tms, dev, smbv_needed)
             with_pred = not skip_predictor
             if torch.is_grad_enabled() and any(p.requires_grad for p in params):
                 enc_out, pred_out = _VJEPAFn.apply(weakref.ref(self), pix, idx, with_pred, *params)
@@ -561,14 +581,14 @@ def vjepa_loss(model, target_encoder, momentum_encoder, inputs):
     def run_target():
         with torch.no_grad():
             return target_encoder(pixel_values_videos=pix, context_mask=inputs["context_mask"], target_mask=inputs["target_mask"], skip_predictor=True,
-                                  smbv_needed=None if full else "target").target_hidden_state
+                                  smbv_needed=None if full else "target", smbv_plumbing=inputs.get("smbv_plumbing_target")).target_hidden_state
 
     if side is not None:
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             tgt = run_target()
     out = model(pixel_values_videos=inputs["pixel_values_videos"], context_mask=inputs["context_mask"], target_mask=inputs["target_mask"],
-                skip_predictor=False, smbv_needed=None if full else "context")
+                skip_predictor=False, smbv_needed=None if full else "context", smbv_plumbing=inputs.get("smbv_plumbing_context"))
     pred = out.predictor_output.last_hidden_state
     if side is not None:
         cur.wait_stream(side)

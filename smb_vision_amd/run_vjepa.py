@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import logging
 import os
+import functools
 import random
 import sys
 from dataclasses import dataclass, field
@@ -51,13 +52,23 @@ class SmbVJEPATrainer(SmbTrainer):
         return (loss, outputs) if return_outputs else loss
 
 
-def collate_fn(examples):
-    """run_vjepa.py:144-160: stack the volumes; ONE random example's masks for every row; masks wrapped in 1-element lists."""
+def collate_fn(examples, num_patches=0):
+    """run_vjepa.py:144-160: stack the volumes; ONE random example's masks for every row; masks wrapped in 1-element lists.
+    ``num_patches`` (the model's token count; the harness binds it with functools.partial): also ship the step's index arrays, see below."""
     pixel_values = torch.stack([ex["image"] for ex in examples])
     ex = random.choice(examples)
     context_mask = torch.stack([ex["context_mask"] for _ in examples])
     target_mask = torch.stack([ex["target_mask"] for _ in examples])
-    return {"pixel_values_videos": pixel_values, "context_mask": [context_mask], "target_mask": [target_mask]}
+    batch = {"pixel_values_videos": pixel_values, "context_mask": [context_mask], "target_mask": [target_mask]}
+    n_tokens = num_patches
+    if n_tokens and context_mask.shape[1] < n_tokens and target_mask.shape[1] < n_tokens:
+        # the index arithmetic of the step (sorted predictor slots, the encoder's [consumed | other] token order) done here, on the host, by the
+        # DataLoader's workers: vjepa_loss hands each array set to the forward it was built for (modeling_vjepa.index_plumbing)
+        from .modeling_vjepa import index_plumbing
+        batch["smbv_plumbing_context"] = index_plumbing([context_mask.long()], [target_mask.long()], n_tokens, "context")
+        batch["smbv_plumbing_target"] = index_plumbing([context_mask.long()], [target_mask.long()], n_tokens, "target")
+    return batch
+
 
 
 class SyntheticVJEPADataset(Dataset):
@@ -109,7 +120,7 @@ def main(argv=None):
     gen = VJEPAMaskGenerator(input_size=(dargs.depth, dargs.image_size, dargs.image_size), patch_size=(dargs.patch_size,) * 3,
                              pred_mask_scale=(0.2, 0.8), aspect_ratio=(0.3, 3.0), num_blocks=dargs.num_mask_blocks)
     train = SyntheticVJEPADataset(dargs.num_train_volumes, dargs.image_size, dargs.depth, gen, 1234)
-    trainer = SmbVJEPATrainer(model=model, args=targs, train_dataset=train, data_collator=collate_fn)
+    trainer = SmbVJEPATrainer(model=model, args=targs, train_dataset=train, data_collator=functools.partial(collate_fn, num_patches=model.num_patches))
     result = trainer.train()
     trainer.save_model()
     trainer.log_metrics("train", result.metrics)

@@ -279,3 +279,30 @@ def test_attention_plugin_registers_and_refuses_cpu():
     import pytest
     with pytest.raises(RuntimeError, match="MI355X"):
         model(pixel_values=torch.rand(1, 32, 1, 32, 32), bool_masked_pos=mask)
+
+
+def test_vjepa_collate_ships_the_index_arrays():
+    """run_vjepa.collate_fn(num_patches=N): the step's index arithmetic runs on the host (modeling_vjepa.index_plumbing) and travels with the batch;
+    the arrays are what the device-side derivation gives (same function, other device) and a permutation where they must be one."""
+    import torch
+    from smb_vision_amd.modeling_vjepa import index_plumbing
+    from smb_vision_amd.run_vjepa import collate_fn
+    g = torch.Generator().manual_seed(3)
+    N = 96
+    perm = torch.randperm(N, generator=g)
+    cm, tm = perm[:30].sort().values, perm[30:80].sort().values
+    examples = [{"image": torch.rand(2, 1, 4, 4), "context_mask": cm, "target_mask": tm} for _ in range(3)]
+    batch = collate_fn(examples, num_patches=N)
+    assert set(batch) == {"pixel_values_videos", "context_mask", "target_mask", "smbv_plumbing_context", "smbv_plumbing_target"}
+    assert set(collate_fn(examples)) == {"pixel_values_videos", "context_mask", "target_mask"}   # the reference's batch when not asked for more
+    pc, pt = batch["smbv_plumbing_context"], batch["smbv_plumbing_target"]
+    assert pc["enc_needed"] == 30 and pt["enc_needed"] == 50 and pc["n_masks"] == 1
+    for pl, sel in ((pc, cm), (pt, tm)):
+        assert pl["all_idx"].dtype == torch.int32 and pl["all_idx"].shape == (3, N)
+        assert torch.equal(pl["all_idx"].sort(dim=1).values, torch.arange(N, dtype=torch.int32).repeat(3, 1))      # a permutation of the tokens
+        assert torch.equal(pl["all_idx"][:, :sel.numel()].long(), sel.repeat(3, 1))                                  # consumed tokens first, ascending
+    # predictor slots: targets first (by position), then the context
+    assert torch.equal(pc["pred_pos"][0, :50].long(), tm) and torch.equal(pc["pred_pos"][0, 50:].long(), cm)
+    assert torch.equal(pc["tgt_slot"][0].long(), torch.arange(50)) and torch.equal(pc["ctx_slot"][0].long(), 50 + torch.arange(30))
+    ref = index_plumbing([batch["context_mask"][0].long()], [batch["target_mask"][0].long()], N, "context")
+    assert all(torch.equal(pc[k], ref[k]) for k in ("tgt_idx", "pred_pos", "ctx_slot", "tgt_slot", "all_idx", "need_rows", "ctx_idx"))

@@ -372,3 +372,38 @@ def test_vjepa_gradients_through_the_encoder_outputs_match_the_oracle(skip_predi
         worst = max(worst, (k, r), key=lambda t: t[1])
         assert r < (2e-1 if k.endswith("attention.key.bias") else 6e-2), (k, r)
     print(f"gradients through the encoder outputs (skip_predictor={skip_predictor}): worst {worst}")
+
+
+def test_host_built_index_arrays_give_the_same_step():
+    """run_vjepa.collate_fn ships the step's index arrays (modeling_vjepa.index_plumbing, built on the host); the forward that receives them must be
+    bit-identical to the one that derives them on the device, and arrays built for another restriction must be ignored, not misused."""
+    from smb_vision_amd.modeling_vjepa import index_plumbing, make_target_encoder, vjepa_loss
+    from smb_vision_amd.run_vjepa import collate_fn
+    blob, c = load("vjepa_tiny")
+    p_on = {k[6:]: v for k, v in blob.items() if k.startswith("param.")}
+    model = build(c, p_on)
+    target = make_target_encoder(build(c, p_on))
+    pix = blob["in.pixel_values_videos"]
+    cm, tm = blob["in.context_mask"], blob["in.target_mask"]
+    examples = [{"image": pix[b], "context_mask": cm[0], "target_mask": tm[0]} for b in range(pix.shape[0])]
+    import random
+    random.seed(0)
+    batch = collate_fn(examples, num_patches=model.num_patches)
+    assert "smbv_plumbing_context" in batch and "smbv_plumbing_target" in batch
+    dev = lambda x: x.cuda() if torch.is_tensor(x) else ({k: dev(v) for k, v in x.items()} if isinstance(x, dict) else ([dev(v) for v in x] if isinstance(x, list) else x))
+    with_arrays = dev(batch)
+    without = {k: v for k, v in with_arrays.items() if not k.startswith("smbv_")}
+    res = []
+    for inputs in (with_arrays, without):
+        model.zero_grad(set_to_none=True)
+        loss, out = vjepa_loss(model, target, None, inputs)
+        loss.backward()
+        res.append((loss.detach().clone(), out.predictor_output.last_hidden_state.detach().clone(), [p.grad.clone() for p in model.parameters()]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert all(torch.equal(a, b) for a, b in zip(res[0][2], res[1][2]))
+    # arrays of the wrong restriction: ignored (the unrestricted forward derives its own)
+    wrong = index_plumbing([with_arrays["context_mask"][0].long()], [with_arrays["target_mask"][0].long()], model.num_patches, "target")
+    a = model(pixel_values_videos=with_arrays["pixel_values_videos"], context_mask=with_arrays["context_mask"], target_mask=with_arrays["target_mask"],
+              smbv_plumbing=wrong)
+    b = model(pixel_values_videos=with_arrays["pixel_values_videos"], context_mask=with_arrays["context_mask"], target_mask=with_arrays["target_mask"])
+    assert torch.equal(a.last_hidden_state, b.last_hidden_state) and torch.equal(a.predictor_output.last_hidden_state, b.predictor_output.last_hidden_state)
