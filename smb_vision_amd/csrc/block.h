@@ -43,6 +43,7 @@ struct BwdScratch {  // sized for the widest block of the model
   float *delta, *gpad, *gpad_b;  // gpad / gpad_b: head-padded weight / bias gradients before un-padding (null when no block is padded)
   void* scratch;        // LN-bwd partials / colsum partials / gemm_tn slabs of the products that stay on the caller's stream
   size_t scratch_bytes;
+  void* ln2_part;       // LN2-bwd partials: their reduction runs on the side stream, so they outlive the LN1 backward that reuses `scratch`
   void* f8ws = nullptr; // quantised operands of the fp8 attention forward (null unless a block asks for it)
   size_t f8ws_bytes = 0;
   void* wscratch;       // gemm_tn slabs + column-sum partials of the weight-gradient products that run on the side stream

@@ -171,7 +171,7 @@ size_t layernorm_bwd_workspace_bytes(int rows, int D) { return (size_t)ln_bwd_bl
 
 int layernorm_bwd(const bf16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
                   float* dx, bf16_t* dx_bf16, float* dgamma, float* dbeta, int rows, int D, long grp_in, long grp_out,
-                  long row_off, void* ws, size_t ws_bytes, hipStream_t st) {
+                  long row_off, void* ws, size_t ws_bytes, hipStream_t st, bool launch_reduce) {
   if (rows <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * LN_MAXV) { set_error("layernorm_bwd: bad shape rows=%d D=%d", rows, D); return SMBV_ERR_SHAPE; }
   if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dres) & 15 || ((uintptr_t)dy & 7) || ((uintptr_t)dx_bf16 & 7)) { set_error("layernorm_bwd: alignment"); return SMBV_ERR_ALIGN; }
   const int nblk = ln_bwd_blocks(rows);
@@ -183,8 +183,14 @@ int layernorm_bwd(const bf16_t* dy, const float* x, const float* mean, const flo
   if (nv <= 1) LN_B(1); else if (nv <= 2) LN_B(2); else if (nv <= 3) LN_B(3); else if (nv <= 4) LN_B(4); else LN_B(8);
 #undef LN_B
   int rc = check_launch("layernorm_bwd");
-  if (rc) return rc;
+  if (rc || !launch_reduce) return rc;
   return reduce_cols(part, nblk, 2 * D, dgamma, dbeta, D, st);
+}
+
+// the parameter-gradient half of layernorm_bwd(..., launch_reduce = false): sums the per-block partials `ws` holds into dgamma / dbeta.  Nothing on the
+// input-gradient path reads them, so the block backward runs it on its side stream (block.hip) instead of between two kernels of the critical path.
+int layernorm_bwd_reduce(const void* ws, int rows, int D, float* dgamma, float* dbeta, hipStream_t st) {
+  return reduce_cols((const float*)ws, ln_bwd_blocks(rows), 2 * D, dgamma, dbeta, D, st);
 }
 
 }  // namespace smbv

@@ -55,7 +55,8 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t*
                   long grp_in, long grp_out, long row_off, hipStream_t st, float* y32 = nullptr);
 int layernorm_bwd(const bf16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres, float* dx,
                   bf16_t* dx_bf16, float* dgamma, float* dbeta, int rows, int D, long grp_in, long grp_out, long row_off, void* ws,
-                  size_t ws_bytes, hipStream_t st);
+                  size_t ws_bytes, hipStream_t st, bool launch_reduce = true);
+int layernorm_bwd_reduce(const void* ws, int rows, int D, float* dgamma, float* dbeta, hipStream_t st);
 size_t layernorm_bwd_workspace_bytes(int rows, int D);
 
 int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf16_t* O, int ldo, float* LSE, int B, int S, int H, int Dh,
