@@ -20,10 +20,12 @@
  *   - state inside the library: the immutable code object; a thread-local error string; per device, two private non-blocking side streams and a
  *     few events created on first use and kept for the life of the process (the block backward runs its weight-gradient products beside the
  *     input-gradient ones, the step forwards their weight casts beside the first kernels; everything forked is joined back into `stream` before the
- *     call returns); a 64-KiB `__device__` array of scheduling words for the attention backward (eight slots used round-robin; a launch's last
- *     block hands its slot back zeroed: block roles and tile queues of attn_bwd_pair_kernel - never results; attention-backward
- *     calls of one device are therefore expected on ONE stream at a time, as the step functions issue them); and the
- *     kernel-selection word of smbv_debug_set_variant() below (0 unless a tuning tool sets it).  Nothing else persists between calls.
+ *     call returns); a 64-KiB `__device__` array of scheduling words for the attention backward (block roles and tile queues of
+ *     attn_bwd_pair_kernel - never results): eight slots, each OWNED by one stream of the device (the first eight streams that run an attention
+ *     backward; a ninth takes a two-launch path with no shared state), every word stamped with its launch's epoch, so launches that share a slot
+ *     are always ordered by one stream and a word of another launch is detected, not consumed; 4 bytes of host-mapped status per device
+ *     (smbv_device_status below); and the kernel-selection word of smbv_debug_set_variant() below (0 unless a tuning tool sets it).  Nothing else
+ *     persists between calls.  The step / attention entry points are not meant to be captured into a hipGraph (the launch epochs are host counters).
  */
 #ifndef SMBV_H
 #define SMBV_H
@@ -39,6 +41,7 @@ extern "C" {
 #define SMBV_ERR_ALIGN (-2)
 #define SMBV_ERR_ARG (-3)
 #define SMBV_ERR_WORKSPACE (-4)
+#define SMBV_ERR_STATE (-5)      /* a kernel of an earlier call recorded a fault on this device: see smbv_device_status */
 #define SMBV_MAX_LAYERS 48
 
 typedef void* smbv_stream;   /* hipStream_t */
@@ -47,8 +50,9 @@ typedef uint16_t smbv_bf16;
 /* ABI version = major*1000 + minor.  A binding must check major == SMBV_ABI_MAJOR (struct layouts / argument meanings are only stable within one
  * major) and minor >= the newest entry point it calls.  2000: every *_cfg struct opens with `struct_bytes` (= sizeof of the caller's struct, checked
  * by the library: a binding compiled against a shorter or longer layout is refused with SMBV_ERR_ARG instead of being read past its end);
- * 1000-1002 (round 1-2) had no such guard and grew smbv_mim_cfg / smbv_vjepa_cfg in place. */
-#define SMBV_ABI_MAJOR 2
+ * 1000-1002 (round 1-2) had no such guard and grew smbv_mim_cfg / smbv_vjepa_cfg in place.  3000 (round 4): smbv_attention_fwd / smbv_attention_bwd take
+ * the residual output O_lo, the *_cfg structs end with attn_o_resid. */
+#define SMBV_ABI_MAJOR 3
 int smbv_version(void);
 int smbv_last_error(char* buf, size_t len);               /* copies the thread's last error text; returns its length */
 /* Tuning / A-B hook used by tools/ and by the kernel-equivalence tests, NOT by the product path: selects alternative kernels for the same
@@ -60,6 +64,15 @@ int smbv_last_error(char* buf, size_t len);               /* copies the thread's
  * units of the attention kernels (forward default 2, backward 0), 1<<29 no stagger; 1<<30 the library's side streams at the lowest priority (read once, when
  * they are created). */
 void smbv_debug_set_variant(int bits);
+/* The device's sticky status (ABI 3000).  A kernel that detects a fault it cannot return - today: the attention backward's block scheduler finding a
+ * scheduling word of another launch (0x5001 / 0x5003) or both of its tile queues exhausted (0x5002: a tile was skipped) - stores a code into 4 bytes of
+ * host-mapped memory; every smbv_*_forward / _backward / smbv_attention_bwd call on that device then returns SMBV_ERR_STATE instead of enqueueing more
+ * work on top of incomplete gradients.  This function reads it without synchronising (a fault shows once its kernel has run): 0, or SMBV_ERR_STATE with
+ * the code in smbv_last_error(); clear != 0 resets it.  Never set on a healthy run. */
+int smbv_device_status(int clear);
+/* Test hook for the above (NOT the product path): op 1 dirties the attention backward's scheduling slots on `stream` the way a second launch sharing a
+ * slot would, op 0 restores them (and the host's launch epochs) to their load-time state. */
+int smbv_debug_pair_state(int op, smbv_stream stream);
 
 /* ---- per-op entry points (also what the parity tests call) ------------------------------------------------------ */
 
@@ -101,8 +114,11 @@ size_t smbv_layernorm_bwd_workspace_bytes(int rows, int D);
  * modeling_vjepa.py:251-253); any other Dh is SMBV_ERR_SHAPE (the step functions run such heads zero-padded in 64-wide slots).  Q,K,V: column
  * slices of one token-major [B*S, ld] matrix (head h at columns h*Dh..); O: [B*S, ldo]; LSE/delta: fp32 [B,H,Sq].
  * Sq/q_off: only the queries q_off .. q_off+Sq-1 of every sequence are computed (keys/values: all S); Sq <= 0 means all.
- * (The last decoder block only needs its masked tokens' outputs: spec :717-718 keeps hidden_states[:, -return_token_num:].) */
-int smbv_attention_fwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, smbv_bf16* O, int ldo, float* LSE,
+ * (The last decoder block only needs its masked tokens' outputs: spec :717-718 keeps hidden_states[:, -return_token_num:].)
+ * O_lo (ABI 3000; may be NULL): same layout as O; the forward stores bf16(O_fp32 - O) there and the backward, given the same pointer, forms
+ * delta = rowsum(dO * (O + O_lo)), i.e. from the output to 16 significant bits.  A bf16 O alone puts a 2^-9 relative error into delta that the softmax
+ * Jacobian multiplies by the probability-weighted MEAN key / query - a term that does not average out over many near-uniform keys. */
+int smbv_attention_fwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, smbv_bf16* O, smbv_bf16* O_lo, int ldo, float* LSE,
                        int B, int S, int H, int Dh, float scale, int Sq, int q_off, smbv_stream stream);
 /* The same forward with OCP e4m3 operands on the block-scaled fp8 MFMA (BASELINE.json config 5: "fp8 MFMA QK^T / PV"): Q (pre-scaled), K per
  * (token, head, 32 channels) and V per (channel, 32 keys) under power-of-two E8M0 scales, P in e4m3 under a fixed 2^-7 scale; fp32 softmax and
@@ -110,7 +126,7 @@ int smbv_attention_fwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* 
 size_t smbv_attention_fp8_workspace_bytes(int B, int S, int H);
 int smbv_attention_fwd_fp8(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, smbv_bf16* O, int ldo, float* LSE, int B, int S, int H,
                            int Dh, float scale, int Sq, int q_off, void* ws, size_t ws_bytes, smbv_stream stream);
-int smbv_attention_bwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* dO,
+int smbv_attention_bwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* O_lo, const smbv_bf16* dO,
                        int ldo, const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S,
                        int H, int Dh, float scale, int parts /* bit0 delta, bit1 dK/dV, bit2 dQ; 7 = all */, int Sq, int q_off, smbv_stream stream);
 
@@ -155,6 +171,9 @@ typedef struct smbv_mim_cfg {
                                      one activation set per stack and re-run a block's forward in front of its backward.  Same results bit for bit,
                                      one extra forward of time, ~1/layers of the activation memory */
   int attn_fp8;                   /* 1 = attention forward with OCP e4m3 operands on the block-scaled fp8 MFMA (BASELINE config 5); 0 = bf16 */
+  int attn_o_resid;               /* 1 = every block's attention forward also saves the bf16 residual of its fp32 output, O_lo = bf16(O_fp32 - bf16(O_fp32)), and the
+                                     backward forms delta = rowsum(dO * (O + O_lo)) (see smbv_attention_fwd).  One more [rows, width] bf16 activation per block;
+                                     ignored with attn_fp8 */
 } smbv_mim_cfg;
 
 /* fp32 tensors of one VideoMAELayer in the pinned-era (vendored) state-dict layout. */
@@ -215,6 +234,7 @@ typedef struct smbv_encoder_cfg {
   int final_ln;                   /* VideoMAEModel.layernorm: present iff !config.use_mean_pooling (spec :517-520) */
   float final_ln_eps;
   int train;                      /* 0: inference (one shared activation set); 1: every layer keeps its activations for smbv_encoder_backward */
+  int attn_o_resid;               /* as smbv_mim_cfg.attn_o_resid (train = 1 only) */
 } smbv_encoder_cfg;
 
 typedef struct smbv_encoder_tensors {
@@ -303,6 +323,10 @@ typedef struct smbv_vjepa_cfg {
                                       any order is the same function: pred_pos carries the positions, modeling_vjepa.py:718-746 sorts and unsorts).  The predictor's
                                       output is read at the target tokens only (:737-738), so its LAST block then computes those Ntgt rows only.  0: slots in any
                                       order (e.g. the reference's position-sorted one), every block over all Nctx + Ntgt rows */
+  int attn_o_resid;                /* as smbv_mim_cfg.attn_o_resid.  The V-JEPA encoder at init scale is the case it exists for: attention over 20,480 near-identical
+                                      tokens is uniform, dQ / dK are what survives a 1/sqrt(S) cancellation, and the 2^-9 rounding of a bf16 O inside delta does not
+                                      cancel (10-15 % on some query / key weight gradients at 512x512x320 without it).  Set 0 for a forward that
+                                      is never differentiated (the frozen target encoder) */
 } smbv_vjepa_cfg;
 
 /* fp32 tensors of one VJEPA2Layer: norm1, attention.{query,key,value,proj}.{weight,bias}, norm2, mlp.{fc1,fc2} */

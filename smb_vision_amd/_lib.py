@@ -10,7 +10,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsmbv.so")
 MAX_LAYERS = 48
-ABI_MAJOR, ABI_MINOR_NEEDED = 2, 0  # include/smbv.h SMBV_ABI_MAJOR; the newest entry point these bindings call
+ABI_MAJOR, ABI_MINOR_NEEDED = 3, 0  # include/smbv.h SMBV_ABI_MAJOR; the newest entry point these bindings call
 
 c_f = C.c_void_p  # all device pointers travel as void*
 
@@ -38,7 +38,7 @@ class _Cfg(C.Structure):
 class MimCfg(_Cfg):
     _fields_ = [(n, C.c_int) for n in
                 ("struct_bytes", "B", "T", "H", "W", "ps", "ts", "N", "Nvis", "Nmask", "d", "heads", "ff", "layers", "dd", "dheads", "dff", "dlayers")] + \
-               [("ln_eps", C.c_float), ("dec_norm_eps", C.c_float), ("recompute", C.c_int), ("attn_fp8", C.c_int)]
+               [("ln_eps", C.c_float), ("dec_norm_eps", C.c_float), ("recompute", C.c_int), ("attn_fp8", C.c_int), ("attn_o_resid", C.c_int)]
 
 
 LAYER_FIELDS = ("ln1_w", "ln1_b", "q_w", "k_w", "v_w", "q_b", "v_b", "proj_w", "proj_b", "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
@@ -60,7 +60,7 @@ class MimIO(C.Structure):
 
 class EncoderCfg(_Cfg):
     _fields_ = [(n, C.c_int) for n in ("struct_bytes", "B", "T", "H", "W", "ps", "ts", "N", "Nsel", "d", "heads", "ff", "layers")] + \
-               [("ln_eps", C.c_float), ("final_ln", C.c_int), ("final_ln_eps", C.c_float), ("train", C.c_int)]
+               [("ln_eps", C.c_float), ("final_ln", C.c_int), ("final_ln_eps", C.c_float), ("train", C.c_int), ("attn_o_resid", C.c_int)]
 
 
 class EncoderTensors(C.Structure):
@@ -82,7 +82,7 @@ class AdamHyper(C.Structure):
 
 class VjepaCfg(_Cfg):
     _fields_ = [(n, C.c_int) for n in ("struct_bytes", "B", "T", "H", "W", "ps", "ts", "N", "Nctx", "Ntgt", "d", "heads", "ff", "layers", "pd", "pheads", "pff", "players")] + \
-               [("ln_eps", C.c_float), ("n_masks", C.c_int), ("enc_needed", C.c_int), ("pred_tgt_first", C.c_int)]
+               [("ln_eps", C.c_float), ("n_masks", C.c_int), ("enc_needed", C.c_int), ("pred_tgt_first", C.c_int), ("attn_o_resid", C.c_int)]
 
 
 BLOCK_FIELDS = ("ln1_w", "ln1_b", "q_w", "k_w", "v_w", "q_b", "k_b", "v_b", "proj_w", "proj_b", "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
@@ -106,6 +106,8 @@ _SIGS = {
     "smbv_version": (C.c_int, []),
     "smbv_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
     "smbv_debug_set_variant": (None, [C.c_int]),
+    "smbv_device_status": (C.c_int, [C.c_int]),
+    "smbv_debug_pair_state": (C.c_int, [C.c_int, c_f]),
     "smbv_gemm_nt": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GemmEpi), c_f]),
     "smbv_gemm_tn": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f, C.c_size_t, c_f]),
     "smbv_gemm_tn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -113,10 +115,10 @@ _SIGS = {
     "smbv_layernorm_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_float, C.c_long, C.c_long, C.c_long, c_f]),
     "smbv_layernorm_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, c_f, C.c_size_t, c_f]),
     "smbv_layernorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
-    "smbv_attention_fwd": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, c_f]),
+    "smbv_attention_fwd": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, c_f]),
     "smbv_attention_fp8_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "smbv_attention_fwd_fp8": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, c_f, C.c_size_t, c_f]),
-    "smbv_attention_bwd": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, c_f]),
+    "smbv_attention_bwd": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, c_f]),
     "smbv_prepare_volume": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, c_f]),
     "smbv_gather_bricks": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "smbv_brick_stats": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),

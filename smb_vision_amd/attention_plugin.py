@@ -31,17 +31,17 @@ class _SmbvAttentionFn(torch.autograd.Function):
         packed[:, :, 0].copy_(query.transpose(1, 2))
         packed[:, :, 1].copy_(key.transpose(1, 2))
         packed[:, :, 2].copy_(value.transpose(1, 2))
-        out, lse = ops.attention_fwd(qkv, B, S, H, scale=scaling, Dh=Dh)
-        ctx.save_for_backward(qkv, out, lse)
+        out, lse, out_lo = ops.attention_fwd(qkv, B, S, H, scale=scaling, Dh=Dh, resid=True)  # (+ the bf16 residual of the fp32 output, for delta)
+        ctx.save_for_backward(qkv, out, lse, out_lo)
         ctx.dims = (B, H, S, Dh, scaling, query.dtype)
         return out.view(B, S, H, Dh).to(query.dtype)
 
     @staticmethod
     def backward(ctx, d_out):
-        qkv, out, lse = ctx.saved_tensors
+        qkv, out, lse, out_lo = ctx.saved_tensors
         B, H, S, Dh, scaling, dtype = ctx.dims
         d_rows = d_out.reshape(B * S, H * Dh).to(torch.bfloat16).contiguous()
-        d_qkv, _ = ops.attention_bwd(qkv, out, d_rows, lse, B, S, H, scale=scaling, Dh=Dh)
+        d_qkv, _ = ops.attention_bwd(qkv, out, d_rows, lse, B, S, H, scale=scaling, Dh=Dh, O_lo=out_lo)
         d = d_qkv.view(B, S, 3, H, Dh)
         return (d[:, :, 0].transpose(1, 2).to(dtype), d[:, :, 1].transpose(1, 2).to(dtype), d[:, :, 2].transpose(1, 2).to(dtype), None)
 

@@ -15,7 +15,7 @@
 #include "smbv_common.h"
 #include "smbv_kernels.h"
 #include "block.h"
-#include <atomic>
+#include <mutex>
 #include <type_traits>
 
 namespace smbv {
@@ -59,7 +59,7 @@ __device__ __forceinline__ bf16x8 scale_frag(u32x4 v, float c) {
 }
 
 template <int DH>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO, int ldo,
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ Olo, const bf16_t* __restrict__ dO, int ldo,
                                                          float* __restrict__ delta, int B, int S, int Sq, int qoff, int H) {
   // DH / 8 lanes per (row, head): 16 B each
   constexpr int LP = DH / 8;
@@ -74,8 +74,14 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     const int head = pair % H;
     const u32x4 o = *(const u32x4*)(O + row * ldo + head * DH + sub * 8);
     const u32x4 g = *(const u32x4*)(dO + row * ldo + head * DH + sub * 8);
+    if (Olo) {  // O = hi + lo (the forward's bf16 residual of its fp32 output)
+      const u32x4 ol = *(const u32x4*)(Olo + row * ldo + head * DH + sub * 8);
 #pragma unroll
-    for (int i = 0; i < 4; i++) acc += bf_lo(o[i]) * bf_lo(g[i]) + bf_hi(o[i]) * bf_hi(g[i]);
+      for (int i = 0; i < 4; i++) acc += (bf_lo(o[i]) + bf_lo(ol[i])) * bf_lo(g[i]) + (bf_hi(o[i]) + bf_hi(ol[i])) * bf_hi(g[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc += bf_lo(o[i]) * bf_lo(g[i]) + bf_hi(o[i]) * bf_hi(g[i]);
+    }
   }
   acc += __shfl_xor(acc, 1, 64);
   acc += __shfl_xor(acc, 2, 64);
@@ -788,19 +794,27 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
 // the role the ticket's parity names - the CU's two resident blocks are then one of each kind whenever both kinds have tiles left - and claims the next
 // tile of that role from a device-side queue (or of the other role once its own is exhausted).  Which block computes which tile does not change a single
 // bit of the result: every tile's arithmetic is self-contained.
-struct PairState {            // one slot of the library's device-side scheduling state (zero at module load; every launch leaves its slot as it found it)
-  unsigned head[2];           // next unclaimed tile: [0] key-owner tiles, [1] query-owner tiles - reset by the launch's last block
-  unsigned done;              // blocks of the running launch that have ended
+struct PairState {            // one slot of the library's device-side scheduling state; a slot belongs to ONE stream of its device (attention_bwd, below)
+  unsigned head[2];           // next unclaimed tile: [0] key-owner tiles, [1] query-owner tiles   } each word = (launch epoch & 0xfff) << 20 | count:
+  unsigned done;              // blocks of the running launch that have ended                      } a launch only accepts words stamped with ITS epoch
   unsigned pad[13];
-  unsigned cu_ticket[2048];   // arrival counter per CU, indexed by (XCC id, SE id, SH id, CU id): 3 + 3 + 1 + 4 bits - reset by the launch's last block
+  unsigned cu_ticket[2048];   // arrival counter per CU, indexed by (XCC id, SE id, SH id, CU id): 3 + 3 + 1 + 4 bits (parity only: roles, never results)
 };
 __device__ PairState g_pair_state[8];
+static constexpr unsigned PAIR_COUNT_MASK = 0xfffffu;
+// Scheduling faults are reported, not absorbed: a word that does not carry the launch's epoch (two launches in one slot at once, a slot left dirty), a
+// block that finds both tile queues exhausted (some tile was skipped) - each stores a code into the device's host-mapped status word
+// (streams.hip device_status_word), which every later entry point of the library returns as SMBV_ERR_STATE.  Codes: include/smbv.h smbv_device_status.
+__device__ __forceinline__ void pair_fault(unsigned* status, unsigned code) {
+  if (status) __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 template <int DH, bool QMFMA16>
 __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, int ld,
                                                                const bf16_t* __restrict__ dO, int ldo, const float* __restrict__ LSE,
                                                                const float* __restrict__ delta, bf16_t* __restrict__ dQ, bf16_t* __restrict__ dK,
-                                                               bf16_t* __restrict__ dV, int ldd, int B, int S, int Sq, int qoff, int H, float scale, int slot) {
+                                                               bf16_t* __restrict__ dV, int ldd, int B, int S, int Sq, int qoff, int H, float scale, int slot,
+                                                               unsigned epoch, unsigned* __restrict__ status) {
   constexpr int LDS = DkvLds<128, DH>::BYTES > DqLds<128, DH>::BYTES ? DkvLds<128, DH>::BYTES : DqLds<128, DH>::BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS];
   PairState& ps = g_pair_state[slot];
@@ -813,10 +827,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __r
     // arrivals on a CU alternate (balancing what is RESIDENT on the CU instead - a counter every block undoes when it ends - measured the same:
     // profiles/r03_attn_pair_ab.txt)
     unsigned role = atomicAdd(&ps.cu_ticket[cu], 1u) & 1u;
-    unsigned tile = atomicAdd(&ps.head[role], 1u);
-    if (tile >= (role ? n_q : n_kv)) { role ^= 1u; tile = atomicAdd(&ps.head[role], 1u); }
-    // (the grid has exactly one block per tile, so the second queue cannot be exhausted as well; a block that found it so would idle, not run a tile twice)
-    if (tile >= (role ? n_q : n_kv)) role = 2u;
+    unsigned t = atomicAdd(&ps.head[role], 1u);
+    bool stale = (t >> 20) != epoch;
+    unsigned tile = t & PAIR_COUNT_MASK;
+    if (!stale && tile >= (role ? n_q : n_kv)) {
+      role ^= 1u;
+      t = atomicAdd(&ps.head[role], 1u);
+      stale = (t >> 20) != epoch;
+      tile = t & PAIR_COUNT_MASK;
+    }
+    // The grid has exactly one block per tile, so with a clean slot the second queue cannot be exhausted as well.  A block that finds it so - or a word
+    // of another epoch - runs no tile (never one twice, never one out of range) and raises the fault.
+    if (stale) { pair_fault(status, 0x5001u); role = 2u; }
+    else if (tile >= (role ? n_q : n_kv)) { pair_fault(status, 0x5002u); role = 2u; }
     bc[0] = (int)role;
     bc[1] = (int)tile;
   }
@@ -831,44 +854,101 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __r
     if constexpr (QMFMA16) attn_dq3_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
     else attn_dq2_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
   }
-  // the block that ends last (every other block has claimed its tile long ago) hands the slot back zeroed: no memset node in front of the next launch
-  // (a fill kernel of ~8 us on the critical path, 16 per MIM step)
+  // the block that ends last (every other block has claimed its tile long ago) hands the slot over stamped with the NEXT epoch: no memset node in front of
+  // the next launch (a fill kernel of ~8 us on the critical path, 16 per MIM step)
   __syncthreads();  // (the block's waves are done with the LDS the flag below travels through)
-  if (threadIdx.x == 0) bc[0] = atomicAdd(&ps.done, 1u) == gridDim.x - 1 ? 1 : 0;
+  if (threadIdx.x == 0) {
+    const unsigned d = atomicAdd(&ps.done, 1u);
+    if ((d >> 20) != epoch) { pair_fault(status, 0x5003u); bc[0] = 0; }
+    else bc[0] = (d & PAIR_COUNT_MASK) == gridDim.x - 1 ? 1 : 0;
+  }
   __syncthreads();
   if (bc[0]) {
-    if (threadIdx.x == 0) { ps.head[0] = 0; ps.head[1] = 0; ps.done = 0; }
+    const unsigned next = ((epoch + 1u) & 0xfffu) << 20;
+    if (threadIdx.x == 0) { ps.head[0] = next; ps.head[1] = next; ps.done = next; }
     for (int i = threadIdx.x; i < 2048; i += 256) ps.cu_ticket[i] = 0;   // every launch starts with "first arrival on a CU = key-owner block"
   }
 }
 
+// debug hooks (smbv_debug_pair_state, include/smbv.h): op 1 = dirty every slot's key-owner queue (what an overlapping second launch would do),
+// op 0 = every slot back to its module-load state
+__global__ void pair_state_debug_kernel(int op) {
+  const int slot = blockIdx.x;
+  PairState& ps = g_pair_state[slot];
+  if (op == 1) { if (threadIdx.x == 0) atomicAdd(&ps.head[0], 3u); return; }
+  if (threadIdx.x == 0) { ps.head[0] = 0; ps.head[1] = 0; ps.done = 0; }
+  for (int i = threadIdx.x; i < 2048; i += 256) ps.cu_ticket[i] = 0;
+}
+
+// Host side of the slots: per device, a slot belongs to the first stream that used it (at most 8 streams per device run the pair launch; further
+// streams take the two-launch path, which has no shared state), and the slot's launch epoch counts that stream's launches.  A slot is therefore only
+// ever touched by launches that are ordered by ONE stream: the previous launch's last block has re-stamped it before the next one starts.
+struct PairHost {
+  hipStream_t streams[8];
+  unsigned epoch[8];
+  int n = 0;
+};
+static PairHost g_pair_host[64];
+static std::mutex g_pair_mu;
+
+// returns the slot of (current device, st) and its next epoch, or -1 when all 8 slots of the device belong to other streams
+static int pair_slot_for(hipStream_t st, unsigned* epoch, bool reset = false) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  std::lock_guard<std::mutex> lk(g_pair_mu);
+  PairHost& h = g_pair_host[dev];
+  if (reset) { h.n = 0; return 0; }
+  int slot = -1;
+  for (int i = 0; i < h.n; i++) if (h.streams[i] == st) { slot = i; break; }
+  if (slot < 0) {
+    if (h.n >= 8) return -1;
+    slot = h.n++;
+    h.streams[slot] = st;
+    h.epoch[slot] = 0;
+  }
+  *epoch = h.epoch[slot];
+  h.epoch[slot] = (h.epoch[slot] + 1u) & 0xfffu;
+  return slot;
+}
+
+int pair_state_debug(int op, hipStream_t st) {
+  if (op != 0 && op != 1) { set_error("smbv_debug_pair_state: op %d (0 = reset, 1 = dirty)", op); return SMBV_ERR_ARG; }
+  hipLaunchKernelGGL(pair_state_debug_kernel, dim3(8), dim3(256), 0, st, op);
+  if (op == 0) { unsigned e; pair_slot_for(nullptr, &e, true); }   // the host's epochs restart with the slots
+  return check_launch("pair_state_debug");
+}
+
 int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
-                  float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st) {
+                  float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st,
+                  const bf16_t* O_lo) {
   if (Sq <= 0) { Sq = S; qoff = 0; }
   if (qoff < 0 || qoff + Sq > S) { set_error("attention_bwd: query range outside the sequence"); return SMBV_ERR_SHAPE; }
   if (Dh != 64 && Dh != 32) { set_error("attention_bwd: head_dim %d not supported (64 or 32; other widths run zero-padded in 64-wide slots, block.h)", Dh); return SMBV_ERR_SHAPE; }
   if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 7) || (ldd & 3)) { set_error("attention_bwd: bad shape"); return SMBV_ERR_SHAPE; }
-  if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)dO) & 15) || (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 7)) { set_error("attention_bwd: alignment"); return SMBV_ERR_ALIGN; }
+  if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)O_lo | (uintptr_t)dO) & 15) || (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 7)) { set_error("attention_bwd: alignment"); return SMBV_ERR_ALIGN; }
   if ((size_t)(S + 256) * ld * 2 >= (1ull << 31) || (size_t)(S + 256) * ldo * 2 >= (1ull << 31)) { set_error("attention_bwd: one sequence spans >= 2 GiB of an operand matrix; the LDS-DMA offsets are 32-bit"); return SMBV_ERR_SHAPE; }
   const long pairs = (long)B * Sq * H;
   int rc = SMBV_OK;
   if (parts & 1) {
-    if (Dh == 64) hipLaunchKernelGGL(attn_delta_kernel<64>, dim3(cdiv(pairs * 8, 256)), dim3(256), 0, st, O, dO, ldo, delta, B, S, Sq, qoff, H);
-    else hipLaunchKernelGGL(attn_delta_kernel<32>, dim3(cdiv(pairs * 4, 256)), dim3(256), 0, st, O, dO, ldo, delta, B, S, Sq, qoff, H);
+    if (Dh == 64) hipLaunchKernelGGL(attn_delta_kernel<64>, dim3(cdiv(pairs * 8, 256)), dim3(256), 0, st, O, O_lo, dO, ldo, delta, B, S, Sq, qoff, H);
+    else hipLaunchKernelGGL(attn_delta_kernel<32>, dim3(cdiv(pairs * 4, 256)), dim3(256), 0, st, O, O_lo, dO, ldo, delta, B, S, Sq, qoff, H);
     rc = check_launch("attn_delta");
     if (rc) return rc;
   }
   // both products: ONE launch with mixed block roles (attn_bwd_pair_kernel: -1.3 % encoder, -2.9 % decoder, -3.7 % at head_dim 32, -6.4 % at S = 20,480 x
-  // 12 heads against the two launches side by side, bitwise the same gradients: tools/attn_pair_ab.py); debug bit 524288 keeps the two launches
-  if ((parts & 6) == 6 && !(g_variant & 524288)) {
-    static std::atomic<unsigned> next_slot{0};   // consecutive launches use different slots; one stream at a time per device (include/smbv.h)
-    const int slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) & 7u);
+  // 12 heads against the two launches side by side, bitwise the same gradients: tests/test_ops_gpu.py); debug bit 524288 keeps the two launches, and so
+  // does a ninth stream of one device (every slot of the scheduling state is owned by another stream)
+  unsigned epoch = 0;
+  const int slot = ((parts & 6) == 6 && !(g_variant & 524288)) ? pair_slot_for(st, &epoch) : -1;
+  if (slot >= 0) {
     const int blocks = (cdiv(S, 128) + cdiv(Sq, 128)) * H * B;
+    if ((unsigned)blocks >= PAIR_COUNT_MASK) { set_error("attention_bwd: %d tiles exceed the pair launch's 20-bit tile counters", blocks); return SMBV_ERR_SHAPE; }
+    unsigned* status = device_status_word_dev();   // host-mapped; null if it could not be created (faults then go unreported, as before round 4)
     const bool q16 = !(g_variant & 2);   // A/B: bit 1 = the query-owner block on the 32x32x16 MFMA (attn_dq2_block)
-    if (Dh == 64 && q16) hipLaunchKernelGGL((attn_bwd_pair_kernel<64, true>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot);
-    else if (Dh == 64) hipLaunchKernelGGL((attn_bwd_pair_kernel<64, false>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot);
-    else if (q16) hipLaunchKernelGGL((attn_bwd_pair_kernel<32, true>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot);
-    else hipLaunchKernelGGL((attn_bwd_pair_kernel<32, false>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot);
+    if (Dh == 64 && q16) hipLaunchKernelGGL((attn_bwd_pair_kernel<64, true>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot, epoch, status);
+    else if (Dh == 64) hipLaunchKernelGGL((attn_bwd_pair_kernel<64, false>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot, epoch, status);
+    else if (q16) hipLaunchKernelGGL((attn_bwd_pair_kernel<32, true>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot, epoch, status);
+    else hipLaunchKernelGGL((attn_bwd_pair_kernel<32, false>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot, epoch, status);
     return check_launch("attn_bwd_pair");
   }
   // dK/dV and dQ are independent (disjoint outputs, shared read-only inputs).  Their grids rarely fill a whole number of

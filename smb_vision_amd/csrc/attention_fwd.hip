@@ -66,7 +66,7 @@ __device__ __forceinline__ bf16x8 scale_bf16x8(u32x4 v, float c) {
 // the V image needs no swizzle at all (the 4 keys x 2 column halves x 4 sub-columns of a tr-read group already tile the 64 banks).
 template <int DH>
 __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, int ld,
-                                                           bf16_t* __restrict__ O, int ldo, float* __restrict__ LSE, int S, int Sq, int qoff, int H, float scale, int guarded_only, int xcd_order) {
+                                                           bf16_t* __restrict__ O, bf16_t* __restrict__ Olo, int ldo, float* __restrict__ LSE, int S, int Sq, int qoff, int H, float scale, int guarded_only, int xcd_order) {
   static_assert(DH == 64 || DH == 32, "head widths with a native build");
   constexpr int KS = DH / 16, DT = DH / 32, RB = 2 * DH;  // QK^T k-steps, 32-channel output tiles, LDS row bytes
   constexpr int IMG = 64 * RB, SLOT = 2 * IMG;           // K image | V image
@@ -268,8 +268,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restr
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
         const int d0 = 32 * dt + 8 * rg + 4 * h2;
-        u32x2 pk = {pack_bf16(ot[dt][4 * rg] * inv, ot[dt][4 * rg + 1] * inv), pack_bf16(ot[dt][4 * rg + 2] * inv, ot[dt][4 * rg + 3] * inv)};
+        const float o0 = ot[dt][4 * rg] * inv, o1 = ot[dt][4 * rg + 1] * inv, o2 = ot[dt][4 * rg + 2] * inv, o3 = ot[dt][4 * rg + 3] * inv;
+        const u32x2 pk = {pack_bf16(o0, o1), pack_bf16(o2, o3)};
         *(u32x2*)(op + d0) = pk;
+        if (Olo) {  // the bf16 residual of the fp32 output: O_hi + O_lo carries 16 significant bits into delta = rowsum(dO * O) (attention_bwd.hip)
+          const u32x2 lo = {pack_bf16(o0 - bf_lo(pk[0]), o1 - bf_hi(pk[0])), pack_bf16(o2 - bf_lo(pk[1]), o3 - bf_hi(pk[1]))};
+          *(u32x2*)(Olo + (row0 + qoff + q) * ldo + hoff + d0) = lo;
+        }
       }
     if (h2 == 0) LSE[((size_t)b * H + head) * Sq + q] = (m2 + __log2f(l_tot)) * 0.6931471805599453f;
   }
@@ -278,12 +283,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(const bf16_t* __restr
 extern int g_variant;  // debug hook, capi.hip (smbv_debug_set_variant)
 
 int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf16_t* O, int ldo, float* LSE, int B, int S, int H, int Dh,
-                  float scale, int Sq, int qoff, hipStream_t st) {
+                  float scale, int Sq, int qoff, hipStream_t st, bf16_t* O_lo) {
   if (Sq <= 0) { Sq = S; qoff = 0; }
   if (qoff < 0 || qoff + Sq > S) { set_error("attention_fwd: query range [%d, %d) outside the sequence (%d)", qoff, qoff + Sq, S); return SMBV_ERR_SHAPE; }
   if (Dh != 64 && Dh != 32) { set_error("attention_fwd: head_dim %d not supported (64 or 32; other widths run zero-padded in 64-wide slots, block.h)", Dh); return SMBV_ERR_SHAPE; }
   if (B <= 0 || S <= 0 || H <= 0 || (ld & 7) || (ldo & 3)) { set_error("attention_fwd: bad shape B=%d S=%d H=%d ld=%d ldo=%d", B, S, H, ld, ldo); return SMBV_ERR_SHAPE; }
-  if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || ((uintptr_t)O & 7)) { set_error("attention_fwd: alignment"); return SMBV_ERR_ALIGN; }
+  if ((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) || (((uintptr_t)O | (uintptr_t)O_lo) & 7)) { set_error("attention_fwd: alignment"); return SMBV_ERR_ALIGN; }
   if ((size_t)(S + 512) * ld * 2 >= (1ull << 31)) { set_error("attention_fwd: one sequence spans %zu bytes of the QKV matrix; the LDS-DMA offsets are 32-bit", (size_t)S * ld * 2); return SMBV_ERR_SHAPE; }
   // start-up stagger by SIMD wave slot (smbv_common.h): 2 x 512 clocks per slot; -1 % (head_dim 64) .. -3 % (head_dim 32) for the forward, null for the backward
   // kernels (profiles/r03_attn_stagger_ab.txt); bits 26-28 override the units, bit 29 switches it off
@@ -291,8 +296,8 @@ int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf1
   const int xo = ((g_variant & (1 << 24)) ? 0 : 1) | (stag << 8);
   const bool xgrid = xo & 1;  // XCD-aware block order (smbv_common.h xcd_block_order): -1..3 % at every shape (tools/attn_ab.py); bit 24 = plain grid
   const dim3 grid = xgrid ? dim3(cdiv(Sq, 128) * H * B) : dim3(cdiv(Sq, 128), H, B);
-  if (Dh == 64) hipLaunchKernelGGL(attn_fwd3_kernel<64>, grid, dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale, (g_variant & 2048) ? 1 : 0, xo);
-  else hipLaunchKernelGGL(attn_fwd3_kernel<32>, grid, dim3(256), 0, st, Q, K, V, ld, O, ldo, LSE, S, Sq, qoff, H, scale, (g_variant & 2048) ? 1 : 0, xo);
+  if (Dh == 64) hipLaunchKernelGGL(attn_fwd3_kernel<64>, grid, dim3(256), 0, st, Q, K, V, ld, O, O_lo, ldo, LSE, S, Sq, qoff, H, scale, (g_variant & 2048) ? 1 : 0, xo);
+  else hipLaunchKernelGGL(attn_fwd3_kernel<32>, grid, dim3(256), 0, st, Q, K, V, ld, O, O_lo, ldo, LSE, S, Sq, qoff, H, scale, (g_variant & 2048) ? 1 : 0, xo);
   return check_launch("attention_fwd");
 }
 

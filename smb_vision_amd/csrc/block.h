@@ -25,6 +25,8 @@ struct BlockDims {
   const int* pos = nullptr;       // token position ids for RoPE (null = index within the sequence)
   const float* rope_table = nullptr;
   int attn_fp8 = 0;               // 1: attention forward on the block-scaled fp8 MFMA (attention_fp8.hip); the backward stays bf16
+  int o_resid = 0;                // 1: the attention forward also saves the bf16 residual of its fp32 output (LayerWs::attn_o_lo) and the backward's
+                                  // delta = rowsum(dO * O) is formed from O + O_lo (not with attn_fp8, whose forward keeps no fp32 output tile layout in common)
   int slot() const { return Dh == 32 ? 32 : 64; }  // columns a head occupies in the QKV / attention-output matrices
   int wa() const { return H * slot(); }
   bool padded() const { return Dh != slot(); }
@@ -35,6 +37,7 @@ struct LayerWs {
   bf16_t *wqkv, *wqkv_t, *proj, *proj_t, *fc1, *fc1_t, *fc2, *fc2_t;  // bf16 operand copies of the weights
   float* bqkv;
   bf16_t *ln1, *qkv, *attn_o, *ln2, *pre, *act;                       // saved activations
+  bf16_t* attn_o_lo = nullptr;                                        // bf16(O_fp32 - attn_o) when BlockDims::o_resid, else null
   float *mean1, *rstd1, *mean2, *rstd2, *lse, *x_mid;
 };
 
@@ -73,6 +76,14 @@ struct SideStream {
   int end(hipStream_t caller);
   ~SideStream() { if (used) end(caller_); }  // an error return between begin() and end() still joins the side stream back into the caller's
 };
+
+// The device's sticky status word (streams.hip): 4 bytes of host-mapped memory per device, written by kernels that detect a fault they cannot return
+// (attention_bwd.hip pair_fault) and read - without synchronising - by every entry point: non-zero = the library refuses further work on that device
+// with SMBV_ERR_STATE until smbv_device_status(1) clears it.
+unsigned* device_status_word_dev();            // device-side address for kernel arguments (null if the word could not be created)
+int device_status(bool clear);                 // SMBV_OK, or SMBV_ERR_STATE with the fault code in the error text
+int pair_state_debug(int op, hipStream_t st);  // attention_bwd.hip
+#define SMBV_CHECK_DEVICE_STATE() do { int _ds = smbv::device_status(false); if (_ds) return _ds; } while (0)
 
 struct Carver {
   char* base;

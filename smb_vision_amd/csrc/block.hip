@@ -20,6 +20,7 @@ void carve_layer(Carver& c, LayerWs& L, const BlockDims& d, const LayerWs* share
   L.ln1 = c.take<bf16_t>(rows * w);
   L.qkv = c.take<bf16_t>(rows * 3 * wa);
   L.attn_o = c.take<bf16_t>(rows * wa);
+  L.attn_o_lo = (d.o_resid && !d.attn_fp8) ? c.take<bf16_t>(rows * wa) : nullptr;
   L.ln2 = c.take<bf16_t>(rows * w);
   L.pre = c.take<bf16_t>(rows * ff);
   L.act = c.take<bf16_t>(rows * ff);
@@ -120,7 +121,7 @@ int layer_fwd(const BlockPtrs& p, LayerWs& L, const BlockDims& d, BwdScratch& sc
   if (d.rope_grid > 0) RC(rope3d(L.qkv, 3 * wa, wa, M, S, H, d.slot(), d.Dh, d.rope_grid, d.pos, d.rope_table, 0, st));
   if (d.attn_fp8 && d.slot() != 64) { set_error("layer_fwd: the fp8 attention forward is built for 64-wide head slots (head_dim %d)", d.Dh); return SMBV_ERR_SHAPE; }
   if (d.attn_fp8) RC(attention_fwd_fp8(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, wa, L.lse, B, S, H, 64, d.scale(), Sq, qoff, sc.f8ws, sc.f8ws_bytes, st));
-  else RC(attention_fwd(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, wa, L.lse, B, S, H, d.slot(), d.scale(), Sq, qoff, st));
+  else RC(attention_fwd(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, wa, L.lse, B, S, H, d.slot(), d.scale(), Sq, qoff, st, L.attn_o_lo));
   if (Sq > 0) {
     // ranged tail: projection + MLP on the Sq tokens only; x_mid / x_out keep the full [B*S, w] layout, ln2 / pre / act are compact
     const int Mq = B * Sq;
@@ -230,15 +231,16 @@ int layer_bwd(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDi
     GemmEpi e; e.out_bf16 = sc.d_o; e.ld_ob = wa;
     if (ranged) { e.out_bf16 = sc.d_o + (size_t)qoff * wa; e.grp_in = Sq; e.grp_out = S; }
     // delta = rowsum(dO * O) per (token, head) comes out of this product's epilogue (gemm.hip) instead of a launch of its own in attention_bwd
-    e.dot_with = L.attn_o + (ranged ? (size_t)qoff * wa : 0); e.ld_dot = wa; e.dot_dh = d.slot(); e.dot_rows = ranged ? Sq : S; e.dot_out = sc.delta;
+    e.dot_with = L.attn_o + (ranged ? (size_t)qoff * wa : 0); e.ld_dot = wa;
+    if (L.attn_o_lo) e.dot_with_lo = L.attn_o_lo + (ranged ? (size_t)qoff * wa : 0); e.dot_dh = d.slot(); e.dot_rows = ranged ? Sq : S; e.dot_out = sc.delta;
     if (!(g_variant & 4096) && gemm_nt_rowdot_ok(w, w, Mq, wa, w, e)) delta_fused = true;
-    else { e.dot_with = nullptr; e.dot_out = nullptr; }
+    else { e.dot_with = nullptr; e.dot_with_lo = nullptr; e.dot_out = nullptr; }
     RC(gemm_nt(g2c, w, L.proj_t, w, Mq, wa, w, e, st));
   }
   // ---- attention (dQ exists only for the ranged queries; dK/dV for every token) ----
   if (ranged) HIPRC(hipMemsetAsync(sc.d_qkv, 0, (size_t)M * 3 * wa * sizeof(bf16_t), st));
   RC(attention_bwd(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, sc.d_o, wa, L.lse, sc.delta, sc.d_qkv, sc.d_qkv + wa, sc.d_qkv + 2 * wa, 3 * wa, B,
-                   S, H, d.slot(), d.scale(), delta_fused ? 6 : 7, Sq, qoff, st));
+                   S, H, d.slot(), d.scale(), delta_fused ? 6 : 7, Sq, qoff, st, L.attn_o_lo));
   if (d.rope_grid > 0) RC(rope3d(sc.d_qkv, 3 * wa, wa, M, S, H, d.slot(), d.Dh, d.rope_grid, d.pos, d.rope_table, 1, st));
   // ---- QKV ----
   // (the three products forked above had the whole attention backward to finish: joining them here costs nothing and makes every later

@@ -1,6 +1,7 @@
 // extern "C" surface of libsmbv.so (declared in include/smbv.h) + error plumbing.
 #include "smbv_common.h"
 #include "smbv_kernels.h"
+#include "block.h"
 #include "../../include/smbv.h"
 #include <cstdarg>
 #include <cstdio>
@@ -48,8 +49,10 @@ using namespace smbv;
 
 extern "C" {
 
-int smbv_version(void) { return 2000; }  // 2000: *_cfg structs open with struct_bytes (validated); see include/smbv.h
+int smbv_version(void) { return 3000; }  // 3000: O_lo in smbv_attention_fwd / _bwd, attn_o_resid in the *_cfg structs; see include/smbv.h
 void smbv_debug_set_variant(int bits) { smbv::g_variant = bits; }
+int smbv_device_status(int clear) { return smbv::device_status(clear != 0); }
+int smbv_debug_pair_state(int op, smbv_stream stream) { return smbv::pair_state_debug(op, (hipStream_t)stream); }
 
 int smbv_last_error(char* buf, size_t len) {
   const size_t n = strlen(g_err);
@@ -92,10 +95,10 @@ int smbv_layernorm_bwd(const smbv_bf16* dy, const float* x, const float* mean, c
 }
 size_t smbv_layernorm_bwd_workspace_bytes(int rows, int D) { return layernorm_bwd_workspace_bytes(rows, D); }
 
-int smbv_attention_fwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, smbv_bf16* O, int ldo, float* LSE, int B, int S, int H,
+int smbv_attention_fwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, smbv_bf16* O, smbv_bf16* O_lo, int ldo, float* LSE, int B, int S, int H,
                        int Dh, float scale, int Sq, int q_off, smbv_stream stream) {
   if (!Q || !K || !V || !O || !LSE) { set_error("smbv_attention_fwd: null operand"); return SMBV_ERR_ARG; }
-  return attention_fwd(Q, K, V, ld, O, ldo, LSE, B, S, H, Dh, scale, Sq, q_off, (hipStream_t)stream);
+  return attention_fwd(Q, K, V, ld, O, ldo, LSE, B, S, H, Dh, scale, Sq, q_off, (hipStream_t)stream, O_lo);
 }
 size_t smbv_attention_fp8_workspace_bytes(int B, int S, int H) { return attention_fp8_workspace_bytes(B, S, H); }
 int smbv_attention_fwd_fp8(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, smbv_bf16* O, int ldo, float* LSE, int B, int S, int H, int Dh,
@@ -103,11 +106,12 @@ int smbv_attention_fwd_fp8(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf
   if (!Q || !K || !V || !O || !LSE) { set_error("smbv_attention_fwd_fp8: null operand"); return SMBV_ERR_ARG; }
   return attention_fwd_fp8(Q, K, V, ld, O, ldo, LSE, B, S, H, Dh, scale, Sq, q_off, ws, ws_bytes, (hipStream_t)stream);
 }
-int smbv_attention_bwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* dO, int ldo,
+int smbv_attention_bwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* O_lo, const smbv_bf16* dO, int ldo,
                        const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S, int H, int Dh, float scale,
                        int parts, int Sq, int q_off, smbv_stream stream) {
   if (!Q || !K || !V || !O || !dO || !LSE || !delta || !dQ || !dK || !dV) { set_error("smbv_attention_bwd: null operand"); return SMBV_ERR_ARG; }
-  return attention_bwd(Q, K, V, ld, O, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, H, Dh, scale, parts, Sq, q_off, (hipStream_t)stream);
+  SMBV_CHECK_DEVICE_STATE();
+  return attention_bwd(Q, K, V, ld, O, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, H, Dh, scale, parts, Sq, q_off, (hipStream_t)stream, O_lo);
 }
 
 int smbv_prepare_volume(const void* src, int src_dtype, float* dst, int B, int H0, int W0, int D0, int H, int W, int D, float a_min, float a_max,

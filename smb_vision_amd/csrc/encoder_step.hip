@@ -22,7 +22,7 @@ struct EncWs {
 };
 
 static BlockDims edims(const smbv_encoder_cfg& c) {
-  BlockDims d; d.rows = (size_t)c.B * c.Nsel; d.w = c.d; d.ff = c.ff; d.B = c.B; d.S = c.Nsel; d.H = c.heads; d.Dh = 64; d.eps = c.ln_eps;
+  BlockDims d; d.rows = (size_t)c.B * c.Nsel; d.w = c.d; d.ff = c.ff; d.B = c.B; d.S = c.Nsel; d.H = c.heads; d.Dh = 64; d.eps = c.ln_eps; d.o_resid = c.train ? c.attn_o_resid : 0;
   return d;
 }
 
@@ -194,12 +194,14 @@ size_t smbv_encoder_workspace_bytes(const smbv_encoder_cfg* cfg) {
 
 int smbv_encoder_forward(const smbv_encoder_cfg* cfg, const smbv_encoder_tensors* params, const smbv_encoder_io* io, void* ws, size_t ws_bytes, smbv_stream stream) {
   if (!cfg || !params || !io) { smbv::set_error("smbv_encoder_forward: null argument"); return SMBV_ERR_ARG; }
+  SMBV_CHECK_DEVICE_STATE();
   return smbv::encoder_forward(*cfg, *params, *io, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int smbv_encoder_backward(const smbv_encoder_cfg* cfg, const smbv_encoder_tensors* params, const smbv_encoder_tensors* grads, const smbv_encoder_io* io,
                           const float* d_last_hidden_state, void* ws, size_t ws_bytes, smbv_stream stream) {
   if (!cfg || !params || !grads || !io) { smbv::set_error("smbv_encoder_backward: null argument"); return SMBV_ERR_ARG; }
+  SMBV_CHECK_DEVICE_STATE();
   return smbv::encoder_backward(*cfg, *params, *grads, *io, d_last_hidden_state, ws, ws_bytes, (hipStream_t)stream);
 }
 

@@ -205,8 +205,14 @@ __device__ __forceinline__ void epilogue_rows32(float* ws, const f32x4 (&a0)[4],
           *(u32x4*)(e.out_bf16 + orow * e.ld_ob + n) = p;
           if (e.dot_out) {  // this lane's 8 columns of the row-dot (the bf16-rounded outputs, as a reader of the stored matrix would see them)
             const u32x4 o = *(const u32x4*)(e.dot_with + orow * e.ld_dot + n);
+            if (e.dot_with_lo) {  // (wave-uniform) dot operand = hi + lo: the fp32 value to 16 significant bits
+              const u32x4 ol = *(const u32x4*)(e.dot_with_lo + orow * e.ld_dot + n);
 #pragma unroll
-            for (int q = 0; q < 4; q++) dot += bf_lo(o[q]) * bf_lo(p[q]) + bf_hi(o[q]) * bf_hi(p[q]);
+              for (int q = 0; q < 4; q++) dot += (bf_lo(o[q]) + bf_lo(ol[q])) * bf_lo(p[q]) + (bf_hi(o[q]) + bf_hi(ol[q])) * bf_hi(p[q]);
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; q++) dot += bf_lo(o[q]) * bf_lo(p[q]) + bf_hi(o[q]) * bf_hi(p[q]);
+            }
           }
         }
       }
@@ -366,7 +372,7 @@ int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, in
   const bool ring_shape = K <= 768 && N >= 1024;
   if (gemm_nt_ring_ok(lda, ldb, M, N, K, e) && !(g_variant & 256) && (ring_shape || (g_variant & 131072)))
     return gemm_nt_ring(A, lda, B, ldb, M, N, K, e, (g_variant & 262144) ? 64 : ((g_variant & 512) ? 4 : 3), st, (g_variant >> 20) & 15);
-  if (e.dot_out && (!e.dot_with || (e.dot_dh != 64 && e.dot_dh != 32) || e.dot_rows <= 0 || ((uintptr_t)e.dot_with & 15) || !gemm_nt_rowdot_ok(lda, ldb, M, N, K, e))) {
+  if (e.dot_out && (!e.dot_with || (e.dot_dh != 64 && e.dot_dh != 32) || e.dot_rows <= 0 || (((uintptr_t)e.dot_with | (uintptr_t)e.dot_with_lo) & 15) || !gemm_nt_rowdot_ok(lda, ldb, M, N, K, e))) {
     set_error("gemm_nt: row-dot by-product not available for this product (check gemm_nt_rowdot_ok first)"); return SMBV_ERR_ARG;
   }
   const int tm = cdiv(M, BM), tn = cdiv(N, BN);

@@ -26,11 +26,11 @@ struct MimWs {
 };
 
 static BlockDims enc_dims(const smbv_mim_cfg& c) {
-  BlockDims d; d.rows = (size_t)c.B * c.Nvis; d.w = c.d; d.ff = c.ff; d.B = c.B; d.S = c.Nvis; d.H = c.heads; d.Dh = 64; d.eps = c.ln_eps; d.attn_fp8 = c.attn_fp8;
+  BlockDims d; d.rows = (size_t)c.B * c.Nvis; d.w = c.d; d.ff = c.ff; d.B = c.B; d.S = c.Nvis; d.H = c.heads; d.Dh = 64; d.eps = c.ln_eps; d.attn_fp8 = c.attn_fp8; d.o_resid = c.attn_o_resid;
   return d;
 }
 static BlockDims dec_dims(const smbv_mim_cfg& c) {
-  BlockDims d; d.rows = (size_t)c.B * c.N; d.w = c.dd; d.ff = c.dff; d.B = c.B; d.S = c.N; d.H = c.dheads; d.Dh = 64; d.eps = c.ln_eps; d.attn_fp8 = c.attn_fp8;
+  BlockDims d; d.rows = (size_t)c.B * c.N; d.w = c.dd; d.ff = c.dff; d.B = c.B; d.S = c.N; d.H = c.dheads; d.Dh = 64; d.eps = c.ln_eps; d.attn_fp8 = c.attn_fp8; d.o_resid = c.attn_o_resid;
   return d;
 }
 static BlockPtrs to_block(const smbv_layer_ptrs& p) {
@@ -244,12 +244,14 @@ size_t smbv_mim_workspace_bytes(const smbv_mim_cfg* cfg) {
 
 int smbv_mim_forward(const smbv_mim_cfg* cfg, const smbv_mim_tensors* params, const smbv_mim_io* io, void* ws, size_t ws_bytes, smbv_stream stream) {
   if (!cfg || !params || !io) { smbv::set_error("smbv_mim_forward: null argument"); return SMBV_ERR_ARG; }
+  SMBV_CHECK_DEVICE_STATE();
   return smbv::mim_forward(*cfg, *params, *io, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int smbv_mim_backward(const smbv_mim_cfg* cfg, const smbv_mim_tensors* params, const smbv_mim_tensors* grads, const smbv_mim_io* io, void* ws,
                       size_t ws_bytes, void** events, int n_events, smbv_stream stream) {
   if (!cfg || !params || !grads || !io) { smbv::set_error("smbv_mim_backward: null argument"); return SMBV_ERR_ARG; }
+  SMBV_CHECK_DEVICE_STATE();
   return smbv::mim_backward(*cfg, *params, *grads, *io, ws, ws_bytes, events, n_events, (hipStream_t)stream);
 }
 

@@ -18,6 +18,7 @@ typedef uint16_t bf16_t;  // storage type for bf16 in global memory
 #define SMBV_ERR_ALIGN (-2)
 #define SMBV_ERR_ARG (-3)
 #define SMBV_ERR_WORKSPACE (-4)
+#define SMBV_ERR_STATE (-5)
 
 namespace smbv {
 

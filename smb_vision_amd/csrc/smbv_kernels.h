@@ -30,6 +30,7 @@ struct GemmEpi {
   // With out = dO (the attention output's gradient) and dot_with = O this is flash attention's delta = rowsum(dO * O), which the attention backward
   // otherwise computes in a launch of its own (attn_delta_kernel, 16 launches per MIM step)
   const bf16_t* dot_with = nullptr;
+  const bf16_t* dot_with_lo = nullptr;  // optional second addend of the dot operand (same layout): dot over out * (dot_with + dot_with_lo)
   int ld_dot = 0;
   float* dot_out = nullptr;
   int dot_dh = 64, dot_rows = 0;
@@ -59,10 +60,13 @@ int layernorm_bwd(const bf16_t* dy, const float* x, const float* mean, const flo
 int layernorm_bwd_reduce(const void* ws, int rows, int D, float* dgamma, float* dbeta, hipStream_t st);
 size_t layernorm_bwd_workspace_bytes(int rows, int D);
 
+// O_lo (optional, same layout as O): the forward also stores bf16(O_fp32 - O), the backward forms delta = rowsum(dO * (O + O_lo)) - the rounding of
+// the stored bf16 output otherwise enters delta at 2^-9 relative, which a near-uniform softmax over many keys does not average out
 int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf16_t* O, int ldo, float* LSE, int B, int S, int H, int Dh,
-                  float scale, int Sq, int qoff, hipStream_t st);
+                  float scale, int Sq, int qoff, hipStream_t st, bf16_t* O_lo = nullptr);
 int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
-                  float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st);
+                  float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st,
+                  const bf16_t* O_lo = nullptr);
 
 // fp8 (OCP e4m3, block-scaled MFMA) forward: same contract as attention_fwd plus a caller-owned workspace for the quantised operands
 size_t attention_fp8_workspace_bytes(int B, int S, int H);

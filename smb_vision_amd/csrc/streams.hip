@@ -37,6 +37,46 @@ ForkJoin* fork_join_for_current_device() {
   return &f;
 }
 
+struct StatusWord { unsigned* host = nullptr; unsigned* dev = nullptr; bool tried = false; };
+static StatusWord* status_for_current_device() {
+  static StatusWord table[64];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  StatusWord& w = table[dev];
+  if (!w.tried) {
+    w.tried = true;
+    void* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+      w.host = (unsigned*)h;
+      w.dev = (unsigned*)d;
+      *(volatile unsigned*)w.host = 0u;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  return &w;
+}
+unsigned* device_status_word_dev() {
+  StatusWord* w = status_for_current_device();
+  return w ? w->dev : nullptr;
+}
+int device_status(bool clear) {
+  StatusWord* w = status_for_current_device();
+  if (!w || !w->host) return SMBV_OK;
+  const unsigned code = *(volatile unsigned*)w->host;
+  if (clear) *(volatile unsigned*)w->host = 0u;
+  if (!code) return SMBV_OK;
+  const char* what = code == 0x5001u ? "attention backward: a scheduling word of another launch epoch (two launches shared one slot, or the slot was left dirty)"
+                     : code == 0x5002u ? "attention backward: a block found both tile queues exhausted (a tile was skipped: gradients of that launch are incomplete)"
+                     : code == 0x5003u ? "attention backward: the completion counter carried another launch's epoch"
+                                       : "unknown fault";
+  set_error("device fault 0x%x recorded by an earlier kernel - %s; results since then are not to be trusted (smbv_device_status(1) clears it)", code, what);
+  return SMBV_ERR_STATE;
+}
+
 int stream_edge(ForkJoin* fj, hipEvent_t ev, hipStream_t from, hipStream_t to) {
   std::lock_guard<std::mutex> lk(*(std::mutex*)fj->mu);
   HIPRC(hipEventRecord(ev, from));

@@ -29,7 +29,7 @@ struct VjepaWs {
 
 static BlockDims venc_dims(const smbv_vjepa_cfg& c, const smbv_vjepa_io* io) {
   BlockDims d; d.rows = (size_t)c.B * c.N; d.w = c.d; d.ff = c.ff; d.B = c.B; d.S = c.N; d.H = c.heads; d.Dh = c.d / c.heads; d.eps = c.ln_eps;
-  d.rope_grid = c.W / c.ps; d.pos = io ? io->enc_pos : nullptr; d.rope_table = io ? io->rope_enc : nullptr;
+  d.o_resid = c.attn_o_resid; d.rope_grid = c.W / c.ps; d.pos = io ? io->enc_pos : nullptr; d.rope_table = io ? io->rope_enc : nullptr;
   return d;
 }
 static inline int vmasks(const smbv_vjepa_cfg& c) { return c.n_masks > 1 ? c.n_masks : 1; }
@@ -41,7 +41,7 @@ static inline int vpb(const smbv_vjepa_cfg& c) { return c.B * vmasks(c); }  // p
 static BlockDims vpred_dims(const smbv_vjepa_cfg& c, const smbv_vjepa_io* io) {
   const int Sp = c.Nctx + c.Ntgt;
   BlockDims d; d.rows = (size_t)vpb(c) * Sp; d.w = c.pd; d.ff = c.pff; d.B = vpb(c); d.S = Sp; d.H = c.pheads; d.Dh = c.pd / c.pheads; d.eps = c.ln_eps;
-  d.rope_grid = c.W / c.ps; d.pos = io ? io->pred_pos : nullptr; d.rope_table = io ? io->rope_pred : nullptr;
+  d.o_resid = c.attn_o_resid; d.rope_grid = c.W / c.ps; d.pos = io ? io->pred_pos : nullptr; d.rope_table = io ? io->rope_pred : nullptr;
   return d;
 }
 static BlockPtrs vblock(const smbv_block_ptrs& p) {
@@ -310,11 +310,13 @@ size_t smbv_vjepa_workspace_bytes(const smbv_vjepa_cfg* cfg) {
 }
 int smbv_vjepa_forward(const smbv_vjepa_cfg* cfg, const smbv_vjepa_tensors* params, const smbv_vjepa_io* io, void* ws, size_t ws_bytes, smbv_stream stream) {
   if (!cfg || !params || !io) { smbv::set_error("smbv_vjepa_forward: null argument"); return SMBV_ERR_ARG; }
+  SMBV_CHECK_DEVICE_STATE();
   return smbv::vjepa_forward(*cfg, *params, *io, ws, ws_bytes, (hipStream_t)stream);
 }
 int smbv_vjepa_backward(const smbv_vjepa_cfg* cfg, const smbv_vjepa_tensors* params, const smbv_vjepa_tensors* grads, const smbv_vjepa_io* io, void* ws,
                         size_t ws_bytes, void** events, int n_events, smbv_stream stream) {
   if (!cfg || !params || !grads || !io) { smbv::set_error("smbv_vjepa_backward: null argument"); return SMBV_ERR_ARG; }
+  SMBV_CHECK_DEVICE_STATE();
   return smbv::vjepa_backward(*cfg, *params, *grads, *io, ws, ws_bytes, events, n_events, (hipStream_t)stream);
 }
 

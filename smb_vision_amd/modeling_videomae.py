@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import collections.abc
 import ctypes as C
+import os
 import weakref
 from dataclasses import dataclass
 from typing import Optional
@@ -24,6 +25,17 @@ from transformers.utils import ModelOutput
 
 from . import _lib
 from .masking import split_mask_indices
+
+
+def _residual_wanted(config, default: bool = False) -> bool:
+    """config.smbv_attention_residual: the attention forward also saves the bf16 residual of its fp32 output and the backward forms delta = rowsum(dO * O)
+    from both (smbv_*_cfg.attn_o_resid).  Default: on for V-JEPA, whose encoder attends over all 20,480 near-identical tokens at init scale - the regime in
+    which a bf16 O inside delta costs 10-15 % on some query / key gradients; off for MIM (every gradient tensor within 1e-2 of the fp32 oracle at full size
+    without it, +0.12 ms per step with it: profiles/r04_resid_ab.txt).  The environment variable SMBV_ATTN_RESID = 0 / 1 overrides both (A/B tools)."""
+    env = os.environ.get("SMBV_ATTN_RESID")
+    if env in ("0", "1"):
+        return env == "1"
+    return bool(getattr(config, "smbv_attention_residual", default))
 
 
 @dataclass
@@ -265,6 +277,8 @@ class SmbVideoMAEForPreTraining(PreTrainedModel):
         s.dec_norm_eps = 1e-5
         s.recompute = int(self._use_recompute(s))
         s.attn_fp8 = int(bool(getattr(c, "smbv_attention_fp8", False)))
+        # delta = rowsum(dO * O) from the attention output to 16 significant bits (smbv_mim_cfg.attn_o_resid; one more bf16 activation per block)
+        s.attn_o_resid = int(_residual_wanted(c) and not s.attn_fp8)
         return s
 
     def _use_recompute(self, cfg) -> bool:
@@ -385,7 +399,7 @@ class SmbVideoMAEForPreTraining(PreTrainedModel):
         need = lib.smbv_mim_workspace_bytes(C.byref(cfg))
         if need == 0:
             raise ValueError("smbv_mim_workspace_bytes: " + _lib.last_error())
-        key = (B, n_masked, dev, cfg.recompute, cfg.attn_fp8)
+        key = (B, n_masked, dev, cfg.recompute, cfg.attn_fp8, cfg.attn_o_resid)
         if self._ws is None or self._ws_key != key or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)

@@ -25,6 +25,7 @@ from transformers import PreTrainedModel, VideoMAEConfig
 from transformers.modeling_outputs import BaseModelOutput, ImageClassifierOutput
 
 from . import _lib
+from .modeling_videomae import _residual_wanted
 from .masking import split_mask_indices
 from .modeling_videomae import (_HF5_KEY_MAPPING, _LAYER_SUFFIXES, _Slots, _pair, _register, convert_state_dict_keys,
                                 get_sinusoid_encoding_table)
@@ -125,6 +126,7 @@ class _EncoderRunner:
         cfg.N, cfg.Nsel = self.N, nsel
         cfg.d, cfg.heads, cfg.ff, cfg.layers = c.hidden_size, c.num_attention_heads, c.intermediate_size, c.num_hidden_layers
         cfg.ln_eps, cfg.final_ln, cfg.final_ln_eps, cfg.train = c.layer_norm_eps, int(self.final_ln), c.layer_norm_eps, int(train)
+        cfg.attn_o_resid = int(bool(train and _residual_wanted(c)))
         need = lib.smbv_encoder_workspace_bytes(C.byref(cfg))
         if need == 0:
             raise _lib.SmbvError("smbv_encoder_workspace_bytes: " + _lib.last_error())

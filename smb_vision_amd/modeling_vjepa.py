@@ -28,6 +28,7 @@ from transformers import PreTrainedModel, VJEPA2Config
 from transformers.utils import ModelOutput
 
 from . import _lib
+from .modeling_videomae import _residual_wanted
 from .optim import CHUNK
 
 
@@ -159,7 +160,7 @@ class _VJEPAFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model_ref, pix, idx, with_pred, *params):
         model = model_ref()
-        enc_out, pred_out, st = model._run_forward(pix, idx, with_pred)
+        enc_out, pred_out, st = model._run_forward(pix, idx, with_pred, grad=True)
         ctx.model_ref, ctx.st = model_ref, st
         ctx.set_materialize_grads(False)
         if pred_out is None:
@@ -309,7 +310,7 @@ class SmbVJEPA2Model(PreTrainedModel):
     def _index_plumbing(self, cms, tms, device, needed=None):
         return index_plumbing(cms, tms, self.num_patches, needed)
 
-    def _run_forward(self, pix, idx, with_pred):
+    def _run_forward(self, pix, idx, with_pred, grad=False):
         lib = _lib.load()
         dev = pix.device
         B = pix.shape[0]
@@ -318,10 +319,13 @@ class SmbVJEPA2Model(PreTrainedModel):
         cfg.n_masks = idx["n_masks"]
         cfg.enc_needed = idx["enc_needed"]
         cfg.pred_tgt_first = 0 if os.environ.get("SMBV_VJEPA_PRED_FULL", "0") == "1" else 1   # _index_plumbing puts the target slots first (A/B switch)
+        # delta = rowsum(dO * O) from the attention output to 16 significant bits (smbv_vjepa_cfg.attn_o_resid): only a forward that will be differentiated
+        # pays for the second output (the frozen target encoder never does); config.smbv_attention_residual = False gives the bf16-O delta of flash attention
+        cfg.attn_o_resid = int(bool(grad and _residual_wanted(self.config, True)))
         need = lib.smbv_vjepa_workspace_bytes(C.byref(cfg))
         if need == 0:
             raise ValueError("smbv_vjepa_workspace_bytes: " + _lib.last_error())
-        key = (B, n_ctx, n_tgt, idx["n_masks"], idx["enc_needed"], dev)
+        key = (B, n_ctx, n_tgt, idx["n_masks"], idx["enc_needed"], dev, cfg.attn_o_resid)
         if self._ws is None or self._ws_key != key or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)

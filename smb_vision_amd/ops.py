@@ -111,18 +111,20 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, grp=(0, 0, 0)):
     return dx, dxb, dg, db
 
 
-def attention_fwd(qkv, B, S, H, scale=None, Sq=0, q_off=0, Dh=64):
-    """qkv: bf16 [B*S, 3*H*Dh] (q | k | v column blocks), Dh 64 or 32.  Returns (O bf16 [B*S, H*Dh], LSE fp32 [B,H,S])."""
+def attention_fwd(qkv, B, S, H, scale=None, Sq=0, q_off=0, Dh=64, resid=False):
+    """qkv: bf16 [B*S, 3*H*Dh] (q | k | v column blocks), Dh 64 or 32.  Returns (O bf16 [B*S, H*Dh], LSE fp32 [B,H,S]); with ``resid`` also
+    O_lo = bf16(O_fp32 - O), which attention_bwd takes to form delta from the output to 16 significant bits."""
     _need_gpu(qkv)
     lib = _lib.load()
     w = H * Dh
     scale = scale if scale is not None else Dh ** -0.5
     O = torch.zeros(B * S, w, dtype=torch.bfloat16, device=qkv.device)
+    O_lo = torch.zeros_like(O) if resid else None
     lse = torch.empty(B, H, Sq if Sq > 0 else S, dtype=torch.float32, device=qkv.device)
     base = qkv.data_ptr()
-    check(lib.smbv_attention_fwd(base, base + 2 * w, base + 4 * w, qkv.stride(0), _p(O), w, _p(lse), B, S, H, Dh, scale, Sq, q_off, _stream()),
+    check(lib.smbv_attention_fwd(base, base + 2 * w, base + 4 * w, qkv.stride(0), _p(O), _p(O_lo), w, _p(lse), B, S, H, Dh, scale, Sq, q_off, _stream()),
           "smbv_attention_fwd")
-    return O, lse
+    return (O, lse, O_lo) if resid else (O, lse)
 
 
 def attention_fwd_fp8(qkv, B, S, H, scale=None, Sq=0, q_off=0):
@@ -140,14 +142,14 @@ def attention_fwd_fp8(qkv, B, S, H, scale=None, Sq=0, q_off=0):
     return O, lse
 
 
-def attention_bwd(qkv, O, dO, lse, B, S, H, scale=None, parts=7, out=None, Sq=0, q_off=0, Dh=64):
+def attention_bwd(qkv, O, dO, lse, B, S, H, scale=None, parts=7, out=None, Sq=0, q_off=0, Dh=64, O_lo=None):
     _need_gpu(qkv, O, dO, lse)
     lib = _lib.load()
     w = H * Dh
     scale = scale if scale is not None else Dh ** -0.5
     dqkv, delta = out if out is not None else (torch.zeros_like(qkv), torch.empty(B, H, Sq if Sq > 0 else S, dtype=torch.float32, device=qkv.device))
     base, dbase = qkv.data_ptr(), dqkv.data_ptr()
-    check(lib.smbv_attention_bwd(base, base + 2 * w, base + 4 * w, qkv.stride(0), _p(O), _p(dO), w, _p(lse), _p(delta), dbase, dbase + 2 * w,
+    check(lib.smbv_attention_bwd(base, base + 2 * w, base + 4 * w, qkv.stride(0), _p(O), _p(O_lo), _p(dO), w, _p(lse), _p(delta), dbase, dbase + 2 * w,
                                  dbase + 4 * w, dqkv.stride(0), B, S, H, Dh, scale, parts, Sq, q_off, _stream()), "smbv_attention_bwd")
     return dqkv, delta
 
@@ -216,3 +218,14 @@ def colsum_bf16(X):
     ws = _ws(lib.smbv_colsum_workspace_bytes(M, N), X.device)
     check(lib.smbv_colsum_bf16(_p(X), X.stride(0), M, N, _p(out), _p(ws), ws.numel(), _stream()), "smbv_colsum_bf16")
     return out
+
+
+def device_status(clear=False) -> int:
+    """smbv_device_status: 0, or SMBV_ERR_STATE (-5) once a kernel of an earlier call has recorded a fault on the current device (text: _lib.last_error())."""
+    return int(_lib.load().smbv_device_status(1 if clear else 0))
+
+
+def debug_pair_state(op: int):
+    """smbv_debug_pair_state (test hook): 1 = dirty the attention backward's scheduling slots, 0 = restore them."""
+    check(_lib.load().smbv_debug_pair_state(int(op), _stream()), "smbv_debug_pair_state")
+

@@ -120,7 +120,8 @@ def test_mim_vit_base_512x512x320_step_matches_oracle():
     assert abs(float(o2.loss) - 0.5 * (float(la) + float(lb))) <= 1e-6 * float(la)
 
 
-def test_vjepa_vit_base_512x512x320_matches_oracle():
+@pytest.mark.parametrize("qk_scale", [1.0, 3.0])
+def test_vjepa_vit_base_512x512x320_matches_oracle(qk_scale):
     from transformers import VJEPA2Config
     from smb_vision_amd.masking import VJEPAMaskGenerator
     from smb_vision_amd.modeling_vjepa import SmbVJEPA2Model, make_target_encoder, vjepa_loss
@@ -130,16 +131,16 @@ def test_vjepa_vit_base_512x512x320_matches_oracle():
              pred_num_mask_tokens=10, pred_mlp_ratio=4.0)
     cfg = vo.VJEPAConfig(**{k: v for k, v in c.items()})
     params = vo.init_params(cfg, seed=3, nonzero_small=True)
-    # Encoder query / key projections at 3 x their init scale: logits of standard deviation ~2.7 instead of ~0.3.  At init scale the attention over
-    # 20,480 near-identical tokens (i.i.d. voxels: every patch embedding is the same vector plus a small token-dependent part) is uniform, and the query /
-    # key gradients are what survives an almost complete cancellation (1/sqrt(S) of the terms): the 2^-9 rounding of the stored bf16 attention output
-    # inside delta = rowsum(dO * O) - flash attention's, i.e. the reference's bf16 path's, rounding point too - then shows as 10-15 % of those (tiny)
-    # gradients (measured: encoder.layer.{5,8,10,11} query / key tensors, everything else within 5e-2), which says nothing about the kernels:
-    # tests/test_ops_gpu.py::test_attention_bwd_cancellation_regime_at_the_vjepa_encoder_grid reproduces it at this grid against the same formulas with and
-    # without the rounding points.  A softmax that attends is the regime a parity bound means something in.
+    # qk_scale 1.0: init scale, where run_vjepa.py's training starts.  The attention over 20,480 near-identical tokens (i.i.d. voxels: every patch embedding is the
+    # same vector plus a small token-dependent part) is uniform there and the query / key gradients are what survives an almost complete cancellation
+    # (1/sqrt(S) of the terms).  Round 3 formed delta = rowsum(dO * O) from the stored bf16 O - flash attention's rounding point - whose 2^-9 error enters
+    # those gradients multiplied by the softmax-weighted MEAN key: encoder.layer.{5,8,10,11} query / key tensors sat 10-15 % from the oracle and the test
+    # was run at 3 x the scale instead.  Round 4 removed the rounding point (the forward also stores O_lo = bf16(O_fp32 - O), delta is formed from O + O_lo:
+    # smbv_vjepa_cfg.attn_o_resid, tests/test_ops_gpu.py::test_attention_bwd_cancellation_regime_at_the_vjepa_encoder_grid), so the init-scale case is held
+    # to the same 5e-2 / 0.998 as every other tensor.  qk_scale 3.0 (logits of standard deviation ~2.7 instead of ~0.3): a softmax that attends.
     for k in params:
         if k.startswith("encoder.layer.") and (k.endswith("attention.query.weight") or k.endswith("attention.key.weight")):
-            params[k] = params[k] * 3.0
+            params[k] = params[k] * qk_scale
     torch.manual_seed(7)
     gen = VJEPAMaskGenerator(input_size=(320, 512, 512), patch_size=(16, 16, 16), pred_mask_scale=(0.2, 0.8), aspect_ratio=(0.3, 3.0), num_blocks=3)
     item = gen({"image": None})

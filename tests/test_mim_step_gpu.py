@@ -196,8 +196,10 @@ def test_gradient_checkpointing_recompute_is_bitwise_identical_and_smaller():
     # per-block bf16 weight copies stay, so a 4+3-layer toy shrinks by a quarter (ViT-base at 512x512x320: 5.3 GB -> 1.3 GB)
 
 
-def test_delta_from_the_projection_epilogue_equals_the_standalone_launch():
-    """Round 3: delta = rowsum(dO * O) is a by-product of the out-projection input-gradient product's epilogue (gemm.hip, GemmEpi.dot_*) instead of
+@pytest.mark.parametrize("residual", [False, True])
+def test_delta_from_the_projection_epilogue_equals_the_standalone_launch(residual):
+    """(residual = True: smbv_mim_cfg.attn_o_resid - both delta paths then read O + O_lo; the forward's outputs must not depend on the option and the
+    step must stay within the oracle tolerances.)  Round 3: delta = rowsum(dO * O) is a by-product of the out-projection input-gradient product's epilogue (gemm.hip, GemmEpi.dot_*) instead of
     attn_delta_kernel's own launch (debug bit 4096 restores it).  Same bf16 operands, same products: the two steps' gradients must agree to fp32
     summation order - on a config with a ranged last decoder block, two heads and ragged tiles."""
     import ctypes
@@ -208,7 +210,7 @@ def test_delta_from_the_projection_epilogue_equals_the_standalone_launch():
     c = dict(image_size=96, num_frames=48, patch_size=16, tubelet_size=16, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
              decoder_hidden_size=128, decoder_num_hidden_layers=2, decoder_num_attention_heads=2, decoder_intermediate_size=256)
     torch.manual_seed(0)
-    model = SmbVideoMAEForPreTraining(VideoMAEConfig(num_channels=1, **c)).cuda().train()
+    model = SmbVideoMAEForPreTraining(VideoMAEConfig(num_channels=1, smbv_attention_residual=residual, **c)).cuda().train()
     np.random.seed(1)
     gen = MaskGenerator(96, 48, 16, 16, 0.6)
     mask = torch.stack([gen(), gen()]).cuda()
@@ -231,3 +233,19 @@ def test_delta_from_the_projection_epilogue_equals_the_standalone_launch():
     assert l0 == l1
     for (k, _), a, b in zip(model.named_parameters(), g0, g1):
         assert float((a - b).norm()) <= 2e-3 * float(b.norm()) + 1e-9, k
+    assert bool(model._cfg_struct(2, int(mask[0].sum())).attn_o_resid) == residual
+    if residual:   # same weights and data without the residual: identical forward, gradients equal to bf16-O rounding, and both within the oracle's bound
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        plain = SmbVideoMAEForPreTraining(VideoMAEConfig(num_channels=1, **c))
+        plain.load_state_dict(sd)
+        plain = plain.cuda().train()
+        out = plain(pixel_values=pix, bool_masked_pos=mask)
+        out.loss.backward()
+        torch.cuda.synchronize()
+        assert float(out.loss) == l0
+        ref_loss, _, ref_grads = mim_step(sd, MIMConfig(**c), pix.cpu(), mask.cpu())
+        assert abs(l0 - float(ref_loss)) <= 5e-3 * float(ref_loss)
+        for (k, p), a in zip(plain.named_parameters(), g0):
+            r = ref_grads[k].cuda()
+            assert float((a - r).norm()) <= 6e-2 * float(r.norm()) + 1e-9, k
+            assert float((a - p.grad).norm()) <= 2e-2 * float(r.norm()) + 1e-9, k

@@ -460,7 +460,119 @@ def test_gemm_tn_bias_column_sums_ride_along(ops, M, N1, N2):
     assert torch.equal(xs, xs2) and torch.equal(out, out2)
 
 
-def _attn_bwd_emulated(qkv, O, dO, lse, B, S, H, Dh, Sq, qoff, rounding=True):
+@pytest.mark.parametrize("Dh,Sq,qoff", [(64, 0, 0), (32, 0, 0), (64, 300, 200), (32, 77, 500)])
+def test_attention_residual_output_feeds_delta(ops, Dh, Sq, qoff):
+    """ABI 3000: the forward's optional second output O_lo = bf16(O_fp32 - O) and the backward's delta = rowsum(dO * (O + O_lo)), through both delta
+    paths the library has (attn_delta_kernel here; the out-projection epilogue is covered by the step tests).  O and LSE do not depend on the option."""
+    B, S, H = 2, 777, 3
+    w = H * Dh
+    qkv = rnd(B * S, 3 * w, seed=11).bfloat16()
+    O, lse = ops.attention_fwd(qkv, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh)
+    O2, lse2, O_lo = ops.attention_fwd(qkv, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh, resid=True)
+    assert torch.equal(O, O2) and torch.equal(lse, lse2)
+    n = Sq if Sq > 0 else S
+    rows = slice(qoff, qoff + n)
+    q, k, v, s = _attn_ref(qkv, B, S, H, Dh)
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, S, w)[:, rows]
+    hi, lo = O.float().view(B, S, w)[:, rows], O_lo.float().view(B, S, w)[:, rows]
+    assert float(lo.abs().max()) > 0 and bool((lo.abs() <= hi.abs() * 2.0 ** -8 + 1e-30).all())          # half a bf16 ulp of O at most
+    assert rms_err(hi + lo, ref) < 0.95 * rms_err(hi, ref)     # it carries the fp32 output's low bits (what is left is the bf16 rounding of P, not of O)
+    outside = torch.ones(S, dtype=torch.bool); outside[rows] = False
+    assert float(O_lo.float().view(B, S, w)[:, outside].abs().max() if outside.any() else 0.0) == 0.0   # rows outside the query range are not written
+    dO = torch.zeros(B, S, w, device="cuda")
+    dO[:, rows] = rnd(B, n, w, seed=12)
+    dO = dO.bfloat16().view(B * S, w)
+    _, delta = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh, O_lo=O_lo)
+    _, delta0 = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh)
+    dv = dO.float().view(B, S, H, Dh)[:, rows]
+    want = (dv * (hi + lo).view(B, n, H, Dh)).sum(-1).transpose(1, 2)          # [B, H, n]
+    want0 = (dv * hi.view(B, n, H, Dh)).sum(-1).transpose(1, 2)
+    assert rel_err(delta, want) < 1e-5 and rel_err(delta0, want0) < 1e-5
+    assert not torch.equal(delta, delta0)
+
+
+def _bwd_case(ops, B, S, H, Dh, Sq, qoff, seed):
+    w = H * Dh
+    qkv = rnd(B * S, 3 * w, seed=seed).bfloat16()
+    O, lse = ops.attention_fwd(qkv, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh)
+    n = Sq if Sq > 0 else S
+    dO = torch.zeros(B, S, w, device="cuda")
+    dO[:, qoff:qoff + n] = rnd(B, n, w, seed=seed + 1)
+    return qkv, O, lse, dO.bfloat16().view(B * S, w)
+
+
+@pytest.mark.parametrize("B,S,H,Dh,Sq,qoff", [(1, 1000, 3, 64, 0, 0), (2, 777, 2, 64, 300, 200), (1, 2176, 2, 32, 181, 1056), (2, 640, 3, 32, 0, 0)])
+def test_attention_backward_launch_forms_are_bitwise_equivalent(ops, B, S, H, Dh, Sq, qoff):
+    """the shipped ONE-launch pair with mixed block roles, the two-launch path (debug bit 524288: also what a ninth stream of a device gets) and
+    the query-owner block on the 32x32x16 MFMA (bit 2) run the same arithmetic in the same order per tile - which block computes which tile, and in how
+    many launches, must not change a bit.  (16x16x32 vs 32x32x16 sum a tile's products in a different order: equal to rounding, not bitwise.)"""
+    from smb_vision_amd import _lib
+    lib = _lib.load()
+    qkv, O, lse, dO = _bwd_case(ops, B, S, H, Dh, Sq, qoff, seed=21)
+    try:
+        base, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh)
+        lib.smbv_debug_set_variant(524288)
+        two, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh)
+        lib.smbv_debug_set_variant(2)
+        q32, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh)
+        lib.smbv_debug_set_variant(2 | 524288)
+        q32_two, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh)
+    finally:
+        lib.smbv_debug_set_variant(0)
+    assert torch.equal(base, two)
+    assert torch.equal(q32, q32_two)
+    w = H * Dh
+    assert torch.equal(base[:, w:], q32[:, w:])                      # dK, dV: the key-owner block is the same in all four
+    assert rms_err(base[:, :w], q32[:, :w]) < 2e-3                   # dQ: two MFMA shapes, same products
+
+
+def test_attention_backward_on_two_streams_of_one_device(ops):
+    """The pair launch's scheduling slot belongs to the stream (attention_bwd.hip pair_slot_for): two streams of one device that run attention backwards at
+    the same time (the exported smbv_attention_bwd under user streams, two models) use different slots and get the single-stream results bit for bit."""
+    qkv, O, lse, dO = _bwd_case(ops, 1, 4096, 4, 64, 0, 0, seed=31)
+    want, _ = ops.attention_bwd(qkv, O, dO, lse, 1, 4096, 4)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(3):
+        for st in (s1, s2):
+            with torch.cuda.stream(st):
+                outs.append(ops.attention_bwd(qkv, O, dO, lse, 1, 4096, 4)[0])
+    torch.cuda.synchronize()
+    assert ops.device_status() == 0
+    for o in outs:
+        assert torch.equal(o, want)
+
+
+def test_attention_backward_scheduling_fault_is_an_error_not_wrong_gradients(ops):
+    """the pair launch keeps its tile queues in device memory the library owns.  A slot that is not in the state its launch expects used
+    to give silently missing gradient tiles.  Now every word carries its launch's epoch and a block that finds both queues exhausted reports it: the
+    device's sticky status turns SMBV_ERR_STATE and every later step / attention call is refused until it is cleared."""
+    from smb_vision_amd import _lib
+    qkv, O, lse, dO = _bwd_case(ops, 1, 1024, 2, 64, 0, 0, seed=41)
+    want, _ = ops.attention_bwd(qkv, O, dO, lse, 1, 1024, 2)
+    torch.cuda.synchronize()
+    assert ops.device_status() == 0
+    try:
+        ops.debug_pair_state(1)                                       # every slot's key-owner queue starts 3 tiles in: 3 tiles of the next launch are skipped
+        bad, _ = ops.attention_bwd(qkv, O, dO, lse, 1, 1024, 2)
+        torch.cuda.synchronize()
+        assert not torch.equal(bad, want)                             # (the old behaviour's symptom: this result would have been returned as good)
+        assert ops.device_status() == -5
+        assert "0x5002" in _lib.last_error() or "0x5001" in _lib.last_error()
+        with pytest.raises(_lib.SmbvError, match="device fault"):
+            ops.attention_bwd(qkv, O, dO, lse, 1, 1024, 2)
+    finally:
+        ops.debug_pair_state(0)
+        torch.cuda.synchronize()
+        assert ops.device_status(clear=True) in (0, -5)
+    assert ops.device_status() == 0
+    again, _ = ops.attention_bwd(qkv, O, dO, lse, 1, 1024, 2)
+    torch.cuda.synchronize()
+    assert torch.equal(again, want) and ops.device_status() == 0
+
+
+def _attn_bwd_emulated(qkv, O, dO, lse, B, S, H, Dh, Sq, qoff, rounding=True, O_lo=None):
     """fp32 torch restatement of attn_dkv2_kernel / attn_dq2_kernel WITH their bf16 rounding points (attention_bwd.hip): the key-owner kernel scores
     bf16(K * c) against Q, the query-owner kernel bf16(Q * c) against K (c = scale * log2 e), P = exp2(s' - lse * log2 e) is rounded to bf16 for the
     dV product only, dS = P_fp32 * (dP - delta) is rounded to bf16 for the dK / dQ products, outputs are rounded to bf16.  rounding=False: the same
@@ -470,6 +582,8 @@ def _attn_bwd_emulated(qkv, O, dO, lse, B, S, H, Dh, Sq, qoff, rounding=True):
     bf = (lambda t: t.bfloat16().float()) if rounding else (lambda t: t)
     f = qkv.float().view(B, S, 3, H, Dh)
     dOv, Ov = dO.float().view(B, S, H, Dh), O.float().view(B, S, H, Dh)
+    if O_lo is not None:   # delta from O + O_lo (the forward's bf16 residual of its fp32 output)
+        Ov = Ov + O_lo.float().view(B, S, H, Dh)
     out = [torch.zeros(B, S, H, Dh, device=qkv.device) for _ in range(3)]
     for b in range(B):
         for h in range(H):
@@ -551,3 +665,16 @@ def test_attention_bwd_cancellation_regime_at_the_vjepa_encoder_grid(ops):
     for n, vs_exact, vs_emu, emu_exact in rows:
         assert vs_emu < 5e-3, (n, vs_emu)                       # the kernels ARE the formulas with those rounding points
         assert vs_exact < 1.5 * emu_exact + 5e-3, (n, vs_exact, emu_exact)   # ... and nothing beyond them separates the kernels from exact arithmetic
+    # Round 4: the rounding point removed.  The forward also stores O_lo = bf16(O_fp32 - O) and delta is formed from O + O_lo (16 significant bits):
+    # the same launches then sit within the ordinary bf16-operand distance of exact arithmetic in this regime too.
+    O2, lse2, O_lo = ops.attention_fwd(qkv, B, S, H, Dh=Dh, resid=True)
+    assert torch.equal(O2, O) and torch.equal(lse2, lse)
+    assert float(O_lo.float().abs().max()) <= 2.0 ** -8 * float(O.float().abs().max())     # a residual, half an ulp of O at most
+    dqkv2, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Dh=Dh, O_lo=O_lo)
+    emu2 = _attn_bwd_emulated(qkv, O, dO, lse, B, S, H, Dh, S, 0, O_lo=O_lo)
+    rows2 = [(n, l2(dqkv2[:, i * w:(i + 1) * w], exact[i]), l2(dqkv2[:, i * w:(i + 1) * w], emu2[i])) for i, n in enumerate("qkv")]
+    print("  with the residual output (kernel vs exact | kernel vs same rounding points): " + "; ".join(f"d{n} {a:.2e} | {b:.2e}" for n, a, b in rows2))
+    for n, vs_exact, vs_emu in rows2:
+        assert vs_emu < 5e-3, (n, vs_emu)
+        assert vs_exact < 5e-2, (n, vs_exact)                   # dQ (and dK) vs exact arithmetic within the step's gradient bound
+    assert torch.equal(dqkv2[:, 2 * w:], dqkv[:, 2 * w:])       # dV does not read delta
