@@ -57,7 +57,7 @@ int smbv_version(void);
 int smbv_last_error(char* buf, size_t len);               /* copies the thread's last error text; returns its length */
 /* Tuning / A-B hook used by tools/ and by the kernel-equivalence tests, NOT by the product path: selects alternative kernels for the same
  * arithmetic (process-wide, not thread-safe; 0 = the shipped selection).  Bits: 2 attention backward query-owner blocks on the 32x32x16 MFMA (shipped: 16x16x32); 32 register-staged GEMMs; 256 first-generation 128x128 NT
- * GEMM everywhere / 131072 second-generation ring NT GEMM everywhere (default: by shape); 512 four-slot ring; 262144 ring with 64-deep K slices; 1024 no mixed-tile NT launches (all tiles 128 x 128); 2048 attention forward with the guarded sweep only (no optimistic first sweep); 4096 delta = rowsum(dO * O) by its own launch instead of the
+ * GEMM everywhere; 4 the blocks' weight-gradient products inline on the side stream (one launch each + finishing launches) instead of deferred and grouped; 131072 second-generation ring NT GEMM everywhere (default: by shape); 512 four-slot ring; 262144 ring with 64-deep K slices; 1024 no mixed-tile NT launches (all tiles 128 x 128); 2048 attention forward with the guarded sweep only (no optimistic first sweep); 4096 delta = rowsum(dO * O) by its own launch instead of the
  * out-projection input-gradient epilogue; 8192 attention dQ and dK/dV on
  * one stream (with 524288); 524288 attention backward as two launches (dK/dV, dQ) instead of the one mixed-role launch; 16384 weight- and input-gradient GEMMs on one stream; 32768 / 65536 TN tile selection; bits 20-23 GEMM ablation (timing only); 1<<24 attention forward on the plain (tile, head, batch) grid instead of the
  * XCD-aware block order; 1<<25 attention backward kernels on the XCD-aware block order; bits 26-28 start-up stagger
@@ -100,6 +100,18 @@ size_t smbv_gemm_tn_workspace_bytes(int M, int N1, int N2);
  * (dW = dY^T A, db = sum over tokens of dY) in one launch; ws as above */
 int smbv_gemm_tn_bias(const smbv_bf16* X, int ldx, const smbv_bf16* Y, int ldy, int M, int N1, int N2, float* out, float* xsum, void* ws,
                       size_t ws_bytes, smbv_stream stream);
+
+/* Several such weight (+ bias) gradients as ONE launch (ABI 3000): every output tile is reduced over its product's whole token range - no slabs, no
+ * workspace, no finishing launch; xsum segments as in smbv_gemm_tn_bias: column sum n of X goes to sum_dst[n / seg][n % seg] (NULL segment: dropped;
+ * seg = 0: no sums).  1..8 jobs; every N1, N2 a multiple of 128 (256 x 256 tiles when all are multiples of 256).  The block backward issues a
+ * transformer block's four products this way, deferred to the end of the block and run beside the next block's backward. */
+typedef struct smbv_tn_job {
+  const smbv_bf16* X; const smbv_bf16* Y; float* out;
+  float* sum_dst[3];
+  int ldx, ldy, M, N1, N2, seg;
+  int reserved;                   /* set by the library */
+} smbv_tn_job;
+int smbv_gemm_tn_grouped(const smbv_tn_job* jobs /* host */, int njobs, smbv_stream stream);
 
 /* nn.LayerNorm over the last dim (spec :402-403, :412, :423, :676/:721); y is the bf16 GEMM operand.
  * Input rows are read at (row / grp_in) * grp_out + row % grp_in + row_off when grp_in > 0. */

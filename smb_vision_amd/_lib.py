@@ -27,6 +27,11 @@ class GemmEpi(C.Structure):
     ]
 
 
+class TnJob(C.Structure):
+    _fields_ = [("X", c_f), ("Y", c_f), ("out", c_f), ("sum_dst", c_f * 3), ("ldx", C.c_int), ("ldy", C.c_int), ("M", C.c_int), ("N1", C.c_int),
+                ("N2", C.c_int), ("seg", C.c_int), ("reserved", C.c_int)]
+
+
 class _Cfg(C.Structure):
     """cfg structs open with ``struct_bytes`` (ABI 2000): filled in here so that a binding / library layout mismatch is refused by the library."""
 
@@ -111,6 +116,7 @@ _SIGS = {
     "smbv_gemm_nt": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GemmEpi), c_f]),
     "smbv_gemm_tn": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f, C.c_size_t, c_f]),
     "smbv_gemm_tn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "smbv_gemm_tn_grouped": (C.c_int, [C.POINTER(TnJob), C.c_int, c_f]),
     "smbv_gemm_tn_bias": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f, c_f, C.c_size_t, c_f]),
     "smbv_layernorm_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_float, C.c_long, C.c_long, C.c_long, c_f]),
     "smbv_layernorm_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, c_f, C.c_size_t, c_f]),

@@ -41,12 +41,11 @@ struct LayerWs {
   float *mean1, *rstd1, *mean2, *rstd2, *lse, *x_mid;
 };
 
-struct BwdScratch {  // sized for the widest block of the model
-  bf16_t *d_act, *d_ln, *d_o, *d_qkv, *gath0, *gath1;
+struct BwdScratch {  // sized for the widest block of the model (d_act, d_qkv and the blocks' LayerNorm partials live in the WgradPipe's rings)
+  bf16_t *d_ln, *d_o, *gath0, *gath1;
   float *delta, *gpad, *gpad_b;  // gpad / gpad_b: head-padded weight / bias gradients before un-padding (null when no block is padded)
-  void* scratch;        // LN-bwd partials / colsum partials / gemm_tn slabs of the products that stay on the caller's stream
+  void* scratch;        // LN-bwd partials / colsum partials / gemm_tn slabs of the products the STEP issues on the caller's stream (head, embeddings)
   size_t scratch_bytes;
-  void* ln2_part;       // LN2-bwd partials: their reduction runs on the side stream, so they outlive the LN1 backward that reuses `scratch`
   void* f8ws = nullptr; // quantised operands of the fp8 attention forward (null unless a block asks for it)
   size_t f8ws_bytes = 0;
   void* wscratch;       // gemm_tn slabs + column-sum partials of the weight-gradient products that run on the side stream
@@ -56,6 +55,7 @@ struct BwdScratch {  // sized for the widest block of the model
 struct ForkJoin {  // streams.hip
   hipStream_t side = nullptr, wside = nullptr;
   hipEvent_t fork = nullptr, join = nullptr, wfork = nullptr, wjoin = nullptr;
+  hipEvent_t wdone[4] = {nullptr, nullptr, nullptr, nullptr};  // WgradPipe: "deferred launch #k has finished" (slot k & 3)
   bool ready = false;
   void* mu = nullptr;  // std::mutex*: a record + wait pair on one of the events above is made under it (two host threads on one device)
 };
@@ -120,12 +120,43 @@ struct BwdNeeds {  // running maxima over the blocks of a model (elements, excep
 void bwd_scratch_requirements(const BlockDims& d, BwdNeeds& n);
 void carve_bwd_scratch(Carver& cv, BwdScratch& sc, const BwdNeeds& n);  // everything of BwdScratch except gath0 / gath1
 
+// Deferred weight gradients (round 4).  A block's four weight-gradient products (+ bias sums, + the LayerNorm parameter reductions) do not feed the
+// rest of the backward: with a pipe, layer_bwd only collects them and, once the block's input gradient is done, issues them as ONE grouped launch
+// (gemm_tn_grouped: every tile over all tokens, no slabs) on the library's side stream, where it runs beside the NEXT block's backward.  What that
+// launch reads must outlive the block: the bf16 residual gradients (in / mid) come from a ring of six buffers (block k: in = gb[2k], mid = gb[2k+1],
+// out = gb[2k+2], indices mod 6), d_act / d_qkv / the LayerNorm partials from rings of two; block k starts only after launch k-2 has finished
+// (event ring), which frees exactly the ring entries it overwrites.  Blocks the grouped launch cannot take (head-padded widths, widths that are not
+// multiples of 128, non-adjacent q/k/v gradients, a ranged block at B > 1, recompute - whose shared activation set the next block's forward
+// overwrites) run their products inline on the same side stream, as before; they use the same rings.
+struct WgradPipe {
+  ForkJoin* fj = nullptr;        // null until begin(); stays null when the side stream is unavailable or switched off (variant bit 16384): all inline
+  bool allow_defer = true;       // false: every block inline (recompute)
+  int k = 0;                     // blocks issued through this pipe
+  int waited = -1;               // the caller's stream has waited for deferred launches <= waited
+  bool deferred[4] = {false, false, false, false};  // launch (k & 3) was deferred and its wdone event recorded
+  bf16_t* gb[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bf16_t* d_act[2] = {nullptr, nullptr};
+  bf16_t* d_qkv[2] = {nullptr, nullptr};
+  void* ln1_part[2] = {nullptr, nullptr};
+  void* ln2_part[2] = {nullptr, nullptr};
+  size_t part_bytes = 0;
+  bf16_t* cur() const { return gb[(2 * k) % 6]; }   // the bf16 gradient w.r.t. the next block's OUTPUT is written here by whoever produces it
+  int begin();                                      // looks up the device's side stream / events
+  int wait_for(int launch, hipStream_t st);         // st waits for deferred launch #launch (no-op if it was inline or already waited for)
+  int drain(hipStream_t st);                        // st waits for everything deferred so far (end of the backward)
+  // DP: a gradient group produced INLINE on `st` is final here - recorded through the side stream when earlier groups are still pending there, so that
+  // the events complete in their array order (dp.py waits for a bucket's LAST event only)
+  int mark_inline(hipEvent_t ev, hipStream_t st);
+};
+void carve_wgrad_pipe(Carver& cv, WgradPipe& pipe, size_t gb_elems, const struct BwdNeeds& n);
+
 // Sq > 0: only tokens qoff..qoff+Sq-1 of every sequence are needed downstream (see mim_step.hip); 0 = all tokens.
 int layer_fwd(const BlockPtrs& p, LayerWs& L, const BlockDims& d, BwdScratch& sc, const float* x_in, float* x_out, bf16_t* x_out_bf16, int Sq, int qoff,
               hipStream_t st);
-// g/gb: gradient w.r.t. the block output (fp32 + bf16 copy) on entry, w.r.t. the block input on exit; g2/gb2: ping-pong partners.
-int layer_bwd(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDims& d, BwdScratch& sc, const float* x_in, float* g, bf16_t* gb, float* g2,
-              bf16_t* gb2, int Sq, int qoff, hipStream_t st);
+// Backward of one block through a WgradPipe (above): the bf16 gradient w.r.t. the block's output comes in at pipe.cur(), leaves at pipe.cur() (after the call: k advanced); g: fp32 gradient in / out, g2: the
+// mid-block partner.  dp_event (may be null): recorded when this block's parameter gradients are final - on the side stream for a deferred block.
+int layer_bwd(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDims& d, BwdScratch& sc, const float* x_in, float* g, float* g2, WgradPipe& pipe,
+              int Sq, int qoff, hipEvent_t dp_event, hipStream_t st);
 
 #define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
 #define HIPRC(x) do { hipError_t _e = (x); if (_e != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(_e)); return (int)_e; } } while (0)

@@ -93,16 +93,13 @@ void bwd_scratch_requirements(const BlockDims& d, BwdNeeds& n) {
 }
 
 void carve_bwd_scratch(Carver& cv, BwdScratch& sc, const BwdNeeds& n) {
-  sc.d_act = cv.take<bf16_t>(n.act);
   sc.d_ln = cv.take<bf16_t>(n.we);
   sc.d_o = cv.take<bf16_t>(n.we);
-  sc.d_qkv = cv.take<bf16_t>(n.qkv);
   sc.delta = cv.take<float>(n.delta);
   sc.gpad = n.gpad ? cv.take<float>(n.gpad) : nullptr;
   sc.gpad_b = n.gpad_b ? cv.take<float>(n.gpad_b) : nullptr;
   sc.scratch = cv.take<char>(n.scratch);
   sc.scratch_bytes = n.scratch;
-  sc.ln2_part = cv.take<char>(n.scratch);
   sc.wscratch = cv.take<char>(n.wscratch);
   sc.wscratch_bytes = n.wscratch;
   sc.f8ws = n.f8 ? cv.take<char>(n.f8) : nullptr;
@@ -160,48 +157,108 @@ int layer_fwd(const BlockPtrs& p, LayerWs& L, const BlockDims& d, BwdScratch& sc
   return SMBV_OK;
 }
 
-int layer_bwd(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDims& d, BwdScratch& sc, const float* x_in, float* g, bf16_t* gb, float* g2,
-              bf16_t* gb2, int Sq, int qoff, hipStream_t st) {
+void carve_wgrad_pipe(Carver& cv, WgradPipe& pipe, size_t gb_elems, const BwdNeeds& n) {
+  for (int i = 0; i < 6; i++) pipe.gb[i] = cv.take<bf16_t>(gb_elems);
+  for (int i = 0; i < 2; i++) {
+    pipe.d_act[i] = cv.take<bf16_t>(n.act);
+    pipe.d_qkv[i] = cv.take<bf16_t>(n.qkv);
+    pipe.ln1_part[i] = cv.take<char>(n.scratch);
+    pipe.ln2_part[i] = cv.take<char>(n.scratch);
+  }
+  pipe.part_bytes = n.scratch;
+}
+
+int WgradPipe::begin() {
+  fj = (g_variant & 16384) ? nullptr : fork_join_for_current_device();
+  k = 0;
+  waited = -1;
+  for (bool& x : deferred) x = false;
+  return SMBV_OK;
+}
+int WgradPipe::wait_for(int launch, hipStream_t st) {
+  if (!fj || launch < 0 || launch <= waited || launch < k - 4 || !deferred[launch & 3]) return SMBV_OK;
+  HIPRC(hipStreamWaitEvent(st, fj->wdone[launch & 3], 0));
+  waited = launch;
+  return SMBV_OK;
+}
+int WgradPipe::drain(hipStream_t st) {
+  if (k > 0) RC(wait_for(k - 1, st));   // the side stream is in order: its last launch finishing means all of them have
+  return SMBV_OK;
+}
+int WgradPipe::mark_inline(hipEvent_t ev, hipStream_t st) {
+  if (!ev) return SMBV_OK;
+  const bool pending = fj && k > 0 && deferred[(k - 1) & 3] && waited < k - 1;
+  if (!pending) { HIPRC(hipEventRecord(ev, st)); return SMBV_OK; }
+  RC(stream_edge(fj, fj->wfork, st, fj->wside));
+  HIPRC(hipEventRecord(ev, fj->wside));
+  return SMBV_OK;
+}
+
+namespace {
+struct BwdBufs {
+  float *g, *g2;                       // fp32 residual gradient: in / out, mid
+  bf16_t *gb_in, *gb_mid, *gb_out;     // its bf16 copies (gb_out may alias gb_in when nothing deferred reads gb_in)
+  bf16_t *d_act, *d_qkv;
+  void *ln1_part, *ln2_part;
+  size_t part_bytes;
+};
+
+// defer != null: the weight-gradient products are collected and issued as one grouped launch on defer's side stream at the end (see block.h)
+int layer_bwd_core(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDims& d, BwdScratch& sc, const float* x_in, const BwdBufs& bf, int Sq, int qoff,
+                   hipStream_t st, WgradPipe* defer, int launch_no, hipEvent_t dp_event, WgradPipe* pipe) {
   const int w = d.w, ff = d.ff, wa = d.wa(), B = d.B, S = d.S, H = d.H;
   const int M = (int)d.rows;
   const bool ranged = Sq > 0;
   const int Mq = ranged ? B * Sq : M;
+  float *g = bf.g, *g2 = bf.g2;
+  bf16_t *gb = bf.gb_in, *gb2 = bf.gb_mid;
   SideStream side;
+  TnJob jobs[4];
+  int nj = 0;
+  // one weight (+ bias: the column sums ride along, gemm.hip) gradient product: collected for the grouped launch, or issued on the side stream beside
+  // the input-gradient product that shares its dY
+  auto wgrad = [&](const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int Mr, int N1, int N2, float* out, const TnColsum& cs) -> int {
+    if (defer) {
+      TnJob& j = jobs[nj++];
+      j.X = X; j.Y = Y; j.out = out; j.ldx = ldx; j.ldy = ldy; j.M = Mr; j.N1 = N1; j.N2 = N2; j.seg = cs.seg; j.tile0 = 0;
+      for (int i = 0; i < 3; i++) j.sum_dst[i] = cs.dst[i];
+      return SMBV_OK;
+    }
+    return gemm_tn(X, ldx, Y, ldy, Mr, N1, N2, out, sc.wscratch, sc.wscratch_bytes, side.st, &cs);
+  };
   // ---- MLP (on the ranged rows only when Sq > 0: ln2 / pre / act are compact then) ----
   const bf16_t* gbc = gb;
   if (ranged) {
     gbc = gb + (size_t)qoff * w;  // contiguous for B == 1
     if (B > 1) { RC(gather_rows_bf16(gb, sc.gath0, Mq, w, Sq, S, qoff, st)); gbc = sc.gath0; }
   }
-  // weight (+ bias: the column sums ride along, gemm.hip) gradients go to the side stream; the input-gradient product they share dY with
-  // stays on `st` - the two run side by side and fill each other's tails
-  RC(side.begin(st));
+  if (!defer) RC(side.begin(st));
   {
     TnColsum cs; cs.dst[0] = gr.fc2_b; cs.seg = w;
-    RC(gemm_tn(gbc, w, L.act, ff, Mq, w, ff, gr.fc2_w, sc.wscratch, sc.wscratch_bytes, side.st, &cs));
+    RC(wgrad(gbc, w, L.act, ff, Mq, w, ff, gr.fc2_w, cs));
   }
   {
-    GemmEpi e; e.dgelu_pre = L.pre; e.ld_pre = ff; e.out_bf16 = sc.d_act; e.ld_ob = ff;
+    GemmEpi e; e.dgelu_pre = L.pre; e.ld_pre = ff; e.out_bf16 = bf.d_act; e.ld_ob = ff;
     RC(gemm_nt(gbc, w, L.fc2_t, w, Mq, ff, w, e, st));
   }
-  RC(side.begin(st));  // d_act is ready
+  if (!defer) RC(side.begin(st));  // d_act is ready
   {
     TnColsum cs; cs.dst[0] = gr.fc1_b; cs.seg = ff;
-    RC(gemm_tn(sc.d_act, ff, L.ln2, w, Mq, ff, w, gr.fc1_w, sc.wscratch, sc.wscratch_bytes, side.st, &cs));
+    RC(wgrad(bf.d_act, ff, L.ln2, w, Mq, ff, w, gr.fc1_w, cs));
   }
   {
     GemmEpi e; e.out_bf16 = sc.d_ln; e.ld_ob = w;
-    RC(gemm_nt(sc.d_act, ff, L.fc1_t, ff, Mq, w, ff, e, st));
+    RC(gemm_nt(bf.d_act, ff, L.fc1_t, ff, Mq, w, ff, e, st));
   }
   // ---- LN2 (+ residual): g2 = g + LNbwd(d_ln); every non-ranged row of g2 is zero ----
   if (ranged) {
     HIPRC(hipMemsetAsync(g2, 0, (size_t)M * w * sizeof(float), st));
     HIPRC(hipMemsetAsync(gb2, 0, (size_t)M * w * sizeof(bf16_t), st));
-    RC(layernorm_bwd(sc.d_ln, L.x_mid, L.mean2, L.rstd2, p.ln2_w, g, g2, gb2, gr.ln2_w, gr.ln2_b, Mq, w, Sq, S, qoff, sc.ln2_part, sc.scratch_bytes, st, false));
+    RC(layernorm_bwd(sc.d_ln, L.x_mid, L.mean2, L.rstd2, p.ln2_w, g, g2, gb2, gr.ln2_w, gr.ln2_b, Mq, w, Sq, S, qoff, bf.ln2_part, bf.part_bytes, st, false));
   } else {
-    RC(layernorm_bwd(sc.d_ln, L.x_mid, L.mean2, L.rstd2, p.ln2_w, g, g2, gb2, gr.ln2_w, gr.ln2_b, M, w, 0, 0, 0, sc.ln2_part, sc.scratch_bytes, st, false));
+    RC(layernorm_bwd(sc.d_ln, L.x_mid, L.mean2, L.rstd2, p.ln2_w, g, g2, gb2, gr.ln2_w, gr.ln2_b, M, w, 0, 0, 0, bf.ln2_part, bf.part_bytes, st, false));
   }
-  // (the partials' reduction into the LN2 weight / bias gradients follows on the side stream, after the next fork)
+  // (the partials' reduction into the LN2 weight / bias gradients follows on the side stream)
   // ---- attention output projection ----
   const bf16_t* g2c = gb2;
   const bf16_t* aoc = L.attn_o;
@@ -215,12 +272,14 @@ int layer_bwd(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDi
       g2c = sc.gath0; aoc = sc.gath1;
     }
   }
-  RC(side.begin(st));  // gb2 (and, ranged, its gathered copy) is ready
-  RC(layernorm_bwd_reduce(sc.ln2_part, Mq, w, gr.ln2_w, gr.ln2_b, side.st));   // (-0.04 ms per MIM step against running it on `st` behind the LN2 backward)
+  if (!defer) {
+    RC(side.begin(st));  // gb2 (and, ranged, its gathered copy) is ready
+    RC(layernorm_bwd_reduce(bf.ln2_part, Mq, w, gr.ln2_w, gr.ln2_b, side.st));   // (-0.04 ms per MIM step against running it on `st` behind the LN2 backward)
+  }
   {
     TnColsum cs; cs.dst[0] = gr.proj_b; cs.seg = w;
     if (!d.padded()) {
-      RC(gemm_tn(g2c, w, aoc, wa, Mq, w, wa, gr.proj_w, sc.wscratch, sc.wscratch_bytes, side.st, &cs));
+      RC(wgrad(g2c, w, aoc, wa, Mq, w, wa, gr.proj_w, cs));
     } else {
       RC(gemm_tn(g2c, w, aoc, wa, Mq, w, wa, sc.gpad, sc.wscratch, sc.wscratch_bytes, side.st, &cs));   // [w, H*64] -> [w, H*Dh]
       RC(map_copy_f32(gr.proj_w, sc.gpad, (size_t)w * w, d.Dh, 64, side.st));
@@ -231,40 +290,42 @@ int layer_bwd(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDi
     GemmEpi e; e.out_bf16 = sc.d_o; e.ld_ob = wa;
     if (ranged) { e.out_bf16 = sc.d_o + (size_t)qoff * wa; e.grp_in = Sq; e.grp_out = S; }
     // delta = rowsum(dO * O) per (token, head) comes out of this product's epilogue (gemm.hip) instead of a launch of its own in attention_bwd
-    e.dot_with = L.attn_o + (ranged ? (size_t)qoff * wa : 0); e.ld_dot = wa;
-    if (L.attn_o_lo) e.dot_with_lo = L.attn_o_lo + (ranged ? (size_t)qoff * wa : 0); e.dot_dh = d.slot(); e.dot_rows = ranged ? Sq : S; e.dot_out = sc.delta;
+    e.dot_with = L.attn_o + (ranged ? (size_t)qoff * wa : 0); e.ld_dot = wa; e.dot_dh = d.slot(); e.dot_rows = ranged ? Sq : S; e.dot_out = sc.delta;
+    if (L.attn_o_lo) e.dot_with_lo = L.attn_o_lo + (ranged ? (size_t)qoff * wa : 0);
     if (!(g_variant & 4096) && gemm_nt_rowdot_ok(w, w, Mq, wa, w, e)) delta_fused = true;
     else { e.dot_with = nullptr; e.dot_with_lo = nullptr; e.dot_out = nullptr; }
     RC(gemm_nt(g2c, w, L.proj_t, w, Mq, wa, w, e, st));
   }
   // ---- attention (dQ exists only for the ranged queries; dK/dV for every token) ----
-  if (ranged) HIPRC(hipMemsetAsync(sc.d_qkv, 0, (size_t)M * 3 * wa * sizeof(bf16_t), st));
-  RC(attention_bwd(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, sc.d_o, wa, L.lse, sc.delta, sc.d_qkv, sc.d_qkv + wa, sc.d_qkv + 2 * wa, 3 * wa, B,
+  if (ranged) HIPRC(hipMemsetAsync(bf.d_qkv, 0, (size_t)M * 3 * wa * sizeof(bf16_t), st));
+  RC(attention_bwd(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, sc.d_o, wa, L.lse, sc.delta, bf.d_qkv, bf.d_qkv + wa, bf.d_qkv + 2 * wa, 3 * wa, B,
                    S, H, d.slot(), d.scale(), delta_fused ? 6 : 7, Sq, qoff, st, L.attn_o_lo));
-  if (d.rope_grid > 0) RC(rope3d(sc.d_qkv, 3 * wa, wa, M, S, H, d.slot(), d.Dh, d.rope_grid, d.pos, d.rope_table, 1, st));
+  if (d.rope_grid > 0) RC(rope3d(bf.d_qkv, 3 * wa, wa, M, S, H, d.slot(), d.Dh, d.rope_grid, d.pos, d.rope_table, 1, st));
   // ---- QKV ----
-  // (the three products forked above had the whole attention backward to finish: joining them here costs nothing and makes every later
-  // write on `st` - LN1 backward rewrites g / gb - safe whatever the scheduling of the two queues)
-  RC(side.end(st));
-  RC(side.begin(st));  // d_qkv is ready
+  if (!defer) {
+    // (the three products forked above had the whole attention backward to finish: joining them here costs nothing and makes every later
+    // write on `st` - LN1 backward may rewrite gb - safe whatever the scheduling of the two queues)
+    RC(side.end(st));
+    RC(side.begin(st));  // d_qkv is ready
+  }
   const size_t ww = (size_t)w * w;
   const bool contiguous = gr.k_w == gr.q_w + ww && gr.v_w == gr.k_w + ww;
   if (!d.padded()) {
     if (contiguous) {
       TnColsum cs; cs.dst[0] = gr.q_b; cs.dst[1] = gr.k_b; cs.dst[2] = gr.v_b; cs.seg = w;   // VideoMAE has no key bias: null drops that segment
-      RC(gemm_tn(sc.d_qkv, 3 * w, L.ln1, w, M, 3 * w, w, gr.q_w, sc.wscratch, sc.wscratch_bytes, side.st, &cs));
+      RC(wgrad(bf.d_qkv, 3 * w, L.ln1, w, M, 3 * w, w, gr.q_w, cs));
     } else {
       float* wdst[3] = {gr.q_w, gr.k_w, gr.v_w};
       float* bdst[3] = {gr.q_b, gr.k_b, gr.v_b};
       for (int sec = 0; sec < 3; sec++) {
         TnColsum cs; cs.dst[0] = bdst[sec]; cs.seg = w;
-        RC(gemm_tn(sc.d_qkv + sec * w, 3 * w, L.ln1, w, M, w, w, wdst[sec], sc.wscratch, sc.wscratch_bytes, side.st, bdst[sec] ? &cs : nullptr));
+        RC(gemm_tn(bf.d_qkv + sec * w, 3 * w, L.ln1, w, M, w, w, wdst[sec], sc.wscratch, sc.wscratch_bytes, side.st, bdst[sec] ? &cs : nullptr));
       }
     }
   } else {
     // head-padded layout (head_dim < 64): sums and products land in the padded scratch, then the real columns are compacted
     TnColsum cs; cs.dst[0] = sc.gpad_b; cs.seg = 3 * wa;
-    RC(gemm_tn(sc.d_qkv, 3 * wa, L.ln1, w, M, 3 * wa, w, sc.gpad, sc.wscratch, sc.wscratch_bytes, side.st, &cs));   // [3*H*64, w]
+    RC(gemm_tn(bf.d_qkv, 3 * wa, L.ln1, w, M, 3 * wa, w, sc.gpad, sc.wscratch, sc.wscratch_bytes, side.st, &cs));   // [3*H*64, w]
     float* dst[3] = {gr.q_w, gr.k_w, gr.v_w};
     float* bdst[3] = {gr.q_b, gr.k_b, gr.v_b};
     for (int sec = 0; sec < 3; sec++) {
@@ -274,13 +335,51 @@ int layer_bwd(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDi
   }
   {
     GemmEpi e; e.out_bf16 = sc.d_ln; e.ld_ob = w;
-    RC(gemm_nt(sc.d_qkv, 3 * wa, L.wqkv_t, 3 * wa, M, w, 3 * wa, e, st));
+    RC(gemm_nt(bf.d_qkv, 3 * wa, L.wqkv_t, 3 * wa, M, w, 3 * wa, e, st));
   }
   // ---- LN1 (+ residual) over all rows: g = g2 + LNbwd(d_ln) ----
-  RC(layernorm_bwd(sc.d_ln, x_in, L.mean1, L.rstd1, p.ln1_w, g2, g, gb, gr.ln1_w, gr.ln1_b, M, w, 0, 0, 0, sc.scratch, sc.scratch_bytes, st));
-  // join: this block's parameter gradients are final on `st` (the caller records the data-parallel event next), and every buffer the side
-  // products read (gb, d_act, gb2, d_qkv, the saved activations) may be overwritten by the next block
+  RC(layernorm_bwd(sc.d_ln, x_in, L.mean1, L.rstd1, p.ln1_w, g2, g, bf.gb_out, gr.ln1_w, gr.ln1_b, M, w, 0, 0, 0, bf.ln1_part, bf.part_bytes, st, !defer));
+  if (defer) {
+    // the block's input gradient is done: everything its parameter gradients need exists.  One edge into the side stream, the two LayerNorm parameter
+    // reductions, the grouped launch; "launch_no finished" is what lets block launch_no + 2 overwrite the ring entries this one read
+    ForkJoin* fj = defer->fj;
+    RC(stream_edge(fj, fj->wfork, st, fj->wside));
+    RC(layernorm_bwd_reduce(bf.ln2_part, Mq, w, gr.ln2_w, gr.ln2_b, fj->wside));
+    RC(layernorm_bwd_reduce(bf.ln1_part, M, w, gr.ln1_w, gr.ln1_b, fj->wside));
+    RC(gemm_tn_grouped(jobs, nj, fj->wside));
+    HIPRC(hipEventRecord(fj->wdone[launch_no & 3], fj->wside));
+    if (dp_event) HIPRC(hipEventRecord(dp_event, fj->wside));
+    return SMBV_OK;
+  }
+  // join: this block's parameter gradients are final on `st`, and every buffer the side products read (gb, d_act, gb2, d_qkv, the saved
+  // activations) may be overwritten by the next block
   RC(side.end(st));
+  if (dp_event) { if (pipe) RC(pipe->mark_inline(dp_event, st)); else HIPRC(hipEventRecord(dp_event, st)); }
+  return SMBV_OK;
+}
+}  // namespace
+
+int layer_bwd(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDims& d, BwdScratch& sc, const float* x_in, float* g, float* g2, WgradPipe& pipe,
+              int Sq, int qoff, hipEvent_t dp_event, hipStream_t st) {
+  const int k = pipe.k;
+  RC(pipe.wait_for(k - 2, st));   // the ring entries this block overwrites were read by deferred launch k - 2
+  BwdBufs bf;
+  bf.g = g; bf.g2 = g2;
+  bf.gb_in = pipe.gb[(2 * k) % 6]; bf.gb_mid = pipe.gb[(2 * k + 1) % 6]; bf.gb_out = pipe.gb[(2 * k + 2) % 6];
+  bf.d_act = pipe.d_act[k & 1]; bf.d_qkv = pipe.d_qkv[k & 1];
+  bf.ln1_part = pipe.ln1_part[k & 1]; bf.ln2_part = pipe.ln2_part[k & 1]; bf.part_bytes = pipe.part_bytes;
+  const int w = d.w, ff = d.ff;
+  const size_t ww = (size_t)w * w;
+  const bool ranged = Sq > 0;
+  const size_t Mmax = d.rows;
+  const bool shapes_ok = w % 128 == 0 && ff % 128 == 0 && Mmax * (size_t)std::max(ff, 3 * w) * 2 < (1ull << 31);
+  const bool defer = pipe.fj && pipe.allow_defer && !(g_variant & 4) && !d.padded() && shapes_ok && gr.k_w == gr.q_w + ww && gr.v_w == gr.k_w + ww &&
+                     !(ranged && d.B > 1) && !(g_variant & 32);
+  const int rc = layer_bwd_core(p, gr, L, d, sc, x_in, bf, Sq, qoff, st, defer ? &pipe : nullptr, k, dp_event, &pipe);
+  if (rc) return rc;
+  pipe.deferred[k & 3] = defer;
+  if (!defer) pipe.waited = k;   // an inline block joins the (in-order) side stream: everything before it has finished as well
+  pipe.k = k + 1;
   return SMBV_OK;
 }
 

@@ -82,6 +82,14 @@ int smbv_gemm_tn_bias(const smbv_bf16* X, int ldx, const smbv_bf16* Y, int ldy, 
   return gemm_tn(X, ldx, Y, ldy, M, N1, N2, out, ws, ws_bytes, (hipStream_t)stream, &cs);
 }
 
+static_assert(sizeof(smbv_tn_job) == sizeof(smbv::TnJob), "smbv_tn_job mirrors TnJob");
+int smbv_gemm_tn_grouped(const smbv_tn_job* jobs, int njobs, smbv_stream stream) {
+  if (!jobs || njobs <= 0 || njobs > TN_GROUP_MAX) { set_error("smbv_gemm_tn_grouped: 1..%d jobs", TN_GROUP_MAX); return SMBV_ERR_ARG; }
+  TnJob j[TN_GROUP_MAX];
+  memcpy(j, jobs, sizeof(TnJob) * njobs);
+  return gemm_tn_grouped(j, njobs, (hipStream_t)stream);
+}
+
 int smbv_layernorm_fwd(const float* x, const float* gamma, const float* beta, smbv_bf16* y, float* mean, float* rstd, int rows, int D, float eps,
                        long grp_in, long grp_out, long row_off, smbv_stream stream) {
   if (!x || !gamma || !beta || !y || !mean || !rstd) { set_error("smbv_layernorm_fwd: null operand"); return SMBV_ERR_ARG; }

@@ -15,9 +15,10 @@ struct EncWs {
   bf16_t *a_patch, *lnf_bf16;
   float *x0, *x1, *meanf, *rstdf;
   float* x[SMBV_MAX_LAYERS + 1];  // train: residual stream per layer
-  float *g0, *g1;                 // train: gradient ping-pong (fp32 + bf16 copies)
-  bf16_t *gb0, *gb1;
+  float *g0, *g1;                 // train: fp32 gradient ping-pong
+  bf16_t* d_out_bf16;
   BwdScratch sc;
+  WgradPipe pipe;                 // train: bf16 gradient ring + the rings of the deferred weight-gradient launches (block.h)
   size_t total;
 };
 
@@ -53,14 +54,14 @@ static void carve(const smbv_encoder_cfg& c, void* base, EncWs& w) {
     w.rstdf = cv.take<float>(R);
     w.g0 = cv.take<float>(R * c.d);
     w.g1 = cv.take<float>(R * c.d);
-    w.gb0 = cv.take<bf16_t>(R * c.d);
-    w.gb1 = cv.take<bf16_t>(R * c.d);
+    w.d_out_bf16 = cv.take<bf16_t>(R * c.d);
     BwdNeeds nd;
     bwd_scratch_requirements(de, nd);
     nd.scratch = std::max(nd.scratch, gemm_tn_workspace_bytes((int)R, c.d, K));
     nd.scratch = std::max(nd.scratch, colsum_workspace_bytes((int)R, std::max(c.d, K)));
     w.sc = BwdScratch{};
     carve_bwd_scratch(cv, w.sc, nd);
+    carve_wgrad_pipe(cv, w.pipe, R * c.d, nd);
     w.sc.gath0 = cv.take<bf16_t>(16);
     w.sc.gath1 = cv.take<bf16_t>(16);
     w.total = (cv.off + 255) & ~(size_t)255;
@@ -159,24 +160,23 @@ static int encoder_backward(const smbv_encoder_cfg& c, const smbv_encoder_tensor
     b.proj_w = q.proj_w; b.proj_b = q.proj_b; b.ln2_w = q.ln2_w; b.ln2_b = q.ln2_b; b.fc1_w = q.fc1_w; b.fc1_b = q.fc1_b; b.fc2_w = q.fc2_w; b.fc2_b = q.fc2_b;
     return b;
   };
+  WgradPipe& pipe = W.pipe;
+  RC(pipe.begin());
   if (c.final_ln) {
-    RC(cast_f32_bf16(d_out, W.gb1, R * c.d, st));
-    RC(layernorm_bwd(W.gb1, W.x[c.layers], W.meanf, W.rstdf, p.lnf_w, nullptr, W.g0, W.gb0, gr.lnf_w, gr.lnf_b, (int)R, c.d, 0, 0, 0, W.sc.scratch,
+    RC(cast_f32_bf16(d_out, W.d_out_bf16, R * c.d, st));
+    RC(layernorm_bwd(W.d_out_bf16, W.x[c.layers], W.meanf, W.rstdf, p.lnf_w, nullptr, W.g0, pipe.cur(), gr.lnf_w, gr.lnf_b, (int)R, c.d, 0, 0, 0, W.sc.scratch,
                      W.sc.scratch_bytes, st));
   } else {
     HIPRC(hipMemcpyAsync(W.g0, d_out, R * c.d * sizeof(float), hipMemcpyDeviceToDevice, st));
-    RC(cast_f32_bf16(d_out, W.gb0, R * c.d, st));
+    RC(cast_f32_bf16(d_out, pipe.cur(), R * c.d, st));
   }
-  float *g = W.g0, *g2 = W.g1;
-  bf16_t *gb = W.gb0, *gb2 = W.gb1;
-  for (int l = c.layers - 1; l >= 0; l--) {
-    RC(layer_bwd(blk(p, l), blk(gr, l), W.L[l], de, W.sc, W.x[l], g, gb, g2, gb2, 0, 0, st));
-    // layer_bwd leaves the gradient w.r.t. its input in (g, gb) again (see block.h)
-  }
+  for (int l = c.layers - 1; l >= 0; l--)
+    RC(layer_bwd(blk(p, l), blk(gr, l), W.L[l], de, W.sc, W.x[l], W.g0, W.g1, pipe, 0, 0, nullptr, st));   // fp32 gradient in / out: W.g0; bf16: the pipe's ring
   {
     TnColsum cs; cs.dst[0] = gr.pe_b; cs.seg = c.d;
-    RC(gemm_tn(gb, c.d, W.a_patch, K, (int)R, c.d, K, gr.pe_w, W.sc.scratch, W.sc.scratch_bytes, st, &cs));
+    RC(gemm_tn(pipe.cur(), c.d, W.a_patch, K, (int)R, c.d, K, gr.pe_w, W.sc.scratch, W.sc.scratch_bytes, st, &cs));
   }
+  RC(pipe.drain(st));
   (void)io;
   return SMBV_OK;
 }

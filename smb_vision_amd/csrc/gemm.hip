@@ -525,17 +525,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
 // (Round 3: the same kernel with 32-token slices through a four-slot ring - three slices in flight behind a counted vmcnt, one barrier per slice -
 // measured 0..12 % SLOWER at every shape of the step, profiles/r03_gemm_tn_ring_ab.txt: with two blocks per CU the other block's MFMAs already cover
 // a step's copy, and the ring doubles the barriers.  Not kept.)
-__global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y, int ldy,
-                                                             int M, int N1, int N2, float* __restrict__ out, int ldo, int tiles_1,
-                                                             int mchunk, size_t slab_stride, float* __restrict__ xsum) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * BK * 128 * 2];
+// One 128 x 128 output tile over the token range [mbeg, mend): out tile rows a0.., columns b0.. (leading dimension ldo); xsum != null: this block also
+// forms the column sums of X over its token range for its 128 columns (do_sum), delivered by tn_store_sum.
+struct TnSum { float *d0, *d1, *d2; int seg; };  // where column sum n of X goes: d{n / seg}[n % seg] (null = dropped); seg = 0: xsum_flat[n]
+__device__ __forceinline__ void tn_store_sum(const TnSum& ts, float* xsum_flat, int n, float v) {
+  if (ts.seg > 0) {
+    const int sg = n / ts.seg;
+    float* d = sg == 0 ? ts.d0 : (sg == 1 ? ts.d1 : ts.d2);   // (selects, not an indexed array: hipcc would promote that to LDS)
+    if (d) d[n - sg * ts.seg] = v;
+  } else {
+    xsum_flat[n] = v;
+  }
+}
+__device__ __forceinline__ void tn128_tile(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y, int ldy, int N1, int N2, float* __restrict__ o,
+                                           int ldo, int a0, int b0, int mbeg, int mend, bool do_sum, float* __restrict__ xsum_flat, const TnSum& ts,
+                                           unsigned char* smem) {
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int w1 = w >> 1, w2 = w & 1;
-  const int tile_1 = blockIdx.x % tiles_1, tile_2 = blockIdx.x / tiles_1;
-  const int a0 = tile_1 * 128, b0 = tile_2 * 128;
-  const int z = blockIdx.y;
-  const int mbeg = z * mchunk, mend = min(M, mbeg + mchunk);
   const int nk = (mend - mbeg + BK - 1) / BK;
 
   // (the copies are issued from asm statements - smbv_common.h - because hipcc puts a vmcnt(0) in front of the first ds_read_b64_tr_b16
@@ -573,7 +580,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
   for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool do_sum = xsum != nullptr && tile_2 == 0;
   f32x4 accb[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 
   if (nk > 0) stage(0, 0);
@@ -619,9 +625,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
 
   if (do_sum && l < 16) {
 #pragma unroll
-    for (int k = 0; k < 2; k++) xsum[(size_t)z * N1 + a0 + w1 * 64 + (2 * w2 + k) * 16 + l] = accb[k][0];
+    for (int k = 0; k < 2; k++) tn_store_sum(ts, xsum_flat, a0 + w1 * 64 + (2 * w2 + k) * 16 + l, accb[k][0]);
   }
-  float* o = out + (size_t)z * slab_stride;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int n1 = a0 + w1 * 64 + i * 16 + (l & 15);
@@ -633,24 +638,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
   }
 }
 
+__global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y, int ldy,
+                                                             int M, int N1, int N2, float* __restrict__ out, int ldo, int tiles_1,
+                                                             int mchunk, size_t slab_stride, float* __restrict__ xsum) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * BK * 128 * 2];
+  const int tile_1 = blockIdx.x % tiles_1, tile_2 = blockIdx.x / tiles_1;
+  const int z = blockIdx.y;
+  const int mbeg = z * mchunk, mend = min(M, mbeg + mchunk);
+  const TnSum none = {nullptr, nullptr, nullptr, 0};
+  tn128_tile(X, ldx, Y, ldy, N1, N2, out + (size_t)z * slab_stride, ldo, tile_1 * 128, tile_2 * 128, mbeg, mend, xsum != nullptr && tile_2 == 0,
+             xsum ? xsum + (size_t)z * N1 : nullptr, none, smem);
+}
+
 // TN, 256 x 256 output tile, for wide outputs (gemm_tn_use_256).  A 128 x 128 block is bound by its own copy latency: its LDS (64 KiB,
 // 2 blocks per CU) lets 2 x 32 KiB fly per CU.  A 256 x 256 tile needs half the operand bytes per MAC and, alone on its CU, keeps three
 // 32-token slices (96 KiB) in flight: 8 waves (2 x 4), each 128 x 64 of the output, slices [32 tokens][512 B] of X and of Y
 // through a ring of four LDS slots filled by LDS-DMA hidden from hipcc (smbv_common.h), one counted vmcnt + one barrier per slice, fragments
 // by ds_read_b64_tr_b16 (same 32-byte-column XOR swizzle as the 128 kernel; 512-B rows keep its bank pattern).  The token range is split
 // into slabs so that tiles x slabs fills one round of 256 blocks; slabs are summed by reduce_tn_kernel in slab order.
-__global__ __launch_bounds__(512, 1) void gemm_tn_256_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y, int ldy,
-                                                              int M, int N1, int N2, float* __restrict__ out, int ldo, int tiles_1,
-                                                              int mchunk, size_t slab_stride, float* __restrict__ xsum) {
+__device__ __forceinline__ void tn256_tile(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y, int ldy, int N1, int N2, float* __restrict__ o,
+                                           int ldo, int a0, int b0, int mbeg, int mend, bool do_sum, float* __restrict__ xsum_flat, const TnSum& ts,
+                                           unsigned char* smem) {
   constexpr int SLICE = 2 * 32 * 512;  // X image | Y image
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * SLICE];
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int w1 = w >> 2, w2 = w & 3;  // 2 (n1) x 4 (n2)
-  const int tile_1 = blockIdx.x % tiles_1, tile_2 = blockIdx.x / tiles_1;
-  const int a0 = tile_1 * 256, b0 = tile_2 * 256;
-  const int z = blockIdx.y;
-  const int mbeg = z * mchunk, mend = min(M, mbeg + mchunk);
   const int nks = (mend - mbeg + 31) / 32;
 
   const i32x4 rx = dma_rsrc(X, mend > 0 ? (unsigned)(((size_t)(mend - 1) * ldx + N1) * 2) : 0u);
@@ -681,7 +693,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_256_kernel(const bf16_t* __res
   for (int i = 0; i < 8; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool do_sum = xsum != nullptr && tile_2 == 0;  // wave (w1, w2) sums column tiles 2 w2, 2 w2 + 1 of its 128-wide n1 slice
+  // (do_sum) wave (w1, w2) sums column tiles 2 w2, 2 w2 + 1 of its 128-wide n1 slice
   f32x4 accb[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 
   const int g = l >> 4, q = (l >> 2) & 3, p = l & 3;
@@ -762,9 +774,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_256_kernel(const bf16_t* __res
 
   if (do_sum && l < 16) {
 #pragma unroll
-    for (int k = 0; k < 2; k++) xsum[(size_t)z * N1 + a0 + w1 * 128 + (2 * w2 + k) * 16 + l] = accb[k][0];
+    for (int k = 0; k < 2; k++) tn_store_sum(ts, xsum_flat, a0 + w1 * 128 + (2 * w2 + k) * 16 + l, accb[k][0]);
   }
-  float* o = out + (size_t)z * slab_stride;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     const int n1 = a0 + w1 * 128 + i * 16 + (l & 15);
@@ -774,6 +785,38 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_256_kernel(const bf16_t* __res
       *(f32x4*)(o + (size_t)n1 * ldo + n2) = acc[i][j];
     }
   }
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_tn_256_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y, int ldy,
+                                                              int M, int N1, int N2, float* __restrict__ out, int ldo, int tiles_1,
+                                                              int mchunk, size_t slab_stride, float* __restrict__ xsum) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 2 * 32 * 512];
+  const int tile_1 = blockIdx.x % tiles_1, tile_2 = blockIdx.x / tiles_1;
+  const int z = blockIdx.y;
+  const int mbeg = z * mchunk, mend = min(M, mbeg + mchunk);
+  const TnSum none = {nullptr, nullptr, nullptr, 0};
+  tn256_tile(X, ldx, Y, ldy, N1, N2, out + (size_t)z * slab_stride, ldo, tile_1 * 256, tile_2 * 256, mbeg, mend, xsum != nullptr && tile_2 == 0,
+             xsum ? xsum + (size_t)z * N1 : nullptr, none, smem);
+}
+
+// ---- grouped launch: several weight-gradient products (one transformer block's four) as ONE grid, every tile reduced over its product's WHOLE token
+// range: no slabs, no finishing launch, the bias gradients (column sums of X) written straight to their tensors.  block.hip defers a block's products
+// to the end of its backward and runs this launch on the side stream beside the NEXT block's backward.
+template <int TILE>
+__global__ __launch_bounds__(TILE == 256 ? 512 : 256, TILE == 256 ? 1 : 2) void gemm_tn_grouped_kernel(TnGroup g) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[TILE == 256 ? 4 * 2 * 32 * 512 : 2 * 2 * BK * 128 * 2];
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < TN_GROUP_MAX; i++)
+    if (i < g.njobs && (int)blockIdx.x >= g.job[i].tile0) j = i;
+  const TnJob& J = g.job[j];
+  const int tile = (int)blockIdx.x - J.tile0;
+  const int tiles_1 = J.N1 / TILE;
+  const int tile_1 = tile % tiles_1, tile_2 = tile / tiles_1;
+  const TnSum ts = {J.sum_dst[0], J.sum_dst[1], J.sum_dst[2], J.seg};
+  const bool do_sum = J.seg > 0 && tile_2 == 0;
+  if constexpr (TILE == 256) tn256_tile(J.X, J.ldx, J.Y, J.ldy, J.N1, J.N2, J.out, J.N2, tile_1 * 256, tile_2 * 256, 0, J.M, do_sum, nullptr, ts, smem);
+  else tn128_tile(J.X, J.ldx, J.Y, J.ldy, J.N1, J.N2, J.out, J.N2, tile_1 * 128, tile_2 * 128, 0, J.M, do_sum, nullptr, ts, smem);
 }
 
 // slabs for the 256 x 256 kernel: tiles x slabs as close to one full round of 256 blocks as the token count allows (>= 256 tokens a slab)
@@ -847,6 +890,39 @@ size_t gemm_tn_workspace_bytes(int M, int N1, int N2) {
   const int s = std::max(gemm_tn_splits(M, N1, N2), (N1 % 256 == 0 && N2 % 256 == 0) ? gemm_tn_splits_256(M, N1, N2) : 1);
   // slabs (when the token range is split) + the per-slab column sums of X (bias gradient), 256-B aligned behind them
   return (s > 1 ? (((size_t)s * N1 * N2 * sizeof(float) + 255) & ~(size_t)255) : 0) + (size_t)s * N1 * sizeof(float);
+}
+
+static int tn_group_tile(const TnJob* jobs, int njobs) {  // 256, 128, or 0 = not groupable
+  if (njobs <= 0 || njobs > TN_GROUP_MAX || (g_variant & 32)) return 0;
+  bool all256 = !(g_variant & 32768), all128 = true;
+  for (int i = 0; i < njobs; i++) {
+    const TnJob& j = jobs[i];
+    if (j.M <= 0 || j.N1 <= 0 || j.N2 <= 0 || (j.ldx & 7) || (j.ldy & 7) || !j.X || !j.Y || !j.out) return 0;
+    if ((((uintptr_t)j.X | (uintptr_t)j.Y | (uintptr_t)j.out) & 15)) return 0;
+    if ((size_t)j.M * j.ldx * 2 >= (1ull << 31) || (size_t)j.M * j.ldy * 2 >= (1ull << 31)) return 0;   // 32-bit LDS-DMA offsets
+    if (j.seg < 0 || (j.seg > 0 && (j.N1 % j.seg || j.N1 / j.seg > 3))) return 0;
+    all256 = all256 && j.N1 % 256 == 0 && j.N2 % 256 == 0;
+    all128 = all128 && j.N1 % 128 == 0 && j.N2 % 128 == 0;
+  }
+  return all256 ? 256 : (all128 ? 128 : 0);
+}
+bool gemm_tn_grouped_ok(const TnJob* jobs, int njobs) { return tn_group_tile(jobs, njobs) != 0; }
+
+int gemm_tn_grouped(const TnJob* jobs, int njobs, hipStream_t st) {
+  const int tile = tn_group_tile(jobs, njobs);
+  if (!tile) { set_error("gemm_tn_grouped: products not groupable (1..%d jobs, widths multiples of 128, 16-byte aligned operands)", TN_GROUP_MAX); return SMBV_ERR_SHAPE; }
+  TnGroup g;
+  g.njobs = njobs;
+  int tiles = 0;
+  for (int i = 0; i < njobs; i++) {
+    g.job[i] = jobs[i];
+    g.job[i].tile0 = tiles;
+    tiles += (jobs[i].N1 / tile) * (jobs[i].N2 / tile);
+  }
+  for (int i = njobs; i < TN_GROUP_MAX; i++) { g.job[i] = g.job[0]; g.job[i].tile0 = 0x7fffffff; }
+  if (tile == 256) hipLaunchKernelGGL(gemm_tn_grouped_kernel<256>, dim3(tiles), dim3(512), 0, st, g);
+  else hipLaunchKernelGGL(gemm_tn_grouped_kernel<128>, dim3(tiles), dim3(256), 0, st, g);
+  return check_launch("gemm_tn_grouped");
 }
 
 int gemm_tn(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int M, int N1, int N2, float* out, void* ws, size_t ws_bytes, hipStream_t st,

@@ -20,8 +20,9 @@ struct MimWs {
   float *meanf, *rstdf, *bmean, *brinv, *row_partial;
   // backward scratch
   float *g0, *g1;
-  bf16_t *gb0, *gb1, *dlogits, *d_vis;
-  BwdScratch sc;        // block-backward scratch (d_act, d_ln, d_o, d_qkv, gathers, delta, reduction scratch)
+  bf16_t *dlogits, *d_vis;
+  BwdScratch sc;        // block-backward scratch (d_ln, d_o, gathers, delta, reduction scratch)
+  WgradPipe pipe;       // bf16 residual-gradient ring, d_act / d_qkv / LayerNorm-partial rings of the deferred weight-gradient launches (block.h)
   size_t total;
 };
 
@@ -78,8 +79,6 @@ static void carve(const smbv_mim_cfg& c, void* base, MimWs& w) {
   const size_t gw = std::max(R * c.d, Rd * c.dd);
   w.g0 = cv.take<float>(gw);
   w.g1 = cv.take<float>(gw);
-  w.gb0 = cv.take<bf16_t>(gw);
-  w.gb1 = cv.take<bf16_t>(gw);
   w.dlogits = cv.take<bf16_t>(Rm * K);
   w.d_vis = cv.take<bf16_t>(R * c.dd);
   BwdNeeds nd;
@@ -90,6 +89,7 @@ static void carve(const smbv_mim_cfg& c, void* base, MimWs& w) {
   nd.scratch = std::max(nd.scratch, layernorm_bwd_workspace_bytes((int)Rm, c.dd));
   nd.scratch = std::max(nd.scratch, colsum_workspace_bytes((int)std::max(R, Rd), std::max(std::max(c.d, c.dd), K)));
   carve_bwd_scratch(cv, w.sc, nd);
+  carve_wgrad_pipe(cv, w.pipe, gw, nd);
   w.sc.gath0 = cv.take<bf16_t>(Rm * c.dd);
   w.sc.gath1 = cv.take<bf16_t>(Rm * c.dd);
   w.total = (cv.off + 255) & ~(size_t)255;
@@ -175,11 +175,11 @@ static int mim_backward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const 
   const int need_events = 3 + c.layers + c.dlayers;
   if (events && n_events < need_events) { set_error("mim_backward: need %d events, got %d", need_events, n_events); return SMBV_ERR_ARG; }
   int ev = 0;
-  auto mark = [&]() -> int {
-    if (events) HIPRC(hipEventRecord((hipEvent_t)events[ev], st));
-    ev++;
-    return SMBV_OK;
-  };
+  WgradPipe& pipe = W.pipe;
+  RC(pipe.begin());
+  pipe.allow_defer = !c.recompute;   // the blocks of a stack share ONE activation set under recompute: the next block's forward would overwrite what a deferred launch reads
+  auto next_event = [&]() -> hipEvent_t { return events ? (hipEvent_t)events[ev++] : (ev++, (hipEvent_t) nullptr); };
+  auto mark = [&]() -> int { return pipe.mark_inline(next_event(), st); };   // a group whose gradients were produced on `st`
   const int K = c.ts * c.ps * c.ps;
   const size_t R = (size_t)c.B * c.Nvis, Rd = (size_t)c.B * c.N, Rm = (size_t)c.B * c.Nmask;
   const BlockDims de = enc_dims(c), dd = dec_dims(c);
@@ -196,38 +196,38 @@ static int mim_backward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const 
   }
   // decoder.norm backward scatters into the last N_mask rows of every volume; visible rows get no gradient from the head
   HIPRC(hipMemsetAsync(W.g0, 0, Rd * c.dd * sizeof(float), st));
-  HIPRC(hipMemsetAsync(W.gb0, 0, Rd * c.dd * sizeof(bf16_t), st));
-  RC(layernorm_bwd(W.sc.d_ln, W.xd[c.dlayers], W.meanf, W.rstdf, p.dnorm_w, nullptr, W.g0, W.gb0, gr.dnorm_w, gr.dnorm_b, (int)Rm, c.dd, c.Nmask, c.N,
+  HIPRC(hipMemsetAsync(pipe.cur(), 0, Rd * c.dd * sizeof(bf16_t), st));
+  RC(layernorm_bwd(W.sc.d_ln, W.xd[c.dlayers], W.meanf, W.rstdf, p.dnorm_w, nullptr, W.g0, pipe.cur(), gr.dnorm_w, gr.dnorm_b, (int)Rm, c.dd, c.Nmask, c.N,
                    c.Nvis, W.sc.scratch, W.sc.scratch_bytes, st));
   RC(mark());
   for (int l = c.dlayers - 1; l >= 0; l--) {
     const bool last = l == c.dlayers - 1;  // its forward only produced the masked tokens (see mim_forward)
     // recompute: rebuild this block's activations from its saved input (the last block's are still in the shared set)
     if (c.recompute && !last) RC(layer_fwd(to_block(p.dec[l]), W.dec[l], dd, W.sc, W.xd[l], W.xd[l + 1], nullptr, 0, 0, st));
-    RC(layer_bwd(to_block(p.dec[l]), to_block(gr.dec[l]), W.dec[l], dd, W.sc, W.xd[l], W.g0, W.gb0, W.g1, W.gb1, last ? c.Nmask : 0, last ? c.Nvis : 0, st));
-    RC(mark());
+    RC(layer_bwd(to_block(p.dec[l]), to_block(gr.dec[l]), W.dec[l], dd, W.sc, W.xd[l], W.g0, W.g1, pipe, last ? c.Nmask : 0, last ? c.Nvis : 0, next_event(), st));
   }
   // decoder input: mask_token gradient = sum over masked rows; visible rows flow into encoder_to_decoder
   RC(colsum_f32(W.g0, c.dd, (int)Rm, c.dd, gr.mask_token, c.Nmask, c.N, c.Nvis, W.sc.scratch, W.sc.scratch_bytes, st));
-  RC(gather_rows_bf16(W.gb0, W.d_vis, (int)R, c.dd, c.Nvis, c.N, 0, st));
+  RC(gather_rows_bf16(pipe.cur(), W.d_vis, (int)R, c.dd, c.Nvis, c.N, 0, st));
   RC(gemm_tn(W.d_vis, c.dd, W.enc_out, c.d, (int)R, c.dd, c.d, gr.e2d_w, W.sc.scratch, W.sc.scratch_bytes, st));
   {
-    GemmEpi e; e.out_f32 = W.g1; e.ld_of = c.d; e.out_bf16 = W.gb1; e.ld_ob = c.d;
+    // (pipe.cur() was the last decoder block's output gradient, consumed by the gather above; no deferred launch reads a block's OUTPUT buffer)
+    GemmEpi e; e.out_f32 = W.g1; e.ld_of = c.d; e.out_bf16 = pipe.cur(); e.ld_ob = c.d;
     RC(gemm_nt(W.d_vis, c.dd, W.e2d_t, c.dd, (int)R, c.d, c.dd, e, st));
   }
   RC(mark());
   for (int l = c.layers - 1; l >= 0; l--) {
     // recompute: the decoder ran after the encoder and does not touch the encoder's shared set, so the last encoder block's activations survive
     if (c.recompute && l != c.layers - 1) RC(layer_fwd(to_block(p.enc[l]), W.enc[l], de, W.sc, W.x[l], W.x[l + 1], nullptr, 0, 0, st));
-    RC(layer_bwd(to_block(p.enc[l]), to_block(gr.enc[l]), W.enc[l], de, W.sc, W.x[l], W.g1, W.gb1, W.g0, W.gb0, 0, 0, st));
-    RC(mark());
+    RC(layer_bwd(to_block(p.enc[l]), to_block(gr.enc[l]), W.enc[l], de, W.sc, W.x[l], W.g1, W.g0, pipe, 0, 0, next_event(), st));
   }
   // patch embedding (the volume needs no gradient)
   {
     TnColsum cs; cs.dst[0] = gr.pe_b; cs.seg = c.d;
-    RC(gemm_tn(W.gb1, c.d, W.a_patch, K, (int)R, c.d, K, gr.pe_w, W.sc.scratch, W.sc.scratch_bytes, st, &cs));
+    RC(gemm_tn(pipe.cur(), c.d, W.a_patch, K, (int)R, c.d, K, gr.pe_w, W.sc.scratch, W.sc.scratch_bytes, st, &cs));
   }
   RC(mark());
+  RC(pipe.drain(st));   // the caller's stream is ordered behind every deferred launch: all gradients are final where this call's work ends
   return SMBV_OK;
 }
 

@@ -51,6 +51,19 @@ struct TnColsum {
 int gemm_tn(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int M, int N1, int N2, float* out, void* ws, size_t ws_bytes, hipStream_t st,
             const TnColsum* colsum = nullptr);
 size_t gemm_tn_workspace_bytes(int M, int N1, int N2);
+// Grouped weight-gradient launch: up to TN_GROUP_MAX products out[N1,N2] = X[M,N1]^T Y[M,N2] as ONE grid, every output tile reduced over its product's
+// whole token range (no slabs, no finishing launch); seg > 0: the column sums of X go straight to sum_dst[n / seg][n % seg] (null segment = dropped).
+// All products of a launch use one tile size: 256 x 256 when every N1, N2 is a multiple of 256, else 128 x 128 (multiples of 128 required).
+static constexpr int TN_GROUP_MAX = 8;
+struct TnJob {
+  const bf16_t* X; const bf16_t* Y; float* out;
+  float* sum_dst[3];
+  int ldx, ldy, M, N1, N2, seg;
+  int tile0;  // (filled in by gemm_tn_grouped) first block of this job
+};
+struct TnGroup { TnJob job[TN_GROUP_MAX]; int njobs; };
+bool gemm_tn_grouped_ok(const TnJob* jobs, int njobs);
+int gemm_tn_grouped(const TnJob* jobs, int njobs, hipStream_t st);
 
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd, int rows, int D, float eps,
                   long grp_in, long grp_out, long row_off, hipStream_t st, float* y32 = nullptr);

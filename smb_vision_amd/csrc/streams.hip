@@ -28,7 +28,7 @@ ForkJoin* fork_join_for_current_device() {
       if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
       if (hipStreamCreateWithFlags(&f.wside, hipStreamNonBlocking) != hipSuccess) return nullptr;
     }
-    hipEvent_t* ev[4] = {&f.fork, &f.join, &f.wfork, &f.wjoin};
+    hipEvent_t* ev[8] = {&f.fork, &f.join, &f.wfork, &f.wjoin, &f.wdone[0], &f.wdone[1], &f.wdone[2], &f.wdone[3]};
     for (auto e : ev)
       if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return nullptr;
     f.mu = new std::mutex();

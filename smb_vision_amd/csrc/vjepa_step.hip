@@ -22,8 +22,9 @@ struct VjepaWs {
   float *enc_mean, *enc_rstd, *pred_mean, *pred_rstd, *ctx_emb;
   // backward
   float *g0, *g1, *gtmp;
-  bf16_t *gb0, *gb1, *dpred_bf, *d_tgt, *d_lnfull, *d_ctx, *d_encctx;
+  bf16_t *dpred_bf, *d_tgt, *d_lnfull, *d_ctx, *d_encctx;
   BwdScratch sc;
+  WgradPipe pipe;   // rings of the deferred weight-gradient launches (block.h)
   size_t total;
 };
 
@@ -93,8 +94,6 @@ static void vcarve(const smbv_vjepa_cfg& c, void* base, VjepaWs& w) {
   const size_t gw = std::max(Re * c.d, Rp * c.pd);
   w.g0 = cv.take<float>(gw);
   w.g1 = cv.take<float>(gw);
-  w.gb0 = cv.take<bf16_t>(gw);
-  w.gb1 = cv.take<bf16_t>(gw);
   w.gtmp = cv.take<float>(Rt * c.pd);
   w.dpred_bf = cv.take<bf16_t>(Rt * c.d);
   w.d_tgt = cv.take<bf16_t>(Rt * c.pd);
@@ -118,6 +117,7 @@ static void vcarve(const smbv_vjepa_cfg& c, void* base, VjepaWs& w) {
   tn(Re, c.d, K); tn(Rc, c.pd, c.d); tn(Rt, c.d, c.pd);
   nd.scratch = std::max(nd.scratch, colsum_workspace_bytes((int)std::max(Re, Rp), std::max(std::max(c.d, c.pd), K)));
   carve_bwd_scratch(cv, w.sc, nd);
+  carve_wgrad_pipe(cv, w.pipe, gw, nd);
   w.sc.gath0 = nullptr;
   w.sc.gath1 = nullptr;
   {  // gathered copies of the ranged rows (block.hip: contiguous without them only for one sequence)
@@ -211,13 +211,13 @@ static int vjepa_backward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, 
   const int need_events = 4 + c.layers + c.players;
   if (events && n_events < need_events) { set_error("vjepa_backward: need %d events, got %d", need_events, n_events); return SMBV_ERR_ARG; }
   int ev = 0;
-  auto mark = [&]() -> int {  // a gradient group is final: the data-parallel engine may start averaging it
-    if (events) HIPRC(hipEventRecord((hipEvent_t)events[ev], st));
-    ev++;
-    return SMBV_OK;
-  };
   VjepaWs W;
   vcarve(c, ws, W);
+  WgradPipe& pipe = W.pipe;
+  RC(pipe.begin());
+  auto next_event = [&]() -> hipEvent_t { return events ? (hipEvent_t)events[ev++] : (ev++, (hipEvent_t) nullptr); };
+  // a gradient group produced on `st` is final: the data-parallel engine may start averaging it (the blocks' own groups: layer_bwd, on the side stream)
+  auto mark = [&]() -> int { return pipe.mark_inline(next_event(), st); };
   if (!ws || ws_bytes < W.total || ((uintptr_t)ws & 255)) { set_error("vjepa_backward: workspace too small or misaligned"); return SMBV_ERR_WORKSPACE; }
   const bool with_pred = io.d_pred != nullptr;
   if (!with_pred && !io.d_enc) { set_error("vjepa_backward: neither d_pred nor d_enc"); return SMBV_ERR_ARG; }
@@ -242,19 +242,18 @@ static int vjepa_backward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, 
   const int pneed = vpneed(c);
   HIPRC(hipMemsetAsync(W.d_lnfull, 0, Rp * c.pd * sizeof(bf16_t), st));
   RC(scatter_rows_idx_bf16(W.d_tgt, W.d_lnfull, io.tgt_slot, (long)Rt, c.Ntgt, pneed ? pneed : Sp, c.pd, st));
-  if (pneed) RC(layernorm_bwd(W.d_lnfull, W.xp[c.players], W.pred_mean, W.pred_rstd, p.pred_ln_w, nullptr, W.g0, W.gb0, gr.pred_ln_w, gr.pred_ln_b, vpb(c) * pneed, c.pd,
+  if (pneed) RC(layernorm_bwd(W.d_lnfull, W.xp[c.players], W.pred_mean, W.pred_rstd, p.pred_ln_w, nullptr, W.g0, pipe.cur(), gr.pred_ln_w, gr.pred_ln_b, vpb(c) * pneed, c.pd,
                               pneed, Sp, 0, W.sc.scratch, W.sc.scratch_bytes, st));   // compact dy / statistics; gradients land at the slots' rows of the full layout
-  else RC(layernorm_bwd(W.d_lnfull, W.xp[c.players], W.pred_mean, W.pred_rstd, p.pred_ln_w, nullptr, W.g0, W.gb0, gr.pred_ln_w, gr.pred_ln_b, (int)Rp, c.pd, 0,
+  else RC(layernorm_bwd(W.d_lnfull, W.xp[c.players], W.pred_mean, W.pred_rstd, p.pred_ln_w, nullptr, W.g0, pipe.cur(), gr.pred_ln_w, gr.pred_ln_b, (int)Rp, c.pd, 0,
                         0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
   RC(mark());  // [0] predictor.proj + predictor.layernorm
   for (int l = c.players - 1; l >= 0; l--) {
-    RC(layer_bwd(vblock(p.pred[l]), vblock(gr.pred[l]), W.pred[l], dp, W.sc, W.xp[l], W.g0, W.gb0, W.g1, W.gb1, l == c.players - 1 ? pneed : 0, 0, st));
-    RC(mark());  // [1 .. players] predictor layers, last first
+    RC(layer_bwd(vblock(p.pred[l]), vblock(gr.pred[l]), W.pred[l], dp, W.sc, W.xp[l], W.g0, W.g1, pipe, l == c.players - 1 ? pneed : 0, 0, next_event(), st));   // [1 .. players] predictor layers, last first
   }
   // predictor input: mask-token gradient = sum over the target slots; context slots flow into predictor_embeddings
   RC(gather_rows_idx_f32(W.g0, W.gtmp, io.tgt_slot, (long)Rt, c.Ntgt, Sp, c.pd, st));
   RC(colsum_f32(W.gtmp, c.pd, (int)Rt, c.pd, gr.mask_token, 0, 0, 0, W.sc.scratch, W.sc.scratch_bytes, st));
-  RC(gather_rows_idx_bf16(W.gb0, W.d_ctx, io.ctx_slot, (long)Rc, c.Nctx, Sp, c.pd, st));
+  RC(gather_rows_idx_bf16(pipe.cur(), W.d_ctx, io.ctx_slot, (long)Rc, c.Nctx, Sp, c.pd, st));
   {
     TnColsum cs; cs.dst[0] = gr.pemb_b; cs.seg = c.pd;
     RC(gemm_tn(W.d_ctx, c.pd, W.ctx_bf, c.d, (int)Rc, c.pd, c.d, gr.pemb_w, W.sc.scratch, W.sc.scratch_bytes, st, &cs));
@@ -280,21 +279,21 @@ static int vjepa_backward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, 
   // LayerNorm backward takes its dy in
   if (io.d_enc) RC(add_f32_into_bf16(W.d_lnfull, io.d_enc, Re * c.d, st));
   const int need = vneed(c);
-  if (need) RC(layernorm_bwd(W.d_lnfull, W.x[c.layers], W.enc_mean, W.enc_rstd, p.enc_ln_w, nullptr, W.g0, W.gb0, gr.enc_ln_w, gr.enc_ln_b, c.B * need, c.d, need, c.N, 0,
+  if (need) RC(layernorm_bwd(W.d_lnfull, W.x[c.layers], W.enc_mean, W.enc_rstd, p.enc_ln_w, nullptr, W.g0, pipe.cur(), gr.enc_ln_w, gr.enc_ln_b, c.B * need, c.d, need, c.N, 0,
                              W.sc.scratch, W.sc.scratch_bytes, st));   // compact dy / statistics, gradients written at the tokens' rows of the full layout
-  else RC(layernorm_bwd(W.d_lnfull, W.x[c.layers], W.enc_mean, W.enc_rstd, p.enc_ln_w, nullptr, W.g0, W.gb0, gr.enc_ln_w, gr.enc_ln_b, (int)Re, c.d, 0, 0, 0,
+  else RC(layernorm_bwd(W.d_lnfull, W.x[c.layers], W.enc_mean, W.enc_rstd, p.enc_ln_w, nullptr, W.g0, pipe.cur(), gr.enc_ln_w, gr.enc_ln_b, (int)Re, c.d, 0, 0, 0,
                         W.sc.scratch, W.sc.scratch_bytes, st));
   RC(mark());  // [players+2] encoder.layernorm
   for (int l = c.layers - 1; l >= 0; l--) {
-    RC(layer_bwd(vblock(p.enc[l]), vblock(gr.enc[l]), W.enc[l], de, W.sc, W.x[l], W.g0, W.gb0, W.g1, W.gb1, l == c.layers - 1 ? need : 0, 0, st));
-    RC(mark());  // [players+3 ..] encoder layers, last first
+    RC(layer_bwd(vblock(p.enc[l]), vblock(gr.enc[l]), W.enc[l], de, W.sc, W.x[l], W.g0, W.g1, pipe, l == c.layers - 1 ? need : 0, 0, next_event(), st));   // [players+3 ..] encoder layers, last first
   }
   // patch embedding
   {
     TnColsum cs; cs.dst[0] = gr.pe_b; cs.seg = c.d;
-    RC(gemm_tn(W.gb0, c.d, W.a_patch, K, (int)Re, c.d, K, gr.pe_w, W.sc.scratch, W.sc.scratch_bytes, st, &cs));
+    RC(gemm_tn(pipe.cur(), c.d, W.a_patch, K, (int)Re, c.d, K, gr.pe_w, W.sc.scratch, W.sc.scratch_bytes, st, &cs));
   }
   RC(mark());  // [last] patch embedding
+  RC(pipe.drain(st));   // the caller's stream is ordered behind every deferred launch
   return SMBV_OK;
 }
 

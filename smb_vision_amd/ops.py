@@ -85,6 +85,35 @@ def gemm_tn_bias(X, Y):
     return out, xs
 
 
+def gemm_tn_grouped(pairs, sums=None, out=None):
+    """pairs: list of (X [M,N1], Y [M,N2]) bf16; returns the list of X^T @ Y (fp32) from ONE launch (smbv_gemm_tn_grouped).  sums: per job None or a
+    segment count (1..3): also returns that job's column sums of X as a list of `segments` tensors."""
+    lib = _lib.load()
+    n = len(pairs)
+    jobs = (_lib.TnJob * n)()
+    outs, xs = [], []
+    for i, (X, Y) in enumerate(pairs):
+        _need_gpu(X, Y)
+        M, N1 = X.shape
+        N2 = Y.shape[1]
+        o = out[i] if out is not None else torch.empty(N1, N2, dtype=torch.float32, device=X.device)
+        outs.append(o)
+        j = jobs[i]
+        j.X, j.Y, j.out, j.ldx, j.ldy, j.M, j.N1, j.N2 = X.data_ptr(), Y.data_ptr(), o.data_ptr(), X.stride(0), Y.stride(0), M, N1, N2
+        nseg = sums[i] if sums else None
+        if nseg:
+            segs = [torch.empty(N1 // nseg, dtype=torch.float32, device=X.device) for _ in range(nseg)]
+            j.seg = N1 // nseg
+            for k, t in enumerate(segs):
+                j.sum_dst[k] = t.data_ptr()
+            xs.append(segs)
+        else:
+            j.seg = 0
+            xs.append(None)
+    check(lib.smbv_gemm_tn_grouped(jobs, n, _stream()), "smbv_gemm_tn_grouped")
+    return (outs, xs) if sums else outs
+
+
 def layernorm_fwd(x, gamma, beta, eps, rows=None, grp=(0, 0, 0)):
     _need_gpu(x, gamma, beta)
     lib = _lib.load()

@@ -249,3 +249,41 @@ def test_delta_from_the_projection_epilogue_equals_the_standalone_launch(residua
             r = ref_grads[k].cuda()
             assert float((a - r).norm()) <= 6e-2 * float(r.norm()) + 1e-9, k
             assert float((a - p.grad).norm()) <= 2e-2 * float(r.norm()) + 1e-9, k
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_deferred_grouped_weight_gradients_equal_the_inline_products(B):
+    """Round 4: a block's four weight-gradient products (+ bias sums + LayerNorm parameter reductions) are deferred to the end of the block and issued as
+    ONE grouped launch on the side stream, beside the next block's backward (block.h WgradPipe; debug bit 4 = the per-product launches inside the block).
+    Same bf16 operands, same products, another summation order over the tokens (whole range per tile vs slabs): gradients equal to fp32 rounding, the
+    deferred step bitwise reproducible, and within the oracle tolerances.  Widths are multiples of 128 so that every block defers (4 + 3 blocks: the
+    six-entry gradient ring wraps); at B = 2 the ranged last decoder block runs inline between deferred ones."""
+    import ctypes
+    from transformers import VideoMAEConfig
+    from smb_vision_amd import _lib
+    from smb_vision_amd.masking import MaskGenerator
+    from smb_vision_amd.modeling_videomae import SmbVideoMAEForPreTraining
+    c = dict(image_size=96, num_frames=48, patch_size=16, tubelet_size=16, hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=512,
+             decoder_hidden_size=128, decoder_num_hidden_layers=3, decoder_num_attention_heads=2, decoder_intermediate_size=256)
+    cfg = MIMConfig(**c)
+    params = init_params(cfg, seed=11, nonzero_small=True)
+    model = build_model(c, params)
+    np.random.seed(5)
+    gen = MaskGenerator(96, 48, 16, 16, 0.6)
+    mask = torch.stack([gen() for _ in range(B)])
+    pix = torch.rand(B, 48, 1, 96, 96, generator=torch.Generator().manual_seed(6))
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    loss, logits, grads = run_step(model, pix, mask)
+    loss2, logits2, grads2 = run_step(model, pix, mask)
+    raw.smbv_debug_set_variant(4)
+    try:
+        loss_i, logits_i, grads_i = run_step(model, pix, mask)
+    finally:
+        raw.smbv_debug_set_variant(0)
+    assert torch.equal(loss, loss2) and torch.equal(logits, logits2) and torch.equal(loss, loss_i)
+    for k in grads:
+        assert torch.equal(grads[k], grads2[k]), k
+        assert float((grads[k] - grads_i[k]).norm()) <= 2e-5 * float(grads_i[k].norm()) + 1e-12, (k, float((grads[k] - grads_i[k]).norm()), float(grads_i[k].norm()))
+    ref_loss, ref_logits, ref_grads = mim_step(params, cfg, pix, mask)
+    check_against(loss, logits, grads, ref_loss, ref_logits, ref_grads)
+

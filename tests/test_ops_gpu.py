@@ -115,6 +115,30 @@ def test_gemm_tn_asymmetric(ops):
     assert torch.equal(ops.gemm_tn(X, Y), Y.float())
 
 
+@pytest.mark.parametrize("shapes", [
+    [(1000, 256, 512), (1000, 512, 256), (777, 256, 256), (1000, 768, 256)],     # every width a multiple of 256: 256 x 256 tiles, ragged token counts
+    [(2100, 384, 1536), (2100, 1536, 384), (1300, 384, 384), (2100, 1152, 384)],  # decoder widths: 128 x 128 tiles
+    [(33, 128, 128)],
+])
+def test_gemm_tn_grouped_is_the_products_one_by_one(ops, shapes):
+    """smbv_gemm_tn_grouped: a block's weight-gradient products as one launch, each tile reduced over all tokens (no slabs), bias sums written directly
+    (three segments for the fused q | k | v product, one of them dropped as VideoMAE's missing key bias is)."""
+    pairs = [(rnd(M, N1, seed=10 + i).bfloat16(), rnd(M, N2, seed=20 + i).bfloat16()) for i, (M, N1, N2) in enumerate(shapes)]
+    nseg = [3 if N1 % 3 == 0 and (N1 // 3) % 128 == 0 else 1 for (_, N1, _) in shapes]
+    outs, xs = ops.gemm_tn_grouped(pairs, sums=nseg)
+    outs2, xs2 = ops.gemm_tn_grouped(pairs, sums=nseg)
+    for (X, Y), o, o2, x, x2, (M, N1, N2) in zip(pairs, outs, outs2, xs, xs2, shapes):
+        ref = X.float().t() @ Y.float()
+        assert rel_err(o, ref) < 1e-5 * math.sqrt(M) + 1e-6
+        assert torch.equal(o, o2)                                            # run-to-run identical
+        got = torch.cat(x)
+        assert rel_err(got, X.float().sum(0)) < 1e-5 * math.sqrt(M) + 1e-6 and torch.equal(got, torch.cat(x2))
+        single, xsingle = ops.gemm_tn_bias(X, Y)                              # the per-product launch (slabs + finishing kernel): same sums, other order
+        assert rel_err(o, single) < 2e-5 and rel_err(got, xsingle) < 2e-5
+    with pytest.raises(ValueError):
+        ops.gemm_tn_grouped([(rnd(64, 136, seed=1).bfloat16(), rnd(64, 128, seed=2).bfloat16())])
+
+
 @pytest.mark.parametrize("rows,D", [(5, 64), (1000, 768), (333, 384), (64, 128), (17, 1024)])
 def test_layernorm(ops, rows, D):
     x = rnd(rows, D, seed=1) * 2 + 0.5
