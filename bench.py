@@ -15,8 +15,9 @@ prints ONE JSON line (the task contract):
                         a NEW mask from the bit-exact MaskGenerator with host-built token lists; same barrier protocol.  PCIe-inclusive, therefore
                         reported beside `value`, never as it.
   roofline              dominant kernel = the decoder attention backward (attn_bwd_pair_kernel: key-owner and query-owner blocks in ONE launch, S = 20,480, 6 heads),
-                        timed with HIP events on its launch stream: `frac` counts the ALGORITHMIC five products (S, dP, dV, dK, dQ: 10 S^2 Dh H FLOP),
-                        `executed_frac` the seven products the two kernels execute (dQ's kernel recomputes S and dP); `dkv` is the dK/dV kernel alone;
+                        timed with HIP events on its launch stream: `frac` on SURVEY.md 8(d)'s count (backward = 2 x forward = FOUR S^2 Dh H products, the convention the
+                        step figure uses too), `frac_5_products` on the five a fused flash backward executes (S, dP, dV, dK, dQ), `executed_frac` on the seven
+                        this launch executes (its query-owner blocks recompute S and dP); `dkv` is the dK/dV kernel alone;
                         `step` the whole-step figure (18.46 TFLOP algorithmic fwd+bwd per volume).  Peak 2.5 PFLOP/s dense bf16.
   cpu_baseline          the CPU oracle (oracle/mim_oracle.py, kind "port", fused CPU attention as the reference defaults to SDPA) on this host's cores:
                         one warm-up step on a 2+1-layer model, then 2 timed FULL steps (forward + loss + backward) of the same workload.  Rank 0, N == 1.
@@ -24,6 +25,8 @@ prints ONE JSON line (the task contract):
                         fp32, SDPA attention, forward + loss + backward, one warm-up on a 2+1-layer model and ONE timed full step - beside the port, which stays the
                         headline CPU figure (kind "port"); it validates that the port is not a slower or faster program than the reference's own class.
   config.vjepa_ms_per_step / config.vit_large_fp8_recompute_ms_per_step   BASELINE.json configs 4 and 5 (one GPU), a few steps each after the headline leg.
+  config.no_optimizer_ms_per_step   forward + loss + backward only ("with and without optimizer"); config.b4_ms_per_volume: four volumes per step
+                        (the reference's shipped recipe, scripts/training/run_mim.sh:13-38) on the same model, per volume.
   config.trainer_ms_per_step   the same workload through the shipped harness (smb_vision_amd.run_mim: HF Trainer + SmbTrainer's optimizer tail) with
                         volumes handed over as pinned fp32 CPU tensors the way the reference's DataLoader does; N == 1 only.
 N > 1: `fed` is reported too (every rank feeds its own volumes over PCIe at once).
@@ -331,6 +334,37 @@ def vit_large_leg(device, steps=4, warmup=2):
     return dt / steps * 1e3
 
 
+def b4_leg(model, opt, gen, pix, device, steps=5, warmup=2):
+    """Four volumes per step on the headline model (the shipped launch recipe's batch, scripts/training/run_mim.sh:13-38): fwd + loss + bwd + clip +
+    AdamW; returns (ms per VOLUME, info).  Volumes 2-4 are rolled copies of the resident one (distinct data, no 1 GB of new random numbers), each with
+    its own mask and host-built token lists."""
+    from smb_vision_amd.masking import split_mask_indices_host
+    B = 4
+    pix4 = torch.cat([pix] + [torch.roll(pix, shifts=17 * i, dims=-1) for i in range(1, B)])
+    mask4 = torch.stack([gen() for _ in range(B)])
+    vis, msk = split_mask_indices_host(mask4)
+    mask4, vis, msk = mask4.to(device), vis.to(device), msk.to(device)
+    last = {}
+
+    def step():
+        out = model(pixel_values=pix4, bool_masked_pos=mask4, visible_index=vis, masked_index=msk)
+        out.loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        last["loss"] = out.loss
+
+    for _ in range(warmup):
+        step()
+    dt = timed_region(step, steps, 1, device)
+    ms = dt / steps * 1e3
+    info = dict(ms_per_step=ms, volumes_per_s=B * steps / dt, frac_of_mfma_peak=B * STEP_TFLOP / (ms * 1e-3) / MFMA_PEAK_TFLOPS, final_loss=float(last["loss"].detach()),
+                what="B = 4 volumes per step on one GPU (the reference's shipped recipe, scripts/training/run_mim.sh:13-38), same model / optimizer as the headline leg")
+    del pix4
+    model._ws = None   # the B = 4 workspace (~21 GB) is not kept for the legs that follow
+    torch.cuda.empty_cache()
+    return ms / B, info
+
+
 def reference_class_on_gpu(device, steps=3, warmup=2):
     """The reference's model class on the SAME GPU, for scale (a diagnostic beside the metric; nothing of it is on the product path):
     transformers.VideoMAEForPreTraining (src/run_mim.py:13-21) on the bench workload under bf16 autocast (the Trainer's --bf16) with torch clip + fused
@@ -557,10 +591,14 @@ def main():
             except Exception:
                 pass
             pair_s = kr["pair"] * 1e-3
+            # ONE convention for the line and for the step figure: SURVEY.md 8(d) credits attention backward at 2 x forward = FOUR S x S x Dh products per
+            # launch (8 S^2 Dh H = 1.2885 TFLOP) - that is `achieved` / `frac`.  Beside it: the five products a fused flash backward executes
+            # (`frac_5_products`: S, dP, dV, dK, dQ) and the seven this launch executes (`executed_frac`: its query-owner blocks recompute S and dP).
             line["roofline"] = {"bound": "mfma", "kernel": "decoder attention backward: attn_bwd_pair_kernel - key-owner (dK/dV) and query-owner (dQ) blocks mixed per CU in one launch (S=20480, H=6, Dh=64)",
-                                "achieved": 5 * unit / pair_s / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 5 * unit / pair_s / 1e12 / MFMA_PEAK_TFLOPS,
+                                "achieved": 4 * unit / pair_s / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 4 * unit / pair_s / 1e12 / MFMA_PEAK_TFLOPS,
+                                "frac_5_products": 5 * unit / pair_s / 1e12 / MFMA_PEAK_TFLOPS,
                                 "executed_frac": 7 * unit / pair_s / 1e12 / MFMA_PEAK_TFLOPS, "traffic": traffic, "launch_ms": kr["pair"],
-                                "flop_per_launch": 5 * unit, "executed_flop_per_launch": 7 * unit,
+                                "flop_per_launch": 4 * unit, "flop_per_launch_5_products": 5 * unit, "executed_flop_per_launch": 7 * unit,
                                 "dkv": {"launch_ms": kr["dkv"], "achieved": 4 * unit / (kr["dkv"] * 1e-3) / 1e12, "frac": 4 * unit / (kr["dkv"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
                                         "flop_per_launch": 4 * unit},
                                 "dq": {"launch_ms": kr["dq"], "executed": 3 * unit / (kr["dq"] * 1e-3) / 1e12},
@@ -572,6 +610,23 @@ def main():
                 line["config"]["trainer_ms_per_step"] = None
                 line["config"]["trainer_error"] = repr(e)
         plain = not args.tiny and not args.vit_large and not args.fp8 and not args.recompute and opt is not None and not args.torch_optimizer
+        if world == 1 and plain and not args.no_extra_configs:
+            # SURVEY.md 8(d) "with and without optimizer": forward + loss + backward only, same model and volume, same barrier protocol
+            try:
+                def step_noopt():
+                    model(pixel_values=pix, bool_masked_pos=mask, visible_index=vis_d, masked_index=msk_d).loss.backward()
+                    model.zero_grad(set_to_none=True)
+                for _ in range(2):
+                    step_noopt()
+                line["config"]["no_optimizer_ms_per_step"] = timed_region(step_noopt, args.steps, 1, device) / args.steps * 1e3
+            except Exception as e:
+                line["config"]["no_optimizer_ms_per_step"], line["config"]["no_optimizer_error"] = None, repr(e)
+            # the reference's SHIPPED recipe runs four volumes per device (scripts/training/run_mim.sh:13-38: --per_device_train_batch_size 4); the
+            # headline stays README.md:56-68's B = 1
+            try:
+                line["config"]["b4_ms_per_volume"], line["config"]["b4"] = b4_leg(model, opt, gen, pix, device)
+            except Exception as e:
+                line["config"]["b4_ms_per_volume"], line["config"]["b4_error"] = None, repr(e)
         if world == 1 and plain and not args.no_extra_configs:  # BASELINE.json configs 4 and 5 on one GPU, driver-visible
             try:
                 dtv, info = vjepa_leg(device, 1, 0, steps=5, warmup=2)

@@ -69,13 +69,35 @@ class DataParallelEngine:
         self._events: List[torch.cuda.Event] = []
         self._ev_array = None
         self._buckets = None
+        self.enqueue_lead: List[bool] = []
+        self.broadcast_collectives = 0
         model.dp = self
 
     # -- called by the model ------------------------------------------------------------------------------------------
-    def broadcast_parameters(self, model, src: int = 0):
-        """Identical replicas at start (DDP broadcasts rank 0's parameters at wrap time)."""
-        for p in model.parameters():
-            dist.broadcast(p.data, src=src, group=self.group)
+    def broadcast_parameters(self, model, src: int = 0, chunk_bytes: int = 256 << 20):
+        """Identical replicas at start (DDP broadcasts rank 0's parameters at wrap time).  The ~250 parameter tensors travel as a few flat buffers
+        (<= ``chunk_bytes`` each: ONE collective for ViT-base's 389 MB at the default) instead of one broadcast per tensor - xGMI collectives are
+        latency-bound below a few MB - grouped by dtype and device, order preserved."""
+        from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+        params = [p.data for p in model.parameters()]
+        self.broadcast_collectives = 0
+        i = 0
+        while i < len(params):
+            j, nbytes = i, 0
+            while j < len(params) and params[j].dtype == params[i].dtype and params[j].device == params[i].device and \
+                    (j == i or nbytes + params[j].numel() * params[j].element_size() <= chunk_bytes):
+                nbytes += params[j].numel() * params[j].element_size()
+                j += 1
+            group = params[i:j]
+            if len(group) == 1:
+                dist.broadcast(group[0], src=src, group=self.group)
+            else:
+                flat = _flatten_dense_tensors(group)
+                dist.broadcast(flat, src=src, group=self.group)
+                for p, v in zip(group, _unflatten_dense_tensors(flat, group)):
+                    p.copy_(v)
+            self.broadcast_collectives += 1
+            i = j
 
     def _setup(self, model):
         ranges = model.grad_group_ranges()
@@ -123,8 +145,14 @@ class DataParallelEngine:
             return
         main = torch.cuda.current_stream()
         works = []
+        # The whole backward was enqueued by ONE C call (~5 ms of host time for ~19 ms of GPU work); the collectives are enqueued now.  ``enqueue_lead`` records,
+        # per bucket, whether its gradient-group event had NOT fired yet when its wait + collective were enqueued - i.e. whether the host was ahead of
+        # the GPU and the all-reduce can start the moment the gradients exist (False = the bucket was already complete: its collective starts late by
+        # however long ago that was).  tools/dp_enqueue_lead.py prints it for the bench workload.
+        self.enqueue_lead = []
         with torch.cuda.stream(self.comm_stream):
             for a, b, last in self._buckets:
+                self.enqueue_lead.append(not self._events[last].query())
                 self.comm_stream.wait_event(self._events[last])
                 works.append(allreduce_mean_(flat[a:b], self.group, force))
         with torch.cuda.stream(main):

@@ -201,6 +201,7 @@ class SmbVJEPA2Model(PreTrainedModel):
         self.gradient_checkpointing = False
         self.mask_index = 1  # VJEPA2PredictorEmbeddings.forward default (modeling_vjepa.py:593)
         self._gflat = self._structs = self._ws = self._ws_key = self._rope = None
+        self._plumbing_checks = []
         self.dp = None  # optional smb_vision_amd.dp.DataParallelEngine (gradient averaging after the backward)
         self._fwd_count = 0
         self.reset_parameters()
@@ -302,6 +303,33 @@ class SmbVJEPA2Model(PreTrainedModel):
                     setattr(getattr(ps, path[0])[path[1]], path[2], pp), setattr(getattr(gs, path[0])[path[1]], path[2], gp)
             self._structs = (sig, ps, gs)
         return params
+
+    def _queue_plumbing_check(self, idx, cms, tms):
+        bad = torch.zeros((), dtype=torch.int32, device=cms[0].device)
+        for got, want in zip(list(idx["ctx_tok"]) + list(idx["tgt_tok"]), list(cms) + list(tms)):
+            bad = bad + (got.to(want.dtype) != want).any().to(torch.int32)
+        host = torch.empty(1, dtype=torch.int32).pin_memory()
+        host.copy_(bad.reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._plumbing_checks.append((ev, host, self._fwd_count + 1))
+
+    def _check_pending_plumbing(self, wait=False):
+        keep = []
+        for ev, host, step in self._plumbing_checks:
+            if wait:
+                ev.synchronize()
+            if not ev.query():
+                keep.append((ev, host, step))
+            elif int(host[0]) != 0:
+                self._plumbing_checks = []
+                raise ValueError(f"smbv_plumbing of forward #{step} was not built from the context / target masks passed with it (index_plumbing() must "
+                                 "see the masks the forward receives); its outputs and gradients used the plumbing's masks")
+        self._plumbing_checks = keep
+
+    def check_plumbing(self):
+        """Blocks until every queued smbv_plumbing / mask comparison has been read back; raises if one failed."""
+        self._check_pending_plumbing(wait=True)
 
     def grad_views(self):
         return [self._gflat[o:o + p.numel()].view(p.shape) for p, o in zip(self._ordered_params(), self._goffs)]
@@ -441,10 +469,15 @@ class SmbVJEPA2Model(PreTrainedModel):
             native_heads = (c.hidden_size // c.num_attention_heads) in (32, 64)  # (head-padded encoder widths: the ranged block is not built for them)
             if smbv_needed is not None and (len(cms) != 1 or sel[0].shape[1] >= N or not native_heads or (smbv_needed == "target" and not skip_predictor)):
                 smbv_needed = None  # mask lists, a mask that keeps every token, or a predictor that needs the context rows: the unrestricted forward
+            self._check_pending_plumbing()
             if smbv_plumbing is not None and _plumbing_fits(smbv_plumbing, smbv_needed, cms, tms):
                 # built by index_plumbing() ahead of the step (run_vjepa.collate_fn, on the host): only the uploads remain
                 idx = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else ([t.to(dev, non_blocking=True) for t in v] if isinstance(v, (list, tuple)) else v))
                        for k, v in smbv_plumbing.items()}
+                # the arrays must have been built from THESE masks (a caller that perturbs the masks after collate, or reuses a cached batch
+                # dict, would otherwise run on stale indices silently).  Compared on the device, read back without a synchronisation: a mismatch raises
+                # at the next forward (or at check_plumbing()), naming this step.
+                self._queue_plumbing_check(idx, cms, tms)
             else:
                 idx = self._index_plumbing(cms, tms, dev, smbv_needed)
             with_pred = not skip_predictor
@@ -553,7 +586,11 @@ class MomentumEncoder:
 
 def make_target_encoder(model: SmbVJEPA2Model) -> SmbVJEPA2Model:
     """VJEPATrainer.__init__ (run_vjepa.py:104-106): frozen deep copy of the online model."""
-    t = copy.deepcopy(model)
+    pending, model._plumbing_checks = model._plumbing_checks, []   # (events / pinned buffers of queued checks are not part of a copy)
+    try:
+        t = copy.deepcopy(model)
+    finally:
+        model._plumbing_checks = pending
     t._gflat = t._structs = t._ws = t._ws_key = None
     for p in t.parameters():
         p.requires_grad = False

@@ -31,7 +31,7 @@ from transformers import HfArgumentParser, TrainingArguments, VideoMAEConfig, se
 
 from .masking import MaskGenerator, split_mask_indices_host
 from .modeling_videomae import SmbVideoMAEForPreTraining
-from .trainer import SmbTrainer
+from .trainer import SmbTrainer, detect_last_checkpoint, keep_loss_only, loss_only_metrics, train_and_evaluate
 
 logger = logging.getLogger(__name__)
 os.environ.setdefault("HF_HUB_OFFLINE", "1")
@@ -49,6 +49,7 @@ class DataTrainingArguments:
     mask_patch_size: int = field(default=32, metadata={"help": "The size of the square patches to use for masking."})
     mask_ratio: float = field(default=0.5, metadata={"help": "Percentage of patches to mask."})
     num_train_volumes: int = field(default=16, metadata={"help": "Synthetic volumes per epoch."})
+    num_eval_volumes: int = field(default=2, metadata={"help": "Synthetic validation volumes (used with --do_eval / --eval_strategy)."})
     data_seed_offset: int = field(default=1234, metadata={"help": "Seed of the synthetic volumes."})
 
 
@@ -70,7 +71,10 @@ class ModelArguments:
 
 class SyntheticVolumeDataset(Dataset):
     """Items shaped like the reference pipeline's output (``src/dataloader/mim.py:142-185``): ``image`` f32 (D,1,H,W) in [0,1],
-    ``mask`` bool (N,).  As with MONAI's deterministic ``GenerateMask`` transform, the mask is drawn when the item is produced."""
+    ``mask`` bool (N,).  The mask of item i is drawn from the legacy numpy stream seeded with (seed + i) - a fixed mask per sample, which is what the
+    reference's ``PersistentDataset`` ends up with (``GenerateMask`` is a deterministic transform, so the mask is cached with the image: SURVEY.md 8f-3) and
+    what makes a resumed run see the batches the uninterrupted run saw (HF skips batches by index, without producing the items).  The global numpy
+    stream is left as it was found."""
 
     def __init__(self, n, image_size, depth, mask_generator, seed):
         self.n, self.image_size, self.depth, self.gen, self.seed = n, image_size, depth, mask_generator, seed
@@ -80,7 +84,13 @@ class SyntheticVolumeDataset(Dataset):
 
     def __getitem__(self, i):
         g = torch.Generator().manual_seed(self.seed + i)
-        return {"image": torch.rand(self.depth, 1, self.image_size, self.image_size, generator=g), "mask": self.gen()}
+        state = np.random.get_state()
+        np.random.seed((self.seed + i) % (2 ** 32))
+        try:
+            mask = self.gen()
+        finally:
+            np.random.set_state(state)
+        return {"image": torch.rand(self.depth, 1, self.image_size, self.image_size, generator=g), "mask": mask}
 
 
 def collate_fn(examples):
@@ -110,6 +120,8 @@ def build_trainer(argv=None):
                         model_patch_size=data_args.patch_size, mask_ratio=data_args.mask_ratio)
     np.random.seed(training_args.seed)
     train = SyntheticVolumeDataset(data_args.num_train_volumes, data_args.image_size, data_args.depth, gen, data_args.data_seed_offset)
+    evaluating = training_args.do_eval or str(getattr(training_args.eval_strategy, "value", training_args.eval_strategy)) != "no"
+    val = SyntheticVolumeDataset(data_args.num_eval_volumes, data_args.image_size, data_args.depth, gen, data_args.data_seed_offset + 1_000_003) if evaluating else None
 
     config = VideoMAEConfig.from_pretrained(model_args.config_name_or_path) if model_args.config_name_or_path else VideoMAEConfig()
     config.update({"num_channels": 1, "num_frames": data_args.depth, "tubelet_size": data_args.patch_size, "image_size": data_args.image_size,
@@ -125,17 +137,17 @@ def build_trainer(argv=None):
         model = SmbVideoMAEForPreTraining(config)
 
     # SmbTrainer == HF Trainer + RCCL gradient averaging (instead of accelerate's DDP wrap, acc_configs/multi_gpu_config.yaml) + the fused clip/AdamW tail
-    return SmbTrainer(model=model, args=training_args, train_dataset=train, data_collator=collate_fn)
+    # eval_dataset / compute_metrics as src/run_mim.py:429-436 (the loss is the first "prediction"; only it leaves the device)
+    return SmbTrainer(model=model, args=training_args, train_dataset=train, eval_dataset=val, data_collator=collate_fn, compute_metrics=loss_only_metrics,
+                      preprocess_logits_for_metrics=keep_loss_only)
 
 
 def main(argv=None):
+    """``src/run_mim.py:263-276, 439-455``: auto-resume from the newest ``checkpoint-*`` of ``output_dir`` (or ``--resume_from_checkpoint``), train, save,
+    evaluate under ``--do_eval``."""
     trainer = build_trainer(argv)
-    result = trainer.train()
-    trainer.save_model()
-    trainer.log_metrics("train", result.metrics)
-    trainer.save_metrics("train", result.metrics)
-    trainer.save_state()
-    return result.metrics
+    last = detect_last_checkpoint(trainer.args, logger)
+    return train_and_evaluate(trainer, trainer.args, last)
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@ from transformers import HfArgumentParser, TrainingArguments, VJEPA2Config, set_
 
 from .masking import VJEPAMaskGenerator
 from .modeling_vjepa import MomentumEncoder, SmbVJEPA2Model, l1_loss, make_target_encoder, vjepa_loss
-from .trainer import SmbTrainer
+from .trainer import SmbTrainer, detect_last_checkpoint, keep_loss_only, loss_only_metrics, train_and_evaluate
 
 logger = logging.getLogger(__name__)
 os.environ.setdefault("HF_HUB_OFFLINE", "1")
@@ -50,6 +50,18 @@ class SmbVJEPATrainer(SmbTrainer):
             self.momentum_encoder = MomentumEncoder(self.target_encoder, momentum=self.momentum)
         loss, outputs = vjepa_loss(model, self.target_encoder, self.momentum_encoder, inputs)
         return (loss, outputs) if return_outputs else loss
+
+    def prediction_step(self, model, inputs, prediction_loss_only, ignore_keys=None):
+        """Evaluation (``trainer.evaluate()``, run_vjepa.py:270-275): the stock step would call ``model(**inputs)``, whose output has no loss at all - the L1
+        loss lives in ``compute_loss``.  Here: the same loss against the current target encoder, no gradient, NO momentum update."""
+        inputs = self._prepare_inputs(inputs)
+        if self.target_encoder is None:
+            self.target_encoder = make_target_encoder(getattr(model, "module", model))
+            self.momentum_encoder = MomentumEncoder(self.target_encoder, momentum=self.momentum)
+        with torch.no_grad():
+            loss, _ = vjepa_loss(model, self.target_encoder, None, inputs)
+        loss = loss.detach()
+        return (loss, None, None) if prediction_loss_only else (loss, loss.reshape(1), None)
 
 
 def collate_fn(examples, num_patches=0):
@@ -81,7 +93,14 @@ class SyntheticVJEPADataset(Dataset):
     def __getitem__(self, i):
         g = torch.Generator().manual_seed(self.seed + i)
         item = {"image": torch.rand(self.depth, 1, self.crop, self.crop, generator=g)}
-        return self.gen(item)
+        # a fixed mask per sample (the generator draws from torch's GLOBAL stream, transforms.py:168-170): what the reference's PersistentDataset caches
+        # with the image, and what lets a resumed run see the uninterrupted run's batches; the global stream is left as it was found
+        state = torch.random.get_rng_state()
+        torch.manual_seed(self.seed + i)
+        try:
+            return self.gen(item)
+        finally:
+            torch.random.set_rng_state(state)
 
 
 @dataclass
@@ -91,6 +110,7 @@ class DataTrainingArguments:
     patch_size: int = field(default=16)
     num_mask_blocks: int = field(default=3)
     num_train_volumes: int = field(default=16)
+    num_eval_volumes: int = field(default=2)
 
 
 @dataclass
@@ -120,11 +140,14 @@ def main(argv=None):
     gen = VJEPAMaskGenerator(input_size=(dargs.depth, dargs.image_size, dargs.image_size), patch_size=(dargs.patch_size,) * 3,
                              pred_mask_scale=(0.2, 0.8), aspect_ratio=(0.3, 3.0), num_blocks=dargs.num_mask_blocks)
     train = SyntheticVJEPADataset(dargs.num_train_volumes, dargs.image_size, dargs.depth, gen, 1234)
-    trainer = SmbVJEPATrainer(model=model, args=targs, train_dataset=train, data_collator=functools.partial(collate_fn, num_patches=model.num_patches))
-    result = trainer.train()
-    trainer.save_model()
-    trainer.log_metrics("train", result.metrics)
-    return result.metrics
+    evaluating = targs.do_eval or str(getattr(targs.eval_strategy, "value", targs.eval_strategy)) != "no"
+    val = SyntheticVJEPADataset(dargs.num_eval_volumes, dargs.image_size, dargs.depth, gen, 1_001_237) if evaluating else None
+    # eval_dataset / compute_metrics as src/run_vjepa.py:249-256; auto-resume and the train / save / evaluate tail as :191-205, 258-275 (the EMA target
+    # encoder lives on the trainer and is NOT part of a checkpoint - the reference's behaviour: a resumed run re-copies it from the restored online weights)
+    trainer = SmbVJEPATrainer(model=model, args=targs, train_dataset=train, eval_dataset=val, data_collator=functools.partial(collate_fn, num_patches=model.num_patches),
+                              compute_metrics=loss_only_metrics, preprocess_logits_for_metrics=keep_loss_only)
+    last = detect_last_checkpoint(targs, logger)
+    return train_and_evaluate(trainer, targs, last)
 
 
 if __name__ == "__main__":

@@ -182,3 +182,55 @@ class SmbTrainer(Trainer):
 
 def unwrap_optimizer(optimizer):
     return getattr(optimizer, "optimizer", optimizer)
+
+
+def detect_last_checkpoint(training_args, logger=None):
+    """``src/run_mim.py:263-276`` / ``src/run_vjepa.py:191-205``: an ``output_dir`` that already holds ``checkpoint-*`` directories resumes from the newest one
+    unless ``--resume_from_checkpoint`` names another (or ``--overwrite_output_dir``, where the installed transformers still has that flag)."""
+    import os
+    from transformers.trainer_utils import get_last_checkpoint
+    last = None
+    out = training_args.output_dir
+    if out and os.path.isdir(out) and not getattr(training_args, "overwrite_output_dir", False):
+        last = get_last_checkpoint(out)
+        if last is None and len(os.listdir(out)) > 0 and hasattr(training_args, "overwrite_output_dir"):
+            raise ValueError(f"Output directory ({out}) already exists and is not empty. Use --overwrite_output_dir to overcome.")
+        if last is not None and training_args.resume_from_checkpoint is None and logger is not None:
+            logger.info(f"Checkpoint detected, resuming training at {last}. To avoid this behavior, change the `--output_dir`.")
+    return last
+
+
+def train_and_evaluate(trainer, training_args, last_checkpoint=None):
+    """The tail both reference scripts share (``src/run_mim.py:439-455``, ``src/run_vjepa.py:258-275``): ``train(resume_from_checkpoint=...)`` with the
+    explicit checkpoint first, the detected one second; ``save_model`` / metrics / state; ``evaluate()`` under ``--do_eval``."""
+    checkpoint = training_args.resume_from_checkpoint if training_args.resume_from_checkpoint is not None else last_checkpoint
+    result = trainer.train(resume_from_checkpoint=checkpoint)
+    trainer.save_model()
+    trainer.log_metrics("train", result.metrics)
+    trainer.save_metrics("train", result.metrics)
+    trainer.save_state()
+    metrics = dict(result.metrics)
+    if training_args.do_eval and trainer.eval_dataset is not None:
+        ev = trainer.evaluate()
+        trainer.log_metrics("eval", ev)
+        trainer.save_metrics("eval", ev)
+        metrics.update(ev)
+    return metrics
+
+
+def loss_only_metrics(eval_pred):
+    """The reference's ``compute_metrics=lambda eval_pred: {"loss": eval_pred.predictions[0].item()}`` (``src/run_mim.py:435``, ``src/run_vjepa.py:255``): the
+    model's loss is the first "prediction".  ``.item()`` only works for ONE evaluation batch; the mean over the batches is the
+    same number there and defined for more."""
+    import numpy as np
+    p = eval_pred.predictions
+    p = p[0] if isinstance(p, (tuple, list)) else p
+    return {"loss": float(np.mean(np.asarray(p, dtype=np.float64)))}
+
+
+def keep_loss_only(logits, labels):
+    """``preprocess_logits_for_metrics``: of (loss, logits [B, N_mask, 4096], ...) only the loss travels to the host - the reconstruction of ONE 512 x 512 x 320
+    volume is 109 MB of bf16 that ``compute_metrics`` never reads."""
+    first = logits[0] if isinstance(logits, (tuple, list)) else logits
+    return first.detach().float().reshape(-1)[:1] if first.dim() == 0 or first.numel() == 1 else first
+

@@ -74,6 +74,17 @@ def _worker(rank, world, port, q):
         model._g = p
         eng.broadcast_parameters(model, src=0)
         q.put((rank, bool((p == 0).all()), 0.0))
+        # ... and travels coalesced: many tensors of mixed shapes in few collectives (one flat buffer per <= chunk_bytes), values and order preserved
+        many = [torch.full((3 + i % 5, 2 + i % 3), float(rank * 100 + i)) for i in range(40)]
+
+        class Many:
+            def parameters(self):
+                return many
+        eng.broadcast_parameters(Many(), src=0)
+        ok = all(bool((t == float(i)).all()) for i, t in enumerate(many)) and eng.broadcast_collectives == 1
+        eng.broadcast_parameters(Many(), src=0, chunk_bytes=400)     # forced into several chunks
+        ok = ok and all(bool((t == float(i)).all()) for i, t in enumerate(many)) and 1 < eng.broadcast_collectives < 40
+        q.put((rank, ok, 0.0))
     finally:
         dist.destroy_process_group()
 
@@ -88,7 +99,7 @@ def test_bucketed_allreduce_world2_gloo():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    res = [q.get(timeout=10) for _ in range(4)]
+    res = [q.get(timeout=10) for _ in range(6)]
     assert all(ok for _, ok, _ in res)
     sums = [s for r, ok, s in res if s != 0.0]
     assert len(sums) == 2 and abs(sums[0] - sums[1]) < 1e-5  # both ranks hold the same averaged gradients

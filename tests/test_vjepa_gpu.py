@@ -194,6 +194,27 @@ def test_hf_trainer_runs_vjepa(tmp_path):
     assert os.path.exists(os.path.join(tmp_path, "model.safetensors"))
 
 
+def test_hf_trainer_vjepa_resumes_and_evaluates(tmp_path):
+    """run_vjepa.py:191-205, 258-275: auto-resume + evaluate.  Not bit-identical to an uninterrupted run by the reference's own design: the EMA target
+    encoder lives on the trainer, is not checkpointed, and a resumed run re-copies it from the restored online weights."""
+    import json
+    import shutil
+    from smb_vision_amd.run_vjepa import main
+    common = ["--image_size", "32", "--depth", "16", "--patch_size", "8", "--num_mask_blocks", "2", "--hidden_size", "128", "--num_hidden_layers", "2",
+              "--num_attention_heads", "2", "--pred_hidden_size", "64", "--pred_num_hidden_layers", "2", "--pred_num_attention_heads", "2",
+              "--per_device_train_batch_size", "2", "--report_to", "none", "--bf16", "true", "--learning_rate", "1e-3", "--logging_steps", "1",
+              "--max_grad_norm", "1.0", "--dataloader_num_workers", "0", "--save_strategy", "steps", "--save_steps", "2"]
+    a, b = tmp_path / "a", tmp_path / "b"
+    main(["--output_dir", str(a), "--max_steps", "4", *common])
+    os.makedirs(b)
+    shutil.copytree(a / "checkpoint-2", b / "checkpoint-2")
+    m = main(["--output_dir", str(b), "--max_steps", "4", "--do_eval", "true", "--per_device_eval_batch_size", "2", *common])
+    state = json.load(open(b / "trainer_state.json"))
+    assert state["global_step"] == 4
+    assert [h["step"] for h in state["log_history"] if "loss" in h][:4] == [1, 2, 3, 4]    # steps 1-2 restored from the checkpoint's history, 3-4 run here
+    assert 0 < m["eval_loss"] < 2.0
+
+
 TINY = dict(patch_size=8, crop_size=32, frames_per_clip=8, tubelet_size=2, in_chans=1, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
             mlp_ratio=4.0, pred_hidden_size=64, pred_num_hidden_layers=2, pred_num_attention_heads=2, pred_num_mask_tokens=10, pred_mlp_ratio=4.0)
 
@@ -407,3 +428,14 @@ def test_host_built_index_arrays_give_the_same_step():
               smbv_plumbing=wrong)
     b = model(pixel_values_videos=with_arrays["pixel_values_videos"], context_mask=with_arrays["context_mask"], target_mask=with_arrays["target_mask"])
     assert torch.equal(a.last_hidden_state, b.last_hidden_state) and torch.equal(a.predictor_output.last_hidden_state, b.predictor_output.last_hidden_state)
+    # arrays of the right shapes built from OTHER masks (a batch dict reused after its masks were changed): detected - compared on the device, read back
+    # without a per-step synchronisation, raised at the next forward or by check_plumbing()
+    model.check_plumbing()                                   # everything queued so far was consistent
+    cmask = with_arrays["context_mask"][0].clone()
+    tmask = with_arrays["target_mask"][0].clone()
+    cmask[:, 0], tmask[:, 0] = with_arrays["target_mask"][0][:, 0], with_arrays["context_mask"][0][:, 0]      # same counts, one token swapped between the sets
+    model(pixel_values_videos=with_arrays["pixel_values_videos"], context_mask=[cmask], target_mask=[tmask], smbv_needed="context",
+          smbv_plumbing=with_arrays["smbv_plumbing_context"])
+    with pytest.raises(ValueError, match="was not built from the context / target masks"):
+        model.check_plumbing()
+    model.check_plumbing()                                   # reported once
