@@ -126,11 +126,12 @@ void carve_bwd_scratch(Carver& cv, BwdScratch& sc, const BwdNeeds& n);  // every
 // launch reads must outlive the block: the bf16 residual gradients (in / mid) come from a ring of six buffers (block k: in = gb[2k], mid = gb[2k+1],
 // out = gb[2k+2], indices mod 6), d_act / d_qkv / the LayerNorm partials from rings of two; block k starts only after launch k-2 has finished
 // (event ring), which frees exactly the ring entries it overwrites.  Blocks the grouped launch cannot take (head-padded widths, widths that are not
-// multiples of 128, non-adjacent q/k/v gradients, a ranged block at B > 1, recompute - whose shared activation set the next block's forward
-// overwrites) run their products inline on the same side stream, as before; they use the same rings.
+// multiples of 128, non-adjacent q/k/v gradients, a ranged block at B > 1) run their products inline on the same side stream, as before; they use the
+// same rings.  Under recompute the blocks of a stack share one activation set: the step waits for a block's deferred launch before it re-runs the next
+// block's forward (mim_step.hip), so the launches - and the gradients, bit for bit - are the resident step's.
 struct WgradPipe {
   ForkJoin* fj = nullptr;        // null until begin(); stays null when the side stream is unavailable or switched off (variant bit 16384): all inline
-  bool allow_defer = true;       // false: every block inline (recompute)
+  bool allow_defer = true;       // false: every block inline
   int k = 0;                     // blocks issued through this pipe
   int waited = -1;               // the caller's stream has waited for deferred launches <= waited
   bool deferred[4] = {false, false, false, false};  // launch (k & 3) was deferred and its wdone event recorded

@@ -177,7 +177,8 @@ static int mim_backward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const 
   int ev = 0;
   WgradPipe& pipe = W.pipe;
   RC(pipe.begin());
-  pipe.allow_defer = !c.recompute;   // the blocks of a stack share ONE activation set under recompute: the next block's forward would overwrite what a deferred launch reads
+  // (recompute: the blocks of a stack share ONE activation set, which the next block's re-run forward overwrites - the deferred launch of a block is
+  // waited for in front of that forward, below; same launches, same arithmetic as the resident step: bit-identical gradients)
   auto next_event = [&]() -> hipEvent_t { return events ? (hipEvent_t)events[ev++] : (ev++, (hipEvent_t) nullptr); };
   auto mark = [&]() -> int { return pipe.mark_inline(next_event(), st); };   // a group whose gradients were produced on `st`
   const int K = c.ts * c.ps * c.ps;
@@ -203,7 +204,7 @@ static int mim_backward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const 
   for (int l = c.dlayers - 1; l >= 0; l--) {
     const bool last = l == c.dlayers - 1;  // its forward only produced the masked tokens (see mim_forward)
     // recompute: rebuild this block's activations from its saved input (the last block's are still in the shared set)
-    if (c.recompute && !last) RC(layer_fwd(to_block(p.dec[l]), W.dec[l], dd, W.sc, W.xd[l], W.xd[l + 1], nullptr, 0, 0, st));
+    if (c.recompute && !last) { RC(pipe.drain(st)); RC(layer_fwd(to_block(p.dec[l]), W.dec[l], dd, W.sc, W.xd[l], W.xd[l + 1], nullptr, 0, 0, st)); }
     RC(layer_bwd(to_block(p.dec[l]), to_block(gr.dec[l]), W.dec[l], dd, W.sc, W.xd[l], W.g0, W.g1, pipe, last ? c.Nmask : 0, last ? c.Nvis : 0, next_event(), st));
   }
   // decoder input: mask_token gradient = sum over masked rows; visible rows flow into encoder_to_decoder
@@ -218,7 +219,7 @@ static int mim_backward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const 
   RC(mark());
   for (int l = c.layers - 1; l >= 0; l--) {
     // recompute: the decoder ran after the encoder and does not touch the encoder's shared set, so the last encoder block's activations survive
-    if (c.recompute && l != c.layers - 1) RC(layer_fwd(to_block(p.enc[l]), W.enc[l], de, W.sc, W.x[l], W.x[l + 1], nullptr, 0, 0, st));
+    if (c.recompute && l != c.layers - 1) { RC(pipe.drain(st)); RC(layer_fwd(to_block(p.enc[l]), W.enc[l], de, W.sc, W.x[l], W.x[l + 1], nullptr, 0, 0, st)); }
     RC(layer_bwd(to_block(p.enc[l]), to_block(gr.enc[l]), W.enc[l], de, W.sc, W.x[l], W.g1, W.g0, pipe, 0, 0, next_event(), st));
   }
   // patch embedding (the volume needs no gradient)

@@ -211,7 +211,7 @@ def test_vjepa_vit_base_512x512x320_matches_oracle(qk_scale):
 
 def test_vit_large_512x512x320_fp8_attention_and_recompute_match_oracle_forward():
     """BASELINE.json config 5 at full size (one GPU; DP is the driver's): ViT-large (encoder 1024/24L/16H/4096, decoder 512/12L/8H/2048 as SURVEY.md 8d
-    assumes), 512x512x320, with the fp8 attention forward and per-layer recompute - loss and logits against the oracle's fp32 forward (~30 s of CPU),
+    assumes), 512x512x320, with the fp8 attention forward and per-layer recompute - loss, logits AND every gradient tensor against the oracle's fp32 step,
     next to the bf16 path on the same weights; the recompute step's backward must also reproduce the resident step's gradients bit for bit.
     Stated tolerances: bf16 loss 5e-3 / logits rms 1e-2; fp8 attention loss 1e-2 / logits rms 5e-2 (tests/test_fp8_gpu.py)."""
     from transformers import VideoMAEConfig
@@ -253,10 +253,15 @@ def test_vit_large_512x512x320_fp8_attention_and_recompute_match_oracle_forward(
     mo.SDPA = True
     try:
         torch.set_num_threads(max(1, min(64, len(__import__("os").sched_getaffinity(0)))))
-        with torch.no_grad():
-            ref_loss, ref_logits = mo.mim_forward(params, cfg, pix, mask)
+        # the oracle DIFFERENTIATED at this size too (ViT-large's 16 / 8 heads, K = 1024 / 4096 products, 24 + 12 blocks were only
+        # ever compared HIP against HIP): forward + backward of 64.4 TFLOP in fp32 on the host cores, about a minute and a half
+        ref_loss, ref_logits, ref_grads = mo.mim_step(params, cfg, pix, mask)
     finally:
         mo.SDPA = False
+    worst_bf, n_bf = _cmp_grads(gr_bf, ref_grads, 3e-2, 0.999, label="ViT-large bf16 vs oracle")                       # the ViT-base bounds
+    worst_f8, _ = _cmp_grads(gr_f8, ref_grads, 7e-2, 0.997, label="ViT-large fp8 attention + recompute vs oracle")     # + what e4m3 probabilities cost (tests/test_fp8_gpu.py)
+    assert n_bf >= 24 * 15 + 12 * 15 + 4, n_bf
+    print(f"ViT-large full size: gradients vs the fp32 oracle: bf16 worst {worst_bf}, fp8 attention + recompute worst {worst_f8}, {n_bf} tensors")
     rms = lambda a: float((a - ref_logits).pow(2).mean().sqrt() / ref_logits.pow(2).mean().sqrt())
     print(f"ViT-large full size: oracle loss {float(ref_loss):.6f}; bf16 {l_bf:.6f} (logits rms {rms(g_bf):.2e}); fp8 attention + recompute {l_f8:.6f} "
           f"(logits rms {rms(g_f8):.2e}); workspace {ws_bf / 2**30:.1f} GiB resident, {ws_rc / 2**30:.1f} GiB with recompute")
