@@ -46,20 +46,38 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// One pass over the brick (round 4): a thread keeps its float4s in registers between the mean and the variance sweep (K <= 4096 * RES / 4: the
+// path's 16^3 bricks fit RES = 4; larger bricks re-read the tail from L2 as before).  Two-pass arithmetic, unchanged results.
+template <int RES>
 __global__ __launch_bounds__(256) void brick_stats_kernel(const float* __restrict__ pix, const int* __restrict__ idx, int per_batch,
                                                           float* __restrict__ mean, float* __restrict__ rinv, BrickGeom g) {
   __shared__ float red[4];
   const int row = blockIdx.x;
   const int b = row / per_batch;
   const int tok = idx[row];
+  const int nf = g.K >> 2;
+  f32x4 keep[RES];
   float s = 0.f;
-  for (int f = threadIdx.x; f < (g.K >> 2); f += 256) {
+#pragma unroll
+  for (int i = 0; i < RES; i++) {
+    const int f = threadIdx.x + 256 * i;
+    keep[i] = f < nf ? *(const f32x4*)(pix + brick_elem_off(g, b, tok, 4 * f)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    s += (keep[i][0] + keep[i][1]) + (keep[i][2] + keep[i][3]);
+  }
+  for (int f = threadIdx.x + 256 * RES; f < nf; f += 256) {
     const f32x4 v = *(const f32x4*)(pix + brick_elem_off(g, b, tok, 4 * f));
     s += (v[0] + v[1]) + (v[2] + v[3]);
   }
   const float mu = block_sum_256(s, red) / g.K;
   float q = 0.f;
-  for (int f = threadIdx.x; f < (g.K >> 2); f += 256) {
+#pragma unroll
+  for (int i = 0; i < RES; i++) {
+    if (threadIdx.x + 256 * i < nf) {
+      const f32x4 v = keep[i] - mu;
+      q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+  }
+  for (int f = threadIdx.x + 256 * RES; f < nf; f += 256) {
     const f32x4 v = *(const f32x4*)(pix + brick_elem_off(g, b, tok, 4 * f)) - mu;
     q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
   }
@@ -137,7 +155,7 @@ int brick_stats(const float* pix, const int* idx, int rows, int per_batch, float
   int rc = make_geom(g, T, H, W, ts, ps, "brick_stats");
   if (rc) return rc;
   if (rows <= 0 || per_batch <= 0 || rows % per_batch) { set_error("brick_stats: rows=%d per_batch=%d", rows, per_batch); return SMBV_ERR_SHAPE; }
-  hipLaunchKernelGGL(brick_stats_kernel, dim3(rows), dim3(256), 0, st, pix, idx, per_batch, mean, rinv, g);
+  hipLaunchKernelGGL(brick_stats_kernel<4>, dim3(rows), dim3(256), 0, st, pix, idx, per_batch, mean, rinv, g);
   return check_launch("brick_stats");
 }
 

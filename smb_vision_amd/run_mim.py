@@ -137,7 +137,8 @@ def build_trainer(argv=None):
         model = SmbVideoMAEForPreTraining(config)
 
     # SmbTrainer == HF Trainer + RCCL gradient averaging (instead of accelerate's DDP wrap, acc_configs/multi_gpu_config.yaml) + the fused clip/AdamW tail
-    # eval_dataset / compute_metrics as src/run_mim.py:429-436 (the loss is the first "prediction"; only it leaves the device)
+    # eval_dataset / compute_metrics as src/run_mim.py:429-436 (HF reaches compute_metrics only when label ids exist - never for these models, in the
+    # reference either; eval_loss comes from SmbTrainer.prediction_step)
     return SmbTrainer(model=model, args=training_args, train_dataset=train, eval_dataset=val, data_collator=collate_fn, compute_metrics=loss_only_metrics,
                       preprocess_logits_for_metrics=keep_loss_only)
 

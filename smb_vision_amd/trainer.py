@@ -168,6 +168,22 @@ class SmbTrainer(Trainer):
             return self.optimizer
         return super().create_optimizer(model)
 
+    # -- evaluation -----------------------------------------------------------------------------------------------------------------------
+    def prediction_step(self, model, inputs, prediction_loss_only, ignore_keys=None):
+        """``trainer.evaluate()`` (src/run_mim.py:452-455).  The reference's models take no ``labels``: the stock step then calls ``model(**inputs)``, keeps every
+        output as a "prediction" (for one 512 x 512 x 320 volume: 109 MB of bf16 reconstruction copied to the host per sample) and reports NO loss - and its
+        ``compute_metrics`` (``:435``: the loss as first prediction) is never reached, because HF only calls it when label ids exist.  For the native models the
+        step returns the model's own loss and nothing else: ``eval_loss`` is then HF's mean over the evaluation batches."""
+        if not _is_native(model):
+            return super().prediction_step(model, inputs, prediction_loss_only, ignore_keys=ignore_keys)
+        inputs = self._prepare_inputs(inputs)
+        with torch.no_grad():
+            outputs = model(**inputs)
+        loss = getattr(outputs, "loss", None)
+        if loss is None:
+            return super().prediction_step(model, inputs, prediction_loss_only, ignore_keys=ignore_keys)
+        return (loss.detach().float(), None, None)
+
     def _native_optimizer(self):
         opt = self.optimizer
         opt = getattr(opt, "optimizer", opt)  # accelerate's AcceleratedOptimizer
