@@ -180,8 +180,9 @@ typedef struct smbv_mim_cfg {
   float ln_eps;                   /* config.layer_norm_eps (blocks) */
   float dec_norm_eps;             /* decoder.norm eps: torch default 1e-5 (spec :676) */
   int recompute;                  /* 1 = gradient checkpointing (spec :459-465, torch.utils.checkpoint per layer): keep only every block's input, share
-                                     one activation set per stack and re-run a block's forward in front of its backward.  Same results bit for bit,
-                                     one extra forward of time, ~1/layers of the activation memory */
+                                     two activation sets per stack (even / odd blocks: a block's deferred weight-gradient launch reads one while the next
+                                     block re-runs into the other) and re-run a block's forward in front of its backward.  Same results bit for bit,
+                                     one extra forward of time, ~2/layers of the activation memory */
   int attn_fp8;                   /* 1 = attention forward with OCP e4m3 operands on the block-scaled fp8 MFMA (BASELINE config 5); 0 = bf16 */
   int attn_o_resid;               /* 1 = every block's attention forward also saves the bf16 residual of its fp32 output, O_lo = bf16(O_fp32 - bf16(O_fp32)), and the
                                      backward forms delta = rowsum(dO * (O + O_lo)) (see smbv_attention_fwd).  One more [rows, width] bf16 activation per block;

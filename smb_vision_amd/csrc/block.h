@@ -127,8 +127,8 @@ void carve_bwd_scratch(Carver& cv, BwdScratch& sc, const BwdNeeds& n);  // every
 // out = gb[2k+2], indices mod 6), d_act / d_qkv / the LayerNorm partials from rings of two; block k starts only after launch k-2 has finished
 // (event ring), which frees exactly the ring entries it overwrites.  Blocks the grouped launch cannot take (head-padded widths, widths that are not
 // multiples of 128, non-adjacent q/k/v gradients, a ranged block at B > 1) run their products inline on the same side stream, as before; they use the
-// same rings.  Under recompute the blocks of a stack share one activation set: the step waits for a block's deferred launch before it re-runs the next
-// block's forward (mim_step.hip), so the launches - and the gradients, bit for bit - are the resident step's.
+// same rings.  Under recompute the blocks of a stack alternate between two activation sets and the step waits for launch k - 2 before it re-runs block
+// k's forward (mim_step.hip): the launches - and the gradients, bit for bit - are the resident step's.
 struct WgradPipe {
   ForkJoin* fj = nullptr;        // null until begin(); stays null when the side stream is unavailable or switched off (variant bit 16384): all inline
   bool allow_defer = true;       // false: every block inline
