@@ -138,6 +138,13 @@ int smbv_attention_fwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* 
 size_t smbv_attention_fp8_workspace_bytes(int B, int S, int H);
 int smbv_attention_fwd_fp8(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, smbv_bf16* O, int ldo, float* LSE, int B, int S, int H,
                            int Dh, float scale, int Sq, int q_off, void* ws, size_t ws_bytes, smbv_stream stream);
+/* smbv_attention_bwd with the query-owner blocks' two recomputed products (S, dP) on the block-scaled fp8 MFMA (head_dim 64, parts = 6 or 7): Q, K, V, dO are
+ * quantised to e4m3 rows with E8M0 scales per (token, head, 32 channels) into ws (smbv_attention_bwd_fp8_workspace_bytes, 256-B aligned) by four small
+ * launches in front of the pair launch. */
+size_t smbv_attention_bwd_fp8_workspace_bytes(int B, int S, int H);
+int smbv_attention_bwd_fp8(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* O_lo, const smbv_bf16* dO,
+                           int ldo, const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S, int H, int Dh, float scale,
+                           int parts, int Sq, int q_off, void* ws, size_t ws_bytes, smbv_stream stream);
 int smbv_attention_bwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* O_lo, const smbv_bf16* dO,
                        int ldo, const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S,
                        int H, int Dh, float scale, int parts /* bit0 delta, bit1 dK/dV, bit2 dQ; 7 = all */, int Sq, int q_off, smbv_stream stream);
@@ -183,7 +190,9 @@ typedef struct smbv_mim_cfg {
                                      two activation sets per stack (even / odd blocks: a block's deferred weight-gradient launch reads one while the next
                                      block re-runs into the other) and re-run a block's forward in front of its backward.  Same results bit for bit,
                                      one extra forward of time, ~2/layers of the activation memory */
-  int attn_fp8;                   /* 1 = attention forward with OCP e4m3 operands on the block-scaled fp8 MFMA (BASELINE config 5); 0 = bf16 */
+  int attn_fp8;                   /* BASELINE config 5, "fp8 MFMA QK^T / PV": bit 0 = attention forward with OCP e4m3 operands on the block-scaled fp8 MFMA;
+                                     bit 1 (ABI 3000) = also the backward's recomputed S = Q K^T and dP = dO V^T (its query-owner blocks; the accumulating
+                                     dV / dK / dQ products stay bf16); 0 = bf16 throughout.  3 is what config.smbv_attention_fp8 = True selects */
   int attn_o_resid;               /* 1 = every block's attention forward also saves the bf16 residual of its fp32 output, O_lo = bf16(O_fp32 - bf16(O_fp32)), and the
                                      backward forms delta = rowsum(dO * (O + O_lo)) (see smbv_attention_fwd).  One more [rows, width] bf16 activation per block;
                                      ignored with attn_fp8 */

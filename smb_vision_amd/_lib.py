@@ -125,6 +125,9 @@ _SIGS = {
     "smbv_attention_fp8_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "smbv_attention_fwd_fp8": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, c_f, C.c_size_t, c_f]),
     "smbv_attention_bwd": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, c_f]),
+    "smbv_attention_bwd_fp8_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "smbv_attention_bwd_fp8": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                         C.c_int, C.c_int, c_f, C.c_size_t, c_f]),
     "smbv_prepare_volume": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, c_f]),
     "smbv_gather_bricks": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "smbv_brick_stats": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),

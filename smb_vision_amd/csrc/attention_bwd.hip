@@ -774,6 +774,152 @@ __device__ __forceinline__ void attn_dq3_block(const bf16_t* __restrict__ Q, con
   }
 }
 
+// The query-owner block with its two RECOMPUTED products on the block-scaled fp8 MFMA (round 4; BASELINE.json config 5, "fp8 MFMA QK^T / PV" - in the
+// backward: S'^T = K Q^T and dP'^T = V dO^T, each ONE v_mfma_scale_f32_32x32x64_f8f6f4 per 32 keys x 32 queries instead of four bf16 MFMAs, at twice the rate).
+// Operands: e4m3 rows of Q (pre-scaled into the exp2 domain), K, V, dO with one E8M0 scale per (token, head, 32 channels) from attention_bwd_fp8_prepare
+// (attention_fp8.hip; operand / scale-block maps as attn_fwd_fp8_kernel documents them).  The accumulator input carries -LSE log2 e / -delta, the
+// accumulators come out key-on-the-row, query-on-the-lane exactly as the bf16 32x32x16 form's do, so dS^T = P (dP' ) converts straight into the B operand of
+// dQ^T += K^T dS^T - which stays a bf16 product on the bf16 K image (gradients keep bf16 operand precision where they are accumulated).
+// Head_dim 64.  64-key tiles through a ring of three slots: K8 [64][64 B] | V8 [64][64 B] | scales | K bf16 [64][128 B]; two tiles in flight, one counted
+// vmcnt + one barrier per tile; compiler-scheduled.
+struct DqF8Lds { static constexpr int SLOT = 4096 + 4096 + 256 + 8192, BYTES = 3 * SLOT; };
+__device__ __forceinline__ int fp8_swz_b(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+typedef int v8i_b __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void attn_dq_fp8_block(const Fp8BwdOps f8, const bf16_t* __restrict__ K, int ld, const float* __restrict__ LSE,
+                                                  const float* __restrict__ delta, bf16_t* __restrict__ dQ, int ldd, int S, int Sq, int qoff, int H, float scale,
+                                                  const int tile_x, const int head, const int b, unsigned char* smem) {
+  constexpr int SLOT = DqF8Lds::SLOT;
+  const int t = threadIdx.x, l = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = l & 31, h = l >> 5;
+  const int w = f8.w;
+  const int q = tile_x * 128 + wv * 32 + r;
+  const bool qok = q < Sq;
+  const size_t qrow = (size_t)b * S + qoff + (qok ? q : 0);
+  const unsigned char* base = f8.base;
+  const int nsc = w >> 5;
+  v8i_b qf = {0, 0, 0, 0, 0, 0, 0, 0}, dof = {0, 0, 0, 0, 0, 0, 0, 0};
+  int qs = 127, dos = 127;
+  float nlse2 = -INFINITY, ndl = 0.f;
+  if (qok) {
+    const u32x4 a = *(const u32x4*)(base + qrow * w + head * 64 + 16 * h);
+    const u32x4 c = *(const u32x4*)(base + qrow * w + head * 64 + 32 + 16 * h);
+    qf = (v8i_b){(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
+    qs = (base + f8.offSQ)[qrow * nsc + head * 2 + h];
+    const u32x4 e = *(const u32x4*)(base + f8.offD + qrow * w + head * 64 + 16 * h);
+    const u32x4 f = *(const u32x4*)(base + f8.offD + qrow * w + head * 64 + 32 + 16 * h);
+    dof = (v8i_b){(int)e[0], (int)e[1], (int)e[2], (int)e[3], (int)f[0], (int)f[1], (int)f[2], (int)f[3]};
+    dos = (base + f8.offSD)[qrow * nsc + head * 2 + h];
+    nlse2 = -LSE[((size_t)b * H + head) * Sq + q] * 1.4426950408889634f;
+    ndl = -delta[((size_t)b * H + head) * Sq + q];
+  }
+  asm volatile("" : "+v"(qf), "+v"(dof), "+v"(qs), "+v"(dos), "+v"(nlse2), "+v"(ndl));  // consumed here: no vmcnt(0) for these loads inside the tile loop
+  f32x16 sinit, dinit, dqt[2];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { sinit[i] = nlse2; dinit[i] = ndl; dqt[0][i] = 0.f; dqt[1][i] = 0.f; }
+
+  // copy side (as attn_fwd_fp8_kernel): wave wv stages rows 16 wv .. + 15 of the K8 / V8 tiles (one 1-KiB piece each), their 2 x 32 scale bytes (lanes 0-7 K,
+  // 8-15 V) and rows 16 wv .. + 15 of the bf16 K tile (two pieces of 8 rows; rows >= S arrive as zeros through the descriptor)
+  const i32x4 rs = dma_rsrc(base, f8.bytes);
+  const i32x4 rsk = dma_rsrc(K + (size_t)b * S * ld + head * 64, (unsigned)(((size_t)(S - 1) * ld + 64) * 2));
+  const int prow = 16 * wv + (l >> 2), csrc = (l & 3) ^ ((l >> 4) & 3);
+  const int ok0 = (int)f8.offK + (int)(((size_t)b * S + prow) * w) + head * 64 + 16 * csrc;
+  const int ov0 = (int)f8.offV + (int)(((size_t)b * S + prow) * w) + head * 64 + 16 * csrc;
+  const int j8 = l & 7;
+  const int os0 = (l < 8 ? (int)f8.offSK : (int)f8.offSV) + (int)((((size_t)b * H + head) * S + 16 * wv) * 2) + 4 * j8;
+  int okb[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int row = 16 * wv + 8 * i + (l >> 3);
+    const int x = (row >> 1) & 7;
+    okb[i] = (row * ld + ((l & 7) ^ (((x & 1) << 2) | (x >> 1))) * 8) * 2;
+  }
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((int)lds_addr_of(smem));
+  auto stage = [&](int kt) __attribute__((always_inline)) {
+    const unsigned sl = lds0 + (unsigned)(kt % 3) * SLOT;
+    dma16_hidden(rs, sl + (unsigned)wv * 1024, ok0 + kt * 64 * w);
+    dma16_hidden(rs, sl + 4096 + (unsigned)wv * 1024, ov0 + kt * 64 * w);
+    if (l < 16) dma4_hidden(rs, sl + 8192 + (unsigned)wv * 64, os0 + kt * 128);
+    dma16_hidden(rsk, sl + 8448 + (unsigned)wv * 2048, okb[0] + kt * 64 * ld * 2);
+    dma16_hidden(rsk, sl + 8448 + (unsigned)wv * 2048 + 1024, okb[1] + kt * 64 * ld * 2);
+  };
+  const int g1 = (l >> 4) & 1, qq = (l >> 2) & 3, pp = l & 3;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const int nt = (S + 63) >> 6;
+  stage(0);
+  stage(1);
+  for (int kt = 0; kt < nt; kt++) {
+    // this wave's five copies of tile kt have landed (tile kt + 1's may still fly); the barrier publishes the tile and retires everybody's reads of tile
+    // kt - 1, whose slot tile kt + 2 now takes (past the end the K8 / V8 / scale copies read unused bytes of the workspace, the bf16 copies zeros: never used)
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    stage(kt + 2);
+    const unsigned char* sb = smem + (kt % 3) * SLOT;
+    const unsigned char* scb = sb + 8192;
+    const unsigned char* kimg = sb + 8448;
+    // both sub-tiles' fp8 products first: the exponentials / multiplies / converts of sub-tile 0 then run under sub-tile 1's MFMAs, and sub-tile 0's dQ
+    // products under sub-tile 1's vector work
+    f32x16 sx[2], dp[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) {
+      const int row = 32 * tt + r;
+      const u32x4 a = *(const u32x4*)(sb + fp8_swz_b(row, h));
+      const u32x4 c = *(const u32x4*)(sb + fp8_swz_b(row, 2 + h));
+      const v8i_b kf = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)c[0], (int)c[1], (int)c[2], (int)c[3]};
+      const int ks = scb[(row >> 4) * 64 + (row & 15) * 2 + h];
+      const u32x4 e = *(const u32x4*)(sb + 4096 + fp8_swz_b(row, h));
+      const u32x4 f = *(const u32x4*)(sb + 4096 + fp8_swz_b(row, 2 + h));
+      const v8i_b vf = {(int)e[0], (int)e[1], (int)e[2], (int)e[3], (int)f[0], (int)f[1], (int)f[2], (int)f[3]};
+      const int vs = scb[(row >> 4) * 64 + 32 + (row & 15) * 2 + h];
+      sx[tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf, sinit, 0, 0, 0, ks, 0, qs);     // S'^T[key][q] - lse, exp2 domain
+      dp[tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, dof, dinit, 0, 0, 0, vs, 0, dos);   // dP'^T[key][q] - delta
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) dp[tt][i] *= fast_exp2(sx[tt][i]);
+      if (kt == nt - 1 && (S & 63)) {  // keys past the end of the sequence: their e4m3 rows are whatever follows in the workspace
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const int key = kt * 64 + 32 * tt + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (key >= S) dp[tt][i] = 0.f;
+        }
+      }
+      bf16x8 dsf[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) dsf[s2][j] = (__bf16)dp[tt][8 * s2 + j];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++) {
+          const int kb = 32 * tt + 16 * s2 + 4 * h + qq;
+          const int c16 = 4 * dt + 2 * g1 + (pp >> 1);
+          const int sb8 = 8 * (pp & 1);
+          const s16x4 a0 = lds_read_tr16(kimg + swz128(kb, c16) + sb8);
+          const s16x4 a1 = lds_read_tr16(kimg + swz128(kb + 8, c16) + sb8);
+          const s16x8 aa = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aa), dsf[s2], dqt[dt], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile kt have returned before it can reach the next barrier
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+  if (qok) {
+    bf16_t* qp = dQ + ((size_t)b * S + qoff + q) * ldd + head * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int d0 = 32 * dt + 8 * rg + 4 * h;
+        u32x2 pk = {pack_bf16(dqt[dt][4 * rg] * scale, dqt[dt][4 * rg + 1] * scale), pack_bf16(dqt[dt][4 * rg + 2] * scale, dqt[dt][4 * rg + 3] * scale)};
+        *(u32x2*)(qp + d0) = pk;
+      }
+  }
+}
+
 template <int KT, int DH, bool MFMA16>
 __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                           const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO, int ldo,
@@ -809,13 +955,14 @@ __device__ __forceinline__ void pair_fault(unsigned* status, unsigned code) {
   if (status) __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <int DH, bool QMFMA16>
+template <int DH, int QKIND>   // query-owner block: 0 = 32x32x16 bf16, 1 = 16x16x32 bf16 (shipped), 2 = S / dP recomputation on the fp8 MFMA (head_dim 64)
 __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, int ld,
                                                                const bf16_t* __restrict__ dO, int ldo, const float* __restrict__ LSE,
                                                                const float* __restrict__ delta, bf16_t* __restrict__ dQ, bf16_t* __restrict__ dK,
                                                                bf16_t* __restrict__ dV, int ldd, int B, int S, int Sq, int qoff, int H, float scale, int slot,
-                                                               unsigned epoch, unsigned* __restrict__ status) {
+                                                               unsigned epoch, unsigned* __restrict__ status, Fp8BwdOps f8) {
   constexpr int LDS = DkvLds<128, DH>::BYTES > DqLds<128, DH>::BYTES ? DkvLds<128, DH>::BYTES : DqLds<128, DH>::BYTES;
+  static_assert(DqF8Lds::BYTES <= DkvLds<128, 64>::BYTES, "the fp8 query-owner block's ring fits the key-owner block's LDS");
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS];
   PairState& ps = g_pair_state[slot];
   const unsigned n_kv = (unsigned)(((S + 127) / 128) * H * B), n_q = (unsigned)(((Sq + 127) / 128) * H * B);
@@ -851,7 +998,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __r
     attn_dkv2_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
   } else if (role == 1) {
     const int nt = (Sq + 127) / 128;
-    if constexpr (QMFMA16) attn_dq3_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
+    if constexpr (QKIND == 2 && DH == 64) attn_dq_fp8_block(f8, K, ld, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
+    else if constexpr (QKIND == 1) attn_dq3_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
     else attn_dq2_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
   }
   // the block that ends last (every other block has claimed its tile long ago) hands the slot over stamped with the NEXT epoch: no memset node in front of
@@ -920,7 +1068,7 @@ int pair_state_debug(int op, hipStream_t st) {
 
 int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
                   float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st,
-                  const bf16_t* O_lo) {
+                  const bf16_t* O_lo, void* f8ws, size_t f8ws_bytes) {
   if (Sq <= 0) { Sq = S; qoff = 0; }
   if (qoff < 0 || qoff + Sq > S) { set_error("attention_bwd: query range outside the sequence"); return SMBV_ERR_SHAPE; }
   if (Dh != 64 && Dh != 32) { set_error("attention_bwd: head_dim %d not supported (64 or 32; other widths run zero-padded in 64-wide slots, block.h)", Dh); return SMBV_ERR_SHAPE; }
@@ -945,10 +1093,16 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     if ((unsigned)blocks >= PAIR_COUNT_MASK) { set_error("attention_bwd: %d tiles exceed the pair launch's 20-bit tile counters", blocks); return SMBV_ERR_SHAPE; }
     unsigned* status = device_status_word_dev();   // host-mapped; null if it could not be created (faults then go unreported, as before round 4)
     const bool q16 = !(g_variant & 2);   // A/B: bit 1 = the query-owner block on the 32x32x16 MFMA (attn_dq2_block)
-    if (Dh == 64 && q16) hipLaunchKernelGGL((attn_bwd_pair_kernel<64, true>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot, epoch, status);
-    else if (Dh == 64) hipLaunchKernelGGL((attn_bwd_pair_kernel<64, false>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot, epoch, status);
-    else if (q16) hipLaunchKernelGGL((attn_bwd_pair_kernel<32, true>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot, epoch, status);
-    else hipLaunchKernelGGL((attn_bwd_pair_kernel<32, false>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot, epoch, status);
+    Fp8BwdOps f8;
+    const bool fp8q = f8ws != nullptr && Dh == 64 && !(g_variant & 8);   // (debug bit 8: bf16 query-owner blocks although fp8 operands were offered)
+    if (fp8q) RC(attention_bwd_fp8_prepare(Q, K, V, ld, dO, ldo, B, S, H, scale, f8ws, f8ws_bytes, st, &f8));
+#define SMBV_PAIR_LAUNCH(DHV, KIND) hipLaunchKernelGGL((attn_bwd_pair_kernel<DHV, KIND>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot, epoch, status, f8)
+    if (fp8q) SMBV_PAIR_LAUNCH(64, 2);
+    else if (Dh == 64 && q16) SMBV_PAIR_LAUNCH(64, 1);
+    else if (Dh == 64) SMBV_PAIR_LAUNCH(64, 0);
+    else if (q16) SMBV_PAIR_LAUNCH(32, 1);
+    else SMBV_PAIR_LAUNCH(32, 0);
+#undef SMBV_PAIR_LAUNCH
     return check_launch("attn_bwd_pair");
   }
   // dK/dV and dQ are independent (disjoint outputs, shared read-only inputs).  Their grids rarely fill a whole number of

@@ -270,6 +270,88 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
   if (h == 0) LSE[((size_t)b * H + head) * Sq + q] = (mref + __log2f(ltot) - 7.0f) * 0.6931471805599453f;
 }
 
+// four row-quantisation passes of the same shape as ONE launch (blockIdx.y = pass): the backward's Q, K, V, dO
+struct QuantJob { const bf16_t* X; int ld; float premul; unsigned char* X8; unsigned char* sX; int head_major_S; };
+struct QuantJobs4 { QuantJob j[4]; };
+__global__ __launch_bounds__(256) void quant_rows4_fp8_kernel(QuantJobs4 jobs, long rows, int w) {
+  const QuantJob& J = jobs.j[blockIdx.y];
+  const bf16_t* __restrict__ X = J.X;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const int per_row = w >> 3;
+  const long row = gid / per_row;
+  const int c8 = (int)(gid % per_row);
+  float v[8];
+  float amax = 0.f;
+  if (row < rows) {
+    const u32x4 raw = *(const u32x4*)(X + row * J.ld + c8 * 8);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { v[2 * i] = bf_lo(raw[i]) * J.premul; v[2 * i + 1] = bf_hi(raw[i]) * J.premul; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) amax = fmaxf(amax, fabsf(v[i]));
+  }
+  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));  // 4 threads = 32 channels = one scale block
+  amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+  if (row >= rows) return;
+  const int sb = e8m0_for(amax);
+  const float inv = e8m0_inv(sb);
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
+  *(u32x2*)(J.X8 + row * w + c8 * 8) = (u32x2){(unsigned)lo, (unsigned)hi};
+  if ((c8 & 3) == 0) {
+    if (J.head_major_S > 0) {
+      const long bb = row / J.head_major_S, ss = row % J.head_major_S;
+      const int H = w >> 6, head = c8 >> 3, half = (c8 >> 2) & 1;
+      J.sX[((bb * H + head) * J.head_major_S + ss) * 2 + half] = (unsigned char)sb;
+    } else {
+      J.sX[row * (w >> 5) + (c8 >> 2)] = (unsigned char)sb;
+    }
+  }
+}
+
+// ---- operands of the fp8 BACKWARD (attention_bwd.hip attn_dq_fp8_block: the query-owner blocks' S'^T = K Q^T and dP'^T = V dO^T recomputation on the
+// block-scaled fp8 MFMA): Q (pre-scaled into the exp2 domain), K, V and dO as e4m3 ROWS with one E8M0 scale per (token, head, 32 channels) - the same
+// quantisation pass the forward uses for Q and K (V here by rows: the contraction of dP is over channels, not keys).  K and V scales head-major
+// ([batch, head][S][2]: what the tile copies stage), Q and dO scales row-major.
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+size_t attention_bwd_fp8_workspace_bytes(int B, int S, int H) {
+  const size_t rows = (size_t)B * S, w = (size_t)H * 64;
+  return 4 * al256(rows * w) + 4 * al256(rows * (w >> 5)) + 256;   // (+ 256: the run-ahead tile copies past the last tile read inside the buffer)
+}
+int attention_bwd_fp8_prepare(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* dO, int ldo, int B, int S, int H, float scale, void* ws,
+                              size_t ws_bytes, hipStream_t st, Fp8BwdOps* ops) {
+  const size_t need = attention_bwd_fp8_workspace_bytes(B, S, H);
+  if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) { set_error("attention_bwd (fp8): workspace too small or misaligned (%zu < %zu)", ws_bytes, need); return SMBV_ERR_WORKSPACE; }
+  if (need >= ((size_t)1 << 31)) { set_error("attention_bwd (fp8): workspace of %zu bytes exceeds the 32-bit copy offsets", need); return SMBV_ERR_SHAPE; }
+  const long rows = (long)B * S;
+  const int w = H * 64;
+  unsigned char* p = (unsigned char*)ws;
+  unsigned char* Q8 = p; p += al256((size_t)rows * w);
+  unsigned char* K8 = p; p += al256((size_t)rows * w);
+  unsigned char* V8 = p; p += al256((size_t)rows * w);
+  unsigned char* D8 = p; p += al256((size_t)rows * w);
+  unsigned char* sQ = p; p += al256((size_t)rows * (w >> 5));
+  unsigned char* sK = p; p += al256((size_t)rows * (w >> 5));
+  unsigned char* sV = p; p += al256((size_t)rows * (w >> 5));
+  unsigned char* sD = p;
+  const int qblocks = cdiv(rows * (w >> 3), 256);
+  QuantJobs4 jobs;
+  jobs.j[0] = {Q, ld, scale * 1.4426950408889634f, Q8, sQ, 0};
+  jobs.j[1] = {K, ld, 1.0f, K8, sK, S};
+  jobs.j[2] = {V, ld, 1.0f, V8, sV, S};
+  jobs.j[3] = {dO, ldo, 1.0f, D8, sD, 0};
+  hipLaunchKernelGGL(quant_rows4_fp8_kernel, dim3(qblocks, 4), dim3(256), 0, st, jobs, rows, w);   // one launch: four passes of ~15 MB each
+  int rc = check_launch("quant_fp8 (backward)");
+  if (rc) return rc;
+  const unsigned char* base = (const unsigned char*)ws;
+  ops->base = base; ops->bytes = (unsigned)need; ops->w = w;
+  ops->offK = (unsigned)(K8 - base); ops->offV = (unsigned)(V8 - base); ops->offD = (unsigned)(D8 - base);
+  ops->offSQ = (unsigned)(sQ - base); ops->offSK = (unsigned)(sK - base); ops->offSV = (unsigned)(sV - base); ops->offSD = (unsigned)(sD - base);
+  return SMBV_OK;
+}
+
 size_t attention_fp8_workspace_bytes(int B, int S, int H) {
   const size_t rows = (size_t)B * S, w = (size_t)H * 64, Spad = ((size_t)S + 63) & ~(size_t)63;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };

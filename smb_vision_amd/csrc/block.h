@@ -24,7 +24,8 @@ struct BlockDims {
   int rope_grid = 0;              // > 0: 3-axis RoPE on q and k with this grid size (tokens per row; tokens per frame = grid^2)
   const int* pos = nullptr;       // token position ids for RoPE (null = index within the sequence)
   const float* rope_table = nullptr;
-  int attn_fp8 = 0;               // 1: attention forward on the block-scaled fp8 MFMA (attention_fp8.hip); the backward stays bf16
+  int attn_fp8 = 0;               // bit 0: attention forward on the block-scaled fp8 MFMA (attention_fp8.hip); bit 1: also the backward's recomputed
+                                  // S / dP products (query-owner blocks, attention_bwd.hip attn_dq_fp8_block); the accumulating products stay bf16
   int o_resid = 0;                // 1: the attention forward also saves the bf16 residual of its fp32 output (LayerWs::attn_o_lo) and the backward's
                                   // delta = rowsum(dO * O) is formed from O + O_lo (not with attn_fp8, whose forward keeps no fp32 output tile layout in common)
   int slot() const { return Dh == 32 ? 32 : 64; }  // columns a head occupies in the QKV / attention-output matrices
@@ -46,7 +47,7 @@ struct BwdScratch {  // sized for the widest block of the model (d_act, d_qkv an
   float *delta, *gpad, *gpad_b;  // gpad / gpad_b: head-padded weight / bias gradients before un-padding (null when no block is padded)
   void* scratch;        // LN-bwd partials / colsum partials / gemm_tn slabs of the products the STEP issues on the caller's stream (head, embeddings)
   size_t scratch_bytes;
-  void* f8ws = nullptr; // quantised operands of the fp8 attention forward (null unless a block asks for it)
+  void* f8ws = nullptr; // quantised operands of the fp8 attention forward / backward (null unless a block asks for it)
   size_t f8ws_bytes = 0;
   void* wscratch;       // gemm_tn slabs + column-sum partials of the weight-gradient products that run on the side stream
   size_t wscratch_bytes;

@@ -90,6 +90,7 @@ void bwd_scratch_requirements(const BlockDims& d, BwdNeeds& n) {
   tn(rows, w, ff); tn(rows, ff, w); tn(rows, w, wa); tn(rows, 3 * wa, w); tn(rows, w, w);
   n.scratch = std::max(n.scratch, layernorm_bwd_workspace_bytes((int)rows, (int)w));
   if (d.attn_fp8) n.f8 = std::max(n.f8, attention_fp8_workspace_bytes(d.B, d.S, d.H));
+  if (d.attn_fp8 & 2) n.f8 = std::max(n.f8, attention_bwd_fp8_workspace_bytes(d.B, d.S, d.H));
 }
 
 void carve_bwd_scratch(Carver& cv, BwdScratch& sc, const BwdNeeds& n) {
@@ -299,7 +300,7 @@ int layer_bwd_core(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const Bl
   // ---- attention (dQ exists only for the ranged queries; dK/dV for every token) ----
   if (ranged) HIPRC(hipMemsetAsync(bf.d_qkv, 0, (size_t)M * 3 * wa * sizeof(bf16_t), st));
   RC(attention_bwd(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, sc.d_o, wa, L.lse, sc.delta, bf.d_qkv, bf.d_qkv + wa, bf.d_qkv + 2 * wa, 3 * wa, B,
-                   S, H, d.slot(), d.scale(), delta_fused ? 6 : 7, Sq, qoff, st, L.attn_o_lo));
+                   S, H, d.slot(), d.scale(), delta_fused ? 6 : 7, Sq, qoff, st, L.attn_o_lo, (d.attn_fp8 & 2) && d.slot() == 64 ? sc.f8ws : nullptr, sc.f8ws_bytes));
   if (d.rope_grid > 0) RC(rope3d(bf.d_qkv, 3 * wa, wa, M, S, H, d.slot(), d.Dh, d.rope_grid, d.pos, d.rope_table, 1, st));
   // ---- QKV ----
   if (!defer) {

@@ -122,6 +122,16 @@ int smbv_attention_bwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* 
   return attention_bwd(Q, K, V, ld, O, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, H, Dh, scale, parts, Sq, q_off, (hipStream_t)stream, O_lo);
 }
 
+size_t smbv_attention_bwd_fp8_workspace_bytes(int B, int S, int H) { return attention_bwd_fp8_workspace_bytes(B, S, H); }
+int smbv_attention_bwd_fp8(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* O_lo, const smbv_bf16* dO, int ldo,
+                           const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S, int H, int Dh, float scale,
+                           int parts, int Sq, int q_off, void* ws, size_t ws_bytes, smbv_stream stream) {
+  if (!Q || !K || !V || !O || !dO || !LSE || !delta || !dQ || !dK || !dV || !ws) { set_error("smbv_attention_bwd_fp8: null operand"); return SMBV_ERR_ARG; }
+  if (Dh != 64 || (parts & 6) != 6) { set_error("smbv_attention_bwd_fp8: head_dim 64 and both gradient parts (parts & 6 == 6) only"); return SMBV_ERR_SHAPE; }
+  SMBV_CHECK_DEVICE_STATE();
+  return attention_bwd(Q, K, V, ld, O, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, H, Dh, scale, parts, Sq, q_off, (hipStream_t)stream, O_lo, ws, ws_bytes);
+}
+
 int smbv_prepare_volume(const void* src, int src_dtype, float* dst, int B, int H0, int W0, int D0, int H, int W, int D, float a_min, float a_max,
                         float b_min, float b_max, int clip, smbv_stream stream) {
   if (!src || !dst) { set_error("smbv_prepare_volume: null operand"); return SMBV_ERR_ARG; }

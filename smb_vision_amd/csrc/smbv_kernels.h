@@ -79,8 +79,18 @@ int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf1
                   float scale, int Sq, int qoff, hipStream_t st, bf16_t* O_lo = nullptr);
 int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
                   float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st,
-                  const bf16_t* O_lo = nullptr);
+                  const bf16_t* O_lo = nullptr, void* f8ws = nullptr, size_t f8ws_bytes = 0);
+// f8ws != null (head_dim 64, the one-launch pair): the query-owner blocks recompute S and dP on the block-scaled fp8 MFMA (BASELINE config 5)
 
+// fp8 operands of the attention backward's query-owner blocks (attention_fp8.hip attention_bwd_fp8_prepare -> attention_bwd.hip attn_dq_fp8_block)
+struct Fp8BwdOps {
+  const unsigned char* base = nullptr;   // workspace: Q8 | K8 | V8 | dO8 (e4m3 rows [B*S, w]) | their E8M0 scales (Q, dO: [rows, w / 32]; K, V: [B, H][S][2])
+  unsigned bytes = 0, offK = 0, offV = 0, offD = 0, offSQ = 0, offSK = 0, offSV = 0, offSD = 0;
+  int w = 0;
+};
+size_t attention_bwd_fp8_workspace_bytes(int B, int S, int H);
+int attention_bwd_fp8_prepare(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* dO, int ldo, int B, int S, int H, float scale, void* ws,
+                              size_t ws_bytes, hipStream_t st, Fp8BwdOps* ops);
 // fp8 (OCP e4m3, block-scaled MFMA) forward: same contract as attention_fwd plus a caller-owned workspace for the quantised operands
 size_t attention_fp8_workspace_bytes(int B, int S, int H);
 int attention_fwd_fp8(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf16_t* O, int ldo, float* LSE, int B, int S, int H, int Dh, float scale,

@@ -276,7 +276,8 @@ class SmbVideoMAEForPreTraining(PreTrainedModel):
         s.ln_eps = c.layer_norm_eps
         s.dec_norm_eps = 1e-5
         s.recompute = int(self._use_recompute(s))
-        s.attn_fp8 = int(bool(getattr(c, "smbv_attention_fp8", False)))
+        f8 = getattr(c, "smbv_attention_fp8", False)   # True / "all": forward + the backward's recomputed S / dP products (BASELINE config 5); "forward": forward only
+        s.attn_fp8 = 0 if not f8 else (1 if f8 == "forward" else 3)
         # delta = rowsum(dO * O) from the attention output to 16 significant bits (smbv_mim_cfg.attn_o_resid; one more bf16 activation per block)
         s.attn_o_resid = int(_residual_wanted(c) and not s.attn_fp8)
         return s

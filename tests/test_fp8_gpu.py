@@ -67,8 +67,46 @@ def test_attention_fwd_fp8_matches_fp32_within_the_stated_tolerance(B, S, H, Sq,
     assert rms8 <= 3.5e-2, rms8
 
 
-def test_mim_step_with_fp8_attention_and_recompute():
-    """config.smbv_attention_fp8 = True (+ per-layer recompute): the whole step against the fp32 oracle, tolerances in the module docstring."""
+@pytest.mark.parametrize("B,S,H,Sq,qoff,amp", [(1, 256, 2, 0, 0, 1.0), (2, 1000, 3, 0, 0, 1.0), (1, 2048, 4, 700, 1348, 1.0), (1, 200, 1, 0, 0, 1.5), (1, 4096, 2, 0, 0, 0.3)])
+def test_attention_bwd_fp8_recompute_products(B, S, H, Sq, qoff, amp):
+    """Round 4 (BASELINE config 5, VERDICT r3 missing 1): the attention backward's RECOMPUTED products - S = Q K^T and dP = dO V^T in its query-owner blocks -
+    on the block-scaled fp8 MFMA; the accumulating products (dV, dK in the key-owner blocks, dQ) keep bf16 operands.  So dK and dV are the bf16 path's bit
+    for bit, and dQ carries the e4m3 rounding of Q, K (in P) and of V, dO (in dP).  Stated bound for dQ against the exact fp32 gradient: rms 1.2e-1 at
+    unit-variance operands (measured below; the bf16 path: ~1e-2), 2.5e-1 for the peaky 1.5x case; amp 0.3 = the near-uniform regime the model starts in."""
+    from smb_vision_amd import ops
+    w = H * 64
+    g = torch.Generator().manual_seed(S + 7 * H)
+    qkv = (torch.randn(B * S, 3 * w, generator=g) * amp).bfloat16().cuda()
+    O, lse = ops.attention_fwd(qkv, B, S, H, Sq=Sq, q_off=qoff)
+    n = Sq if Sq else S
+    dO = torch.zeros(B, S, w)
+    dO[:, qoff:qoff + n] = torch.randn(B, n, w, generator=g)
+    dO = dO.bfloat16().view(B * S, w).cuda()
+    d_bf, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff)
+    d_f8, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, fp8=True)
+    d_f8b, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, fp8=True)
+    assert torch.equal(d_f8, d_f8b)                                            # run-to-run identical
+    assert torch.equal(d_f8[:, w:], d_bf[:, w:])                               # dK, dV: the key-owner blocks are the bf16 ones
+    qf = qkv.float().requires_grad_(True)
+    f = qf.view(B, S, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = torch.matmul(f[0][:, :, qoff:qoff + n], f[1].transpose(-1, -2)) * 0.125
+    ref = torch.matmul(torch.softmax(s, -1), f[2]).transpose(1, 2).reshape(B, n, w)
+    ref.backward(dO.float().view(B, S, w)[:, qoff:qoff + n])
+    exact = qf.grad[:, :w]
+    rms = lambda a: float((a.float() - exact).pow(2).mean().sqrt() / exact.pow(2).mean().sqrt())
+    r8, rb = rms(d_f8[:, :w]), rms(d_bf[:, :w])
+    print(f"fp8 backward S={S} H={H} amp={amp}: dQ rms vs exact fp32: fp8 recompute {r8:.2e}, bf16 {rb:.2e}")
+    assert torch.isfinite(d_f8.float()).all()
+    assert r8 <= (2.5e-1 if amp > 1 else 1.2e-1), (r8, rb)
+    outside = torch.ones(S, dtype=torch.bool); outside[qoff:qoff + n] = False
+    if outside.any():
+        assert float(d_f8.float().view(B, S, 3 * w)[:, outside.cuda(), :w].abs().max()) == 0.0   # no dQ outside the query range
+
+
+@pytest.mark.parametrize("mode", [True, "forward"])
+def test_mim_step_with_fp8_attention_and_recompute(mode):
+    """config.smbv_attention_fp8 = True (forward + the backward's recomputed products; "forward": round 3's forward-only form) + per-layer recompute: the
+    whole step against the fp32 oracle, tolerances in the module docstring."""
     from transformers import VideoMAEConfig
     from oracle.mim_oracle import MIMConfig, init_params, mim_step
     from smb_vision_amd.masking import MaskGenerator
@@ -82,10 +120,11 @@ def test_mim_step_with_fp8_attention_and_recompute():
     mask = torch.stack([gen(), gen()])
     pix = torch.rand(2, 64, 1, 128, 128, generator=torch.Generator().manual_seed(5))
     ref_loss, ref_logits, ref_grads = mim_step(params, cfg, pix, mask)
-    model = SmbVideoMAEForPreTraining(VideoMAEConfig(num_channels=1, smbv_attention_fp8=True, smbv_recompute="always", **c))
+    model = SmbVideoMAEForPreTraining(VideoMAEConfig(num_channels=1, smbv_attention_fp8=mode, smbv_recompute="always", **c))
     model.load_state_dict(params)
     model = model.cuda().train()
     model.gradient_checkpointing_enable()
+    assert model._cfg_struct(2, int(mask[0].sum())).attn_fp8 == (3 if mode is True else 1)
     out = model(pixel_values=pix.cuda(), bool_masked_pos=mask.cuda())
     out.loss.backward()
     torch.cuda.synchronize()
@@ -103,4 +142,4 @@ def test_mim_step_with_fp8_attention_and_recompute():
         cos = float((g * r).sum() / (g.norm() * r.norm()))
         worst = max(worst, (k, e), key=lambda t: t[1])
         assert e <= 1.5e-1 and cos >= 0.99, (k, e, cos)
-    print("fp8 MIM step: loss", float(out.loss), "oracle", float(ref_loss), "worst grad", worst)
+    print(f"fp8 MIM step ({mode}): loss", float(out.loss), "oracle", float(ref_loss), "worst grad", worst)
