@@ -18,9 +18,9 @@
  *     points fork onto the per-device side streams below and are NOT safe to run from two host threads on the SAME device at once (the library
  *     serialises the fork / join bookkeeping with a per-device mutex; the side streams themselves are shared);
  *   - state inside the library: the immutable code object; a thread-local error string; per device, two private non-blocking side streams and a
- *     few events created on first use and kept for the life of the process (the block backward runs its weight-gradient products beside the
- *     input-gradient ones, the step forwards their weight casts beside the first kernels; everything forked is joined back into `stream` before the
- *     call returns); a 64-KiB `__device__` array of scheduling words for the attention backward (block roles and tile queues of
+ *     dozen events created on first use and kept for the life of the process (a block's weight-gradient products run as one grouped launch on a side
+ *     stream beside the NEXT block's backward, the step forwards their weight casts beside the first kernels; everything forked is joined back into
+ *     `stream` before the call returns); a 64-KiB `__device__` array of scheduling words for the attention backward (block roles and tile queues of
  *     attn_bwd_pair_kernel - never results): eight slots, each OWNED by one stream of the device (the first eight streams that run an attention
  *     backward; a ninth takes a two-launch path with no shared state), every word stamped with its launch's epoch, so launches that share a slot
  *     are always ordered by one stream and a word of another launch is detected, not consumed; 4 bytes of host-mapped status per device
@@ -237,7 +237,9 @@ size_t smbv_mim_workspace_bytes(const smbv_mim_cfg* cfg);
 int smbv_mim_forward(const smbv_mim_cfg* cfg, const smbv_mim_tensors* params, const smbv_mim_io* io, void* ws, size_t ws_bytes,
                      smbv_stream stream);
 /* Gradients of loss*grad_scale w.r.t. every tensor in `grads` (overwritten, not accumulated).  `events`/`n_events`:
- * optional hipEvent_t array recorded on `stream` as gradient groups complete, in this order:
+ * optional hipEvent_t array recorded as gradient groups complete - a block's event on the library's side stream, behind the block's deferred
+ * weight-gradient launch; the step's own groups on `stream`, or through the side stream while launches are pending there: the events COMPLETE in array
+ * order, so a consumer may gate a range of groups on the last one's event - in this order:
  *   [0] head+decoder.norm, [1..dlayers] decoder layers (last first), [dlayers+1] mask_token+encoder_to_decoder,
  *   [..+layers] encoder layers (last first), [last] patch embedding  — used to launch RCCL all-reduces on a side stream. */
 int smbv_mim_backward(const smbv_mim_cfg* cfg, const smbv_mim_tensors* params, const smbv_mim_tensors* grads, const smbv_mim_io* io,
@@ -390,7 +392,7 @@ typedef struct smbv_vjepa_io {
 size_t smbv_vjepa_workspace_bytes(const smbv_vjepa_cfg* cfg);
 int smbv_vjepa_forward(const smbv_vjepa_cfg* cfg, const smbv_vjepa_tensors* params, const smbv_vjepa_io* io, void* ws, size_t ws_bytes,
                        smbv_stream stream);
-/* events / n_events: optional hipEvent_t array recorded on `stream` as gradient groups complete (for the data-parallel all-reduce), in this
+/* events / n_events: optional hipEvent_t array recorded as gradient groups complete (as smbv_mim_backward's: completion in array order), in this
  * order: [0] predictor.proj + predictor.layernorm, [1..players] predictor layers (last first), [players+1] mask tokens + predictor_embeddings,
  * [players+2] encoder.layernorm, [players+3 .. players+2+layers] encoder layers (last first), [last] patch embedding. */
 int smbv_vjepa_backward(const smbv_vjepa_cfg* cfg, const smbv_vjepa_tensors* params, const smbv_vjepa_tensors* grads, const smbv_vjepa_io* io,

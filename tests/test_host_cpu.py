@@ -306,3 +306,49 @@ def test_vjepa_collate_ships_the_index_arrays():
     assert torch.equal(pc["tgt_slot"][0].long(), torch.arange(50)) and torch.equal(pc["ctx_slot"][0].long(), 50 + torch.arange(30))
     ref = index_plumbing([batch["context_mask"][0].long()], [batch["target_mask"][0].long()], N, "context")
     assert all(torch.equal(pc[k], ref[k]) for k in ("tgt_idx", "pred_pos", "ctx_slot", "tgt_slot", "all_idx", "need_rows", "ctx_idx"))
+
+
+def test_synthetic_datasets_give_one_fixed_item_per_index_and_leave_the_global_rng_alone():
+    """Round 4 (resume): HF skips batches by index when it resumes, without producing the items - the harness datasets therefore derive an item's mask from its
+    index (what the reference's PersistentDataset caches with the image), not from however many items were produced before, and leave the global streams the
+    mask generators draw from exactly as they found them."""
+    from smb_vision_amd.masking import MaskGenerator, VJEPAMaskGenerator
+    from smb_vision_amd.run_mim import SyntheticVolumeDataset
+    from smb_vision_amd.run_vjepa import SyntheticVJEPADataset
+    ds = SyntheticVolumeDataset(8, 32, 16, MaskGenerator(32, 16, 16, 16, 0.5), seed=7)
+    np.random.seed(123)
+    expect_next = np.random.RandomState(123).permutation(5)
+    a3 = ds[3]
+    assert np.array_equal(np.random.permutation(5), expect_next)          # the global numpy stream did not move
+    _ = ds[0], ds[5]
+    b3 = ds[3]
+    assert torch.equal(a3["mask"], b3["mask"]) and torch.equal(a3["image"], b3["image"])
+    assert not torch.equal(ds[3]["mask"], ds[4]["mask"]) or not torch.equal(ds[3]["image"], ds[4]["image"])
+    gen = VJEPAMaskGenerator(input_size=(16, 32, 32), patch_size=(8, 8, 8), pred_mask_scale=(0.2, 0.8), aspect_ratio=(0.3, 3.0), num_blocks=2)
+    dv = SyntheticVJEPADataset(4, 32, 16, gen, 11)
+    torch.manual_seed(5)
+    state = torch.random.get_rng_state()
+    x2 = dv[2]
+    assert torch.equal(torch.random.get_rng_state(), state)               # nor the global torch stream
+    _ = dv[0]
+    y2 = dv[2]
+    assert torch.equal(x2["context_mask"], y2["context_mask"]) and torch.equal(x2["target_mask"], y2["target_mask"])
+
+
+def test_resume_helpers_follow_the_reference_scripts(tmp_path):
+    """src/run_mim.py:263-276: the newest checkpoint-* of output_dir is what a run resumes from unless --resume_from_checkpoint names another; the metric
+    helper is the reference's compute_metrics (loss = first prediction) made safe for more than one evaluation batch."""
+    import types
+    from transformers import EvalPrediction
+    from smb_vision_amd.trainer import detect_last_checkpoint, keep_loss_only, loss_only_metrics
+    args = types.SimpleNamespace(output_dir=str(tmp_path / "run"), resume_from_checkpoint=None)
+    assert detect_last_checkpoint(args) is None                           # no directory yet
+    for n in (2, 10, 4):
+        (tmp_path / "run" / f"checkpoint-{n}").mkdir(parents=True)
+    assert detect_last_checkpoint(args).endswith("checkpoint-10")
+    args.overwrite_output_dir = True                                       # (where the installed transformers still has the flag)
+    assert detect_last_checkpoint(args) is None
+    assert loss_only_metrics(EvalPrediction(predictions=(np.array([1.0, 3.0]), np.zeros((2, 4))), label_ids=None)) == {"loss": 2.0}
+    assert loss_only_metrics(EvalPrediction(predictions=np.array([0.5]), label_ids=None)) == {"loss": 0.5}
+    kept = keep_loss_only((torch.tensor(0.25), torch.zeros(2, 3, 4)), None)
+    assert kept.shape == (1,) and float(kept[0]) == 0.25
