@@ -127,7 +127,7 @@ void carve_bwd_scratch(Carver& cv, BwdScratch& sc, const BwdNeeds& n);  // every
 // launch reads must outlive the block: the bf16 residual gradients (in / mid) come from a ring of six buffers (block k: in = gb[2k], mid = gb[2k+1],
 // out = gb[2k+2], indices mod 6), d_act / d_qkv / the LayerNorm partials from rings of two; block k starts only after launch k-2 has finished
 // (event ring), which frees exactly the ring entries it overwrites.  Blocks the grouped launch cannot take (head-padded widths, widths that are not
-// multiples of 128, non-adjacent q/k/v gradients, a ranged block at B > 1) run their products inline on the same side stream, as before; they use the
+// multiples of 128, a ranged block at B > 1) run their products inline on the same side stream, as before; they use the
 // same rings.  Under recompute the blocks of a stack alternate between two activation sets and the step waits for launch k - 2 before it re-runs block
 // k's forward (mim_step.hip): the launches - and the gradients, bit for bit - are the resident step's.
 struct WgradPipe {

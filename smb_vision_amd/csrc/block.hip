@@ -214,7 +214,7 @@ int layer_bwd_core(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const Bl
   float *g = bf.g, *g2 = bf.g2;
   bf16_t *gb = bf.gb_in, *gb2 = bf.gb_mid;
   SideStream side;
-  TnJob jobs[4];
+  TnJob jobs[6];   // fc2, fc1, proj, fused q|k|v - or q, k, v separately when their gradients are not adjacent in the arena (V-JEPA: biases in between)
   int nj = 0;
   // one weight (+ bias: the column sums ride along, gemm.hip) gradient product: collected for the grouped launch, or issued on the side stream beside
   // the input-gradient product that shares its dY
@@ -319,8 +319,9 @@ int layer_bwd_core(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const Bl
       float* wdst[3] = {gr.q_w, gr.k_w, gr.v_w};
       float* bdst[3] = {gr.q_b, gr.k_b, gr.v_b};
       for (int sec = 0; sec < 3; sec++) {
-        TnColsum cs; cs.dst[0] = bdst[sec]; cs.seg = w;
-        RC(gemm_tn(bf.d_qkv + sec * w, 3 * w, L.ln1, w, M, w, w, wdst[sec], sc.wscratch, sc.wscratch_bytes, side.st, bdst[sec] ? &cs : nullptr));
+        TnColsum cs; cs.dst[0] = bdst[sec]; cs.seg = bdst[sec] ? w : 0;
+        if (defer) RC(wgrad(bf.d_qkv + sec * w, 3 * w, L.ln1, w, M, w, w, wdst[sec], cs));
+        else RC(gemm_tn(bf.d_qkv + sec * w, 3 * w, L.ln1, w, M, w, w, wdst[sec], sc.wscratch, sc.wscratch_bytes, side.st, bdst[sec] ? &cs : nullptr));
       }
     }
   } else {
@@ -374,8 +375,8 @@ int layer_bwd(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDi
   const bool ranged = Sq > 0;
   const size_t Mmax = d.rows;
   const bool shapes_ok = w % 128 == 0 && ff % 128 == 0 && Mmax * (size_t)std::max(ff, 3 * w) * 2 < (1ull << 31);
-  const bool defer = pipe.fj && pipe.allow_defer && !(g_variant & 4) && !d.padded() && shapes_ok && gr.k_w == gr.q_w + ww && gr.v_w == gr.k_w + ww &&
-                     !(ranged && d.B > 1) && !(g_variant & 32);
+  (void)ww;   // (q / k / v weight gradients that are not adjacent in the arena become three jobs of the grouped launch instead of one)
+  const bool defer = pipe.fj && pipe.allow_defer && !(g_variant & 4) && !d.padded() && shapes_ok && !(ranged && d.B > 1) && !(g_variant & 32);
   const int rc = layer_bwd_core(p, gr, L, d, sc, x_in, bf, Sq, qoff, st, defer ? &pipe : nullptr, k, dp_event, &pipe);
   if (rc) return rc;
   pipe.deferred[k & 3] = defer;
