@@ -182,7 +182,9 @@ typedef struct smbv_mim_cfg {
   int B, T, H, W;                 /* volume batch: pixel_values fp32 [B,T,1,H,W] */
   int ps, ts;                     /* patch_size, tubelet_size */
   int N, Nvis, Nmask;             /* tokens per volume: all / visible / masked */
-  int d, heads, ff, layers;       /* encoder: hidden_size, num_attention_heads, intermediate_size, num_hidden_layers */
+  int d, heads, ff, layers;       /* encoder: hidden_size, num_attention_heads, intermediate_size, num_hidden_layers.  Head widths d / heads (and
+                                     dd / dheads): multiples of 8 up to 64; 64 and 32 have native attention builds, the others run zero-padded in
+                                     64-wide slots (exact; SMBV_ERR_SHAPE above 64; the fp8 path: 64 only) */
   int dd, dheads, dff, dlayers;   /* decoder_* */
   float ln_eps;                   /* config.layer_norm_eps (blocks) */
   float dec_norm_eps;             /* decoder.norm eps: torch default 1e-5 (spec :676) */

@@ -23,7 +23,7 @@ struct EncWs {
 };
 
 static BlockDims edims(const smbv_encoder_cfg& c) {
-  BlockDims d; d.rows = (size_t)c.B * c.Nsel; d.w = c.d; d.ff = c.ff; d.B = c.B; d.S = c.Nsel; d.H = c.heads; d.Dh = 64; d.eps = c.ln_eps; d.o_resid = c.train ? c.attn_o_resid : 0;
+  BlockDims d; d.rows = (size_t)c.B * c.Nsel; d.w = c.d; d.ff = c.ff; d.B = c.B; d.S = c.Nsel; d.H = c.heads; d.Dh = c.d / c.heads; d.eps = c.ln_eps; d.o_resid = c.train ? c.attn_o_resid : 0;
   return d;
 }
 
@@ -33,7 +33,7 @@ static int check_cfg(const smbv_encoder_cfg& c) {
   if (c.ps <= 0 || c.ts <= 0 || c.T % c.ts || c.H % c.ps || c.W % c.ps || (c.ps & 3)) { set_error("encoder: volume %dx%dx%d not divisible by tubelet %d / patch %d", c.T, c.H, c.W, c.ts, c.ps); return SMBV_ERR_SHAPE; }
   const int N = (c.T / c.ts) * (c.H / c.ps) * (c.W / c.ps);
   if (c.N != N || c.Nsel <= 0 || c.Nsel > N) { set_error("encoder: token counts N=%d Nsel=%d inconsistent with the volume (%d)", c.N, c.Nsel, N); return SMBV_ERR_SHAPE; }
-  if (c.d % c.heads || c.d / c.heads != 64) { set_error("encoder: head_dim must be 64 (d=%d/%d)", c.d, c.heads); return SMBV_ERR_SHAPE; }
+  if (c.heads <= 0 || c.d % c.heads || c.d / c.heads > 64 || ((c.d / c.heads) & 7)) { set_error("encoder: head_dim must be a multiple of 8 and <= 64 (d=%d/%d)", c.d, c.heads); return SMBV_ERR_SHAPE; }
   if ((c.d & 7) || (c.ff & 7) || ((c.ts * c.ps * c.ps) & 7)) { set_error("encoder: widths must be multiples of 8"); return SMBV_ERR_SHAPE; }
   return SMBV_OK;
 }

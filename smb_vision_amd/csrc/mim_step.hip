@@ -27,11 +27,11 @@ struct MimWs {
 };
 
 static BlockDims enc_dims(const smbv_mim_cfg& c) {
-  BlockDims d; d.rows = (size_t)c.B * c.Nvis; d.w = c.d; d.ff = c.ff; d.B = c.B; d.S = c.Nvis; d.H = c.heads; d.Dh = 64; d.eps = c.ln_eps; d.attn_fp8 = c.attn_fp8; d.o_resid = c.attn_o_resid;
+  BlockDims d; d.rows = (size_t)c.B * c.Nvis; d.w = c.d; d.ff = c.ff; d.B = c.B; d.S = c.Nvis; d.H = c.heads; d.Dh = c.d / c.heads; d.eps = c.ln_eps; d.attn_fp8 = c.attn_fp8; d.o_resid = c.attn_o_resid;
   return d;
 }
 static BlockDims dec_dims(const smbv_mim_cfg& c) {
-  BlockDims d; d.rows = (size_t)c.B * c.N; d.w = c.dd; d.ff = c.dff; d.B = c.B; d.S = c.N; d.H = c.dheads; d.Dh = 64; d.eps = c.ln_eps; d.attn_fp8 = c.attn_fp8; d.o_resid = c.attn_o_resid;
+  BlockDims d; d.rows = (size_t)c.B * c.N; d.w = c.dd; d.ff = c.dff; d.B = c.B; d.S = c.N; d.H = c.dheads; d.Dh = c.dd / c.dheads; d.eps = c.ln_eps; d.attn_fp8 = c.attn_fp8; d.o_resid = c.attn_o_resid;
   return d;
 }
 static BlockPtrs to_block(const smbv_layer_ptrs& p) {
@@ -47,7 +47,11 @@ static int check_cfg(const smbv_mim_cfg& c) {
   if (c.ps <= 0 || c.ts <= 0 || c.T % c.ts || c.H % c.ps || c.W % c.ps || (c.ps & 3)) { set_error("mim: volume %dx%dx%d not divisible by tubelet %d / patch %d", c.T, c.H, c.W, c.ts, c.ps); return SMBV_ERR_SHAPE; }
   const int N = (c.T / c.ts) * (c.H / c.ps) * (c.W / c.ps);
   if (c.N != N || c.Nvis <= 0 || c.Nmask <= 0 || c.Nvis + c.Nmask != N) { set_error("mim: token counts N=%d Nvis=%d Nmask=%d inconsistent with the volume (%d)", c.N, c.Nvis, c.Nmask, N); return SMBV_ERR_SHAPE; }
-  if (c.d % c.heads || c.d / c.heads != 64 || c.dd % c.dheads || c.dd / c.dheads != 64) { set_error("mim: head_dim must be 64 (d=%d/%d, dd=%d/%d)", c.d, c.heads, c.dd, c.dheads); return SMBV_ERR_SHAPE; }
+  if (c.heads <= 0 || c.dheads <= 0 || c.d % c.heads || c.dd % c.dheads) { set_error("mim: width not divisible by heads (d=%d/%d, dd=%d/%d)", c.d, c.heads, c.dd, c.dheads); return SMBV_ERR_SHAPE; }
+  // head widths 64 and 32 have native attention builds; other multiples of 8 below 64 run zero-padded in 64-wide slots (block.h: exact, slower)
+  const int dh = c.d / c.heads, ddh = c.dd / c.dheads;
+  if (dh > 64 || ddh > 64 || (dh & 7) || (ddh & 7)) { set_error("mim: head_dim must be a multiple of 8 and <= 64 (d=%d/%d, dd=%d/%d)", c.d, c.heads, c.dd, c.dheads); return SMBV_ERR_SHAPE; }
+  if (c.attn_fp8 && (dh != 64 || ddh != 64)) { set_error("mim: the fp8 attention path is built for head_dim 64 (d=%d/%d, dd=%d/%d)", c.d, c.heads, c.dd, c.dheads); return SMBV_ERR_SHAPE; }
   if ((c.d & 7) || (c.dd & 7) || (c.ff & 7) || (c.dff & 7) || ((c.ts * c.ps * c.ps) & 7)) { set_error("mim: widths must be multiples of 8"); return SMBV_ERR_SHAPE; }
   return SMBV_OK;
 }
@@ -92,8 +96,11 @@ static void carve(const smbv_mim_cfg& c, void* base, MimWs& w) {
   nd.scratch = std::max(nd.scratch, colsum_workspace_bytes((int)std::max(R, Rd), std::max(std::max(c.d, c.dd), K)));
   carve_bwd_scratch(cv, w.sc, nd);
   carve_wgrad_pipe(cv, w.pipe, gw, nd);
-  w.sc.gath0 = cv.take<bf16_t>(Rm * c.dd);
-  w.sc.gath1 = cv.take<bf16_t>(Rm * c.dd);
+  // row gathers of the ranged last decoder block at B > 1: residual-gradient rows [Rm, dd] and attention-output rows [Rm, H * slot] (wider than dd
+  // when the heads are zero-padded to 64-wide slots)
+  const size_t gath = Rm * (size_t)std::max(c.dd, dd.wa());
+  w.sc.gath0 = cv.take<bf16_t>(gath);
+  w.sc.gath1 = cv.take<bf16_t>(gath);
   w.total = (cv.off + 255) & ~(size_t)255;
 }
 
