@@ -68,7 +68,7 @@ static void carve(const smbv_encoder_cfg& c, void* base, EncWs& w) {
     return;
   }
   carve_layer(cv, w.L[0], de);  // weights of layer 0 + the ONE set of activation buffers
-  const size_t ww = (size_t)c.d * c.d, fw = (size_t)c.ff * c.d;
+  const size_t ww = (size_t)de.wa() * c.d, fw = (size_t)c.ff * c.d;   // (wa = heads x slot: wider than d when the heads are zero-padded to 64-wide slots)
   for (int l = 1; l < c.layers; l++) {
     LayerWs& L = w.L[l];
     L = w.L[0];                                    // share every activation buffer ...
@@ -80,7 +80,7 @@ static void carve(const smbv_encoder_cfg& c, void* base, EncWs& w) {
     L.fc1_t = w.L[0].fc1_t;
     L.fc2 = cv.take<bf16_t>(fw);
     L.fc2_t = w.L[0].fc2_t;
-    L.bqkv = cv.take<float>(3 * (size_t)c.d);
+    L.bqkv = cv.take<float>(3 * (size_t)de.wa());
   }
   w.a_patch = cv.take<bf16_t>(R * K);
   w.x0 = cv.take<float>(R * c.d);

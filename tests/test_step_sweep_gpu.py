@@ -113,3 +113,104 @@ def test_random_vjepa_configuration_matches_oracle(seed):
         assert e < (2e-1 if k.endswith("attention.key.bias") else 8e-2), (k, e, nrm)
     assert ops.device_status() == 0
     print(f"vjepa seed {seed}: {c} {o}: loss {float(loss):.6f} oracle {float(ref_loss):.6f} worst grad {worst}")
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_encoder_configuration_matches_oracle(seed):
+    """And for the encoder-only step (VideoMAEModel.forward: embedding export / the fine-tuning body, smbv_encoder_forward / _backward): all tokens or the
+    visible ones, with and without the final LayerNorm, training mode with a random linear loss on the hidden states - outputs 2e-2, gradients 8e-2
+    (tests/test_encoder_gpu.py's bounds)."""
+    from oracle.mim_oracle import encoder_forward
+    from transformers import VideoMAEConfig
+    from smb_vision_amd import ops
+    from smb_vision_amd.masking import MaskGenerator
+    from smb_vision_amd.modeling_videomae_encoder import SmbVideoMAEModel
+    c, o = draw(500 + seed)
+    cfg = MIMConfig(**c)
+    params = init_params(cfg, seed=300 + seed, nonzero_small=True)
+    g = torch.Generator().manual_seed(seed)
+    final_ln, use_mask = bool(seed & 1), bool(seed & 2)
+    p_enc = {k: v for k, v in params.items() if k.startswith("videomae.")}
+    if final_ln:
+        p_enc["videomae.layernorm.weight"] = 1.0 + 0.1 * torch.randn(c["hidden_size"], generator=g)
+        p_enc["videomae.layernorm.bias"] = 0.1 * torch.randn(c["hidden_size"], generator=g)
+    enc_c = {k: c[k] for k in ("image_size", "num_frames", "patch_size", "tubelet_size", "hidden_size", "num_hidden_layers", "num_attention_heads",
+                               "intermediate_size")}
+    model = SmbVideoMAEModel(VideoMAEConfig(num_channels=1, use_mean_pooling=not final_ln, **enc_c))
+    model.load_state_dict({k[len("videomae."):]: v for k, v in p_enc.items()}, strict=True)
+    model = model.cuda().train()
+    np.random.seed(seed)
+    gen = MaskGenerator(c["image_size"], c["num_frames"], o["mask_patch"], 16, o["ratio"])
+    mask = torch.stack([gen() for _ in range(o["B"])]) if use_mask else None
+    pix = torch.rand(o["B"], c["num_frames"], 1, c["image_size"], c["image_size"], generator=g)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in p_enc.items()}
+    ref = encoder_forward(leaf, cfg, pix, mask, "videomae.", final_ln)
+    G = torch.randn(ref.shape, generator=g)
+    (ref * G).sum().backward()
+    out = model(pix.cuda(), bool_masked_pos=None if mask is None else mask.cuda()).last_hidden_state
+    (out.float() * G.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    d = out.detach().float().cpu() - ref.detach()
+    assert float(d.abs().max() / ref.abs().max()) < 2e-2 and float(d.pow(2).mean().sqrt() / ref.detach().pow(2).mean().sqrt()) < 1e-2
+    worst = ("", 0.0)
+    for k, p_ in model.named_parameters():
+        r = leaf["videomae." + k].grad
+        n = float(r.norm())
+        if n < 1e-10:
+            continue
+        e = float((p_.grad.cpu() - r).norm()) / n
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        assert e < 8e-2, (k, e)
+    with torch.no_grad():   # inference mode (no saved activations): same values
+        ev = model.eval()(pix.cuda(), bool_masked_pos=None if mask is None else mask.cuda()).last_hidden_state
+    assert float((ev.float() - out.detach().float()).abs().max()) <= 2e-2 * float(ref.abs().max())
+    assert ops.device_status() == 0
+    print(f"encoder seed {seed}: final_ln {final_ln} mask {use_mask} B {o['B']} d {c['hidden_size']}/{c['num_attention_heads']}: worst grad {worst}")
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_fp8_step_configuration_matches_oracle(seed):
+    """BASELINE config 5's switches (fp8 attention forward, or forward + the backward's recomputed products; per-layer recompute) on random head_dim-64
+    configurations: the whole step against the fp32 oracle within tests/test_fp8_gpu.py's bounds (loss 1e-2, logits rms 5e-2, gradients 1.5e-1 / cosine 0.99)."""
+    from transformers import VideoMAEConfig
+    from smb_vision_amd import ops
+    from smb_vision_amd.masking import MaskGenerator
+    from smb_vision_amd.modeling_videomae import SmbVideoMAEForPreTraining
+    r = random.Random(3000 + seed)
+    hid, dec = r.choice([64, 128, 192, 256]), r.choice([64, 128, 192])
+    c = dict(image_size=r.choice([64, 96, 128]), num_frames=r.choice([32, 48, 64]), patch_size=16, tubelet_size=16, hidden_size=hid,
+             num_hidden_layers=r.randint(1, 3), num_attention_heads=hid // 64, intermediate_size=r.choice([128, 256, 320, 512]), decoder_hidden_size=dec,
+             decoder_num_hidden_layers=r.randint(1, 3), decoder_num_attention_heads=dec // 64, decoder_intermediate_size=r.choice([128, 192, 256]))
+    B, ratio, mode, recompute = r.randint(1, 3), r.uniform(0.3, 0.8), r.choice([True, "forward"]), r.random() < 0.6
+    cfg = MIMConfig(**c)
+    params = init_params(cfg, seed=400 + seed, nonzero_small=True)
+    np.random.seed(seed)
+    gen = MaskGenerator(c["image_size"], c["num_frames"], 16, 16, ratio)
+    mask = torch.stack([gen() for _ in range(B)])
+    pix = torch.rand(B, c["num_frames"], 1, c["image_size"], c["image_size"], generator=torch.Generator().manual_seed(seed))
+    ref_loss, ref_logits, ref_grads = mim_step(params, cfg, pix, mask)
+    extra = dict(smbv_attention_fp8=mode)
+    if recompute:
+        extra["smbv_recompute"] = "always"
+    model = SmbVideoMAEForPreTraining(VideoMAEConfig(num_channels=1, **c, **extra))
+    model.load_state_dict(params, strict=True)
+    model = model.cuda().train()
+    if recompute:
+        model.gradient_checkpointing_enable()
+    loss, logits, grads = run_step(model, pix, mask)
+    assert abs(float(loss) - float(ref_loss)) <= 1e-2 * float(ref_loss)
+    d = logits - ref_logits
+    assert float(d.pow(2).mean().sqrt()) <= 5e-2 * float(ref_logits.pow(2).mean().sqrt())
+    worst = ("", 0.0)
+    for k, ref in ref_grads.items():
+        n = float(ref.norm())
+        if n < 1e-10:
+            continue
+        e = float((grads[k] - ref).norm()) / n
+        cos = float((grads[k] * ref).sum() / (grads[k].norm() * ref.norm()))
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        assert e <= 1.5e-1 and cos >= 0.99, (k, e, cos)
+    loss2, logits2, grads2 = run_step(model, pix, mask)
+    assert torch.equal(loss, loss2) and all(torch.equal(grads[k], grads2[k]) for k in grads)
+    assert ops.device_status() == 0
+    print(f"fp8 seed {seed}: {c} B {B} mode {mode} recompute {recompute}: loss {float(loss):.6f} oracle {float(ref_loss):.6f} worst grad {worst}")
