@@ -168,6 +168,9 @@ class SmbVideoMAEForPreTraining(PreTrainedModel):
             raise ValueError("smb_vision_amd: only hidden_act='gelu' (exact erf) is implemented")
         if not getattr(config, "qkv_bias", True):
             raise ValueError("smb_vision_amd: qkv_bias=False is not implemented")
+        if float(getattr(config, "hidden_dropout_prob", 0.0) or 0.0) != 0.0 or float(getattr(config, "attention_probs_dropout_prob", 0.0) or 0.0) != 0.0:
+            # (the reference trains with VideoMAEConfig's defaults, 0.0 / 0.0; the fused kernels have no dropout, and silently ignoring it would change training)
+            raise ValueError("smb_vision_amd: hidden_dropout_prob / attention_probs_dropout_prob must be 0 (dropout is not implemented on the HIP path)")
         if not getattr(config, "norm_pix_loss", True):
             # with num_channels != 3 the reference raises here too (spec :869-872)
             raise ValueError("Can't unnormalize non-RGB images. Consider setting config.norm_pix_loss to False.")

@@ -196,6 +196,8 @@ def _check_config(config):
         raise ValueError("smb_vision_amd: only hidden_act='gelu' (exact erf) is implemented")
     if not getattr(config, "qkv_bias", True):
         raise ValueError("smb_vision_amd: qkv_bias=False is not implemented")
+    if float(getattr(config, "hidden_dropout_prob", 0.0) or 0.0) != 0.0 or float(getattr(config, "attention_probs_dropout_prob", 0.0) or 0.0) != 0.0:
+        raise ValueError("smb_vision_amd: hidden_dropout_prob / attention_probs_dropout_prob must be 0 (dropout is not implemented on the HIP path)")
 
 
 class _EncoderModelBase(PreTrainedModel):

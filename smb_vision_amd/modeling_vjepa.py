@@ -195,6 +195,8 @@ class SmbVJEPA2Model(PreTrainedModel):
             raise ValueError("smb_vision_amd: the MI355X V-JEPA path is built for single-channel volumes (in_chans=1, run_vjepa.py:225)")
         if not config.qkv_bias or config.hidden_act != "gelu" or config.drop_path_rate != 0.0:
             raise ValueError("smb_vision_amd: qkv_bias=True, hidden_act='gelu', drop_path_rate=0 only")
+        if any(float(getattr(config, k, 0.0) or 0.0) != 0.0 for k in ("attention_probs_dropout_prob", "attention_dropout")):
+            raise ValueError("smb_vision_amd: attention dropout must be 0 (not implemented on the HIP path; the reference's configuration leaves it at 0)")
         self._table = param_table(config)
         for name, shape, _ in self._table:
             _register(self, name, nn.Parameter(torch.empty(shape)))

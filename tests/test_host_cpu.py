@@ -38,6 +38,33 @@ def test_bad_config_is_rejected_without_gpu():
     assert "mim" in _lib.last_error()
 
 
+def test_unsupported_config_options_raise_instead_of_being_ignored():
+    """Options the HIP path does not compute are refused at construction (a drop-in that silently trained without dropout would not be one); head widths:
+    multiples of 8 up to 64 are accepted by the C side (64 / 32 native, others zero-padded), anything else is SMBV_ERR_SHAPE."""
+    from transformers import VideoMAEConfig, VJEPA2Config
+    from smb_vision_amd.modeling_videomae import SmbVideoMAEForPreTraining
+    from smb_vision_amd.modeling_videomae_encoder import SmbVideoMAEModel
+    from smb_vision_amd.modeling_vjepa import SmbVJEPA2Model
+    tiny = dict(num_channels=1, image_size=32, num_frames=16, patch_size=16, tubelet_size=16, hidden_size=64, num_hidden_layers=1, num_attention_heads=1,
+                intermediate_size=64, decoder_hidden_size=64, decoder_num_hidden_layers=1, decoder_num_attention_heads=1, decoder_intermediate_size=64)
+    for bad in (dict(hidden_dropout_prob=0.1), dict(attention_probs_dropout_prob=0.1), dict(hidden_act="relu"), dict(qkv_bias=False), dict(num_channels=3)):
+        with pytest.raises(ValueError):
+            SmbVideoMAEForPreTraining(VideoMAEConfig(**{**tiny, **bad}))
+        with pytest.raises(ValueError):
+            SmbVideoMAEModel(VideoMAEConfig(**{**tiny, **bad}))
+    vj = dict(patch_size=8, crop_size=16, frames_per_clip=4, tubelet_size=2, in_chans=1, hidden_size=64, num_hidden_layers=1, num_attention_heads=1,
+              pred_hidden_size=64, pred_num_hidden_layers=1, pred_num_attention_heads=1)
+    for bad in (dict(attention_dropout=0.1), dict(attention_probs_dropout_prob=0.1), dict(drop_path_rate=0.1), dict(in_chans=3)):
+        with pytest.raises(ValueError):
+            SmbVJEPA2Model(VJEPA2Config(**{**vj, **bad}))
+    lib = _lib.load()
+    ok = dict(B=1, T=32, H=32, W=32, ps=16, ts=16, N=8, Nvis=4, Nmask=4, ff=64, layers=1, dff=64, dlayers=1, ln_eps=1e-12, dec_norm_eps=1e-5)
+    for d, heads, fine in ((64, 1, True), (64, 2, True), (96, 2, True), (64, 4, True), (160, 2, False), (72, 6, False), (64, 3, False)):
+        cfg = _lib.MimCfg(d=d, heads=heads, dd=64, dheads=1, **ok)
+        n = lib.smbv_mim_workspace_bytes(ctypes.byref(cfg))
+        assert (n > 0) == fine, (d, heads, n, _lib.last_error())
+
+
 def test_workspace_size_vit_base():
     lib = _lib.load()
     cfg = _lib.MimCfg(B=1, T=320, H=512, W=512, ps=16, ts=16, N=20480, Nvis=7168, Nmask=13312, d=768, heads=12, ff=3072, layers=12,
