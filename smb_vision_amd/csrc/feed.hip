@@ -47,8 +47,12 @@ __global__ __launch_bounds__(256) void prepare_volume_kernel(const T* __restrict
       float v = 0.f;  // SpatialPadd: constant 0 after the intensity scaling
       if (hs >= 0 && hs < g.H0 && ws >= 0 && ws < g.W0 && ds >= 0 && ds < g.D0) {
         const float x = raw_to_float<T>(sp[((size_t)hs * g.W0 + ws) * g.D0 + ds]);
-        v = __fdiv_rn(__fsub_rn(x, g.a_min), g.a_rng);                       // each step rounded on its own, as the
-        v = __fadd_rn(__fmul_rn(v, __fsub_rn(g.b_max, g.b_min)), g.b_min);   // reference's tensor ops are (no FMA contraction)
+        // each step rounded on its own, as the reference's tensor ops are.  hipcc's __fmul_rn / __fadd_rn are plain * and +, which -ffp-contract=fast
+        // fuses into one FMA (invisible while b_max - b_min is a power of two, one ulp off at 3.5): the product is pinned in a register between them
+        v = __fdiv_rn(__fsub_rn(x, g.a_min), g.a_rng);
+        v = __fmul_rn(v, __fsub_rn(g.b_max, g.b_min));
+        asm volatile("" : "+v"(v));
+        v = __fadd_rn(v, g.b_min);
         if (g.clip) v = fminf(fmaxf(v, g.b_min), g.b_max);
       }
       tile[wl][rd + e] = v;

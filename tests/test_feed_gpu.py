@@ -45,6 +45,32 @@ def test_prepare_volume_bit_exact(feed, shape, dtype):
     assert np.array_equal(got[0].cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("seed", list(range(32)))
+def test_prepare_volume_random_geometry_bit_exact(feed, seed):
+    """Random source boxes (1..150 per axis), target sizes (odd and even: both centring conventions of pad and crop), intensity windows, clip on / off,
+    batch 1-2: bit-exact against the CPU restatement."""
+    rng = np.random.default_rng(9000 + seed)
+    H0, W0, D0 = (int(rng.integers(1, 151)) for _ in range(3))
+    S, D = int(rng.integers(2, 140)), int(rng.integers(2, 140))
+    B = int(rng.integers(1, 3))
+    a_min = float(rng.choice([-1000.0, -200.0, 0.0]))
+    a_max = a_min + float(rng.choice([300.0, 1200.0, 2000.0]))
+    kw = dict(a_min=a_min, a_max=a_max, b_min=float(rng.choice([0.0, -1.0])), b_max=float(rng.choice([1.0, 2.5])), clip=bool(rng.integers(0, 2)))
+    if seed % 3 == 0:
+        raw = rng.integers(-2000, 2500, size=(B, H0, W0, D0), dtype=np.int16)
+        dev = torch.from_numpy(raw).cuda()
+    elif seed % 3 == 1:
+        raw = (rng.standard_normal((B, H0, W0, D0)) * 900).astype(np.float32)
+        dev = torch.from_numpy(raw).cuda()
+    else:
+        raw = rng.integers(0, 4000, size=(B, H0, W0, D0), dtype=np.uint16)
+        dev = torch.from_numpy(raw.view(np.int16)).cuda().view(torch.uint16)
+    got = feed.prepare_volume(dev, S, D, **kw)
+    assert got.shape == (B, D, 1, S, S)
+    for b in range(B):
+        assert np.array_equal(got[b].cpu().numpy(), fo.prepare_volume(raw[b], S, D, **kw)), (seed, H0, W0, D0, S, D, kw)
+
+
 def test_prepare_volume_batch_and_full_size_property(feed):
     # batch of 2, and the size-independent property at the real geometry: a constant HU volume maps to one value inside the source box
     raw = torch.full((2, 40, 40, 24), 500, dtype=torch.int16).cuda()
