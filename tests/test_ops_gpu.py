@@ -702,3 +702,29 @@ def test_attention_bwd_cancellation_regime_at_the_vjepa_encoder_grid(ops):
         assert vs_emu < 5e-3, (n, vs_emu)
         assert vs_exact < 5e-2, (n, vs_exact)                   # dQ (and dK) vs exact arithmetic within the step's gradient bound
     assert torch.equal(dqkv2[:, 2 * w:], dqkv[:, 2 * w:])       # dV does not read delta
+
+
+def test_gemm_operands_beyond_2_gib_take_the_64_bit_paths(ops):
+    """The LDS-DMA kernels address their operands with 32-bit byte offsets and are selected only below 2 GiB per operand (gemm.hip, gemm_nt_ring.hip:
+    `M * ld * 2 < 2^31`); beyond it the register-staged kernels run (64-bit pointers).  A 2.15-GB activation matrix (350,208 rows x 3,072: B = 17 of the
+    bench's decoder MLP) through both product families and the grouped launch's refusal: results against fp32 torch, rows at the far end included."""
+    M, K, N = 350_208, 3072, 256
+    g = torch.Generator(device="cuda").manual_seed(3)
+    A = torch.empty(M, K, dtype=torch.bfloat16, device="cuda")
+    for i in range(0, M, 43_776):   # (filled in pieces: no 4.3-GB fp32 temporary)
+        A[i:i + 43_776] = torch.randn(43_776, K, generator=g, device="cuda").bfloat16()
+    assert A.numel() * 2 >= 1 << 31
+    W = (torch.randn(N, K, generator=g, device="cuda") * 0.02).bfloat16()
+    out = ops.gemm_nt(A, W)["bf16"]
+    for lo in (0, M // 2, M - 4096):   # first rows, middle, and the rows whose byte offsets exceed 2^31
+        ref = A[lo:lo + 4096].float() @ W.float().t()
+        assert rel_err(out[lo:lo + 4096], ref) < 1e-2, lo
+    Y = torch.randn(M, 128, generator=g, device="cuda").bfloat16()
+    got = ops.gemm_tn(A, Y)
+    ref = torch.zeros(K, 128, dtype=torch.float32, device="cuda")
+    for i in range(0, M, 43_776):
+        ref += A[i:i + 43_776].float().t() @ Y[i:i + 43_776].float()
+    assert rel_err(got, ref) < 1e-3
+    with pytest.raises(ValueError, match="not groupable"):   # the grouped launch refuses (the step then issues the products one by one)
+        ops.gemm_tn_grouped([(A, Y)])
+    assert ops.device_status() == 0
