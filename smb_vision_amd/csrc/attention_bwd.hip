@@ -836,8 +836,8 @@ __device__ __forceinline__ void attn_dq_fp8_block(const Fp8BwdOps f8, const bf16
     okb[i] = (row * ld + ((l & 7) ^ (((x & 1) << 2) | (x >> 1))) * 8) * 2;
   }
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((int)lds_addr_of(smem));
-  auto stage = [&](int kt) __attribute__((always_inline)) {
-    const unsigned sl = lds0 + (unsigned)(kt % 3) * SLOT;
+  auto stage = [&](int kt, int slot) __attribute__((always_inline)) {   // slot = kt % 3, a literal at every call site
+    const unsigned sl = lds0 + (unsigned)slot * SLOT;
     dma16_hidden(rs, sl + (unsigned)wv * 1024, ok0 + kt * 64 * w);
     dma16_hidden(rs, sl + 4096 + (unsigned)wv * 1024, ov0 + kt * 64 * w);
     if (l < 16) dma4_hidden(rs, sl + 8192 + (unsigned)wv * 64, os0 + kt * 128);
@@ -847,15 +847,12 @@ __device__ __forceinline__ void attn_dq_fp8_block(const Fp8BwdOps f8, const bf16
   const int g1 = (l >> 4) & 1, qq = (l >> 2) & 3, pp = l & 3;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   const int nt = (S + 63) >> 6;
-  stage(0);
-  stage(1);
-  for (int kt = 0; kt < nt; kt++) {
-    // this wave's five copies of tile kt have landed (tile kt + 1's may still fly); the barrier publishes the tile and retires everybody's reads of tile
-    // kt - 1, whose slot tile kt + 2 now takes (past the end the K8 / V8 / scale copies read unused bytes of the workspace, the bf16 copies zeros: never used)
-    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    stage(kt + 2);
-    const unsigned char* sb = smem + (kt % 3) * SLOT;
+  // One 64-key tile out of ring slot `slot` (a literal: the loop below is unrolled over the ring, so every LDS read is a per-lane base hoisted out of the
+  // loop plus an immediate - with the slot computed from kt the loop carried ~45 address adds per tile next to its 80 exponentials / multiplies / converts,
+  // in a block that is vector-issue bound)
+  auto tile = [&](int kt, auto slotc) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slotc)::value;
+    const unsigned char* sb = smem + slot * SLOT;
     const unsigned char* scb = sb + 8192;
     const unsigned char* kimg = sb + 8448;
     // both sub-tiles' fp8 products first: the exponentials / multiplies / converts of sub-tile 0 then run under sub-tile 1's MFMAs, and sub-tile 0's dQ
@@ -905,6 +902,27 @@ __device__ __forceinline__ void attn_dq_fp8_block(const Fp8BwdOps f8, const bf16
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile kt have returned before it can reach the next barrier
+  };
+  // this wave's five copies of tile kt have landed (tile kt + 1's may still fly); the barrier publishes the tile and retires everybody's reads of tile
+  // kt - 1, whose slot tile kt + 2 now takes (past the end the K8 / V8 / scale copies read unused bytes of the workspace, the bf16 copies zeros: never used)
+  auto landed = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  stage(0, 0);
+  stage(1, 1);
+  for (int kt = 0; kt < nt; kt += 3) {
+    landed();
+    stage(kt + 2, 2);
+    tile(kt, std::integral_constant<int, 0>{});
+    if (kt + 1 >= nt) break;
+    landed();
+    stage(kt + 3, 0);
+    tile(kt + 1, std::integral_constant<int, 1>{});
+    if (kt + 2 >= nt) break;
+    landed();
+    stage(kt + 4, 1);
+    tile(kt + 2, std::integral_constant<int, 2>{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
   if (qok) {
