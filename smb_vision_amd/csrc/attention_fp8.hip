@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
   for (int i = 0; i < 16; i++) { cin[i] = 7.0f; ol[i] = 0.f; }
   const v8i ones = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};  // e4m3 1.0
   const int nt = (S + 63) >> 6;
+  int pw[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the tile's 64 probabilities as e4m3 (loop-carried only as the conversions' pass-through operand)
   stage(0);
   stage(1);
   for (int kt = 0; kt < nt; kt++) {
@@ -230,13 +231,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const unsigned cha
 #pragma unroll
       for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; ol[i] *= alpha; s[0][i] -= d; s[1][i] -= d; cin[i] -= d; }
     }
-    int pw[8];
 #pragma unroll
     for (int tt = 0; tt < 2; tt++)
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const float p0 = fast_exp2(s[tt][4 * g]), p1 = fast_exp2(s[tt][4 * g + 1]), p2 = fast_exp2(s[tt][4 * g + 2]), p3 = fast_exp2(s[tt][4 * g + 3]);
-        int wd = 0;
+        int wd = pw[4 * tt + g];   // (both halves are overwritten: the previous tile's word as the pass-through operand saves a v_mov 0 per word)
         wd = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, wd, false);   // p' in [0, 256]: 7-8 binades above where P in [0, 1] would sit in e4m3
         wd = __builtin_amdgcn_cvt_pk_fp8_f32(p2, p3, wd, true);
         pw[4 * tt + g] = wd;
