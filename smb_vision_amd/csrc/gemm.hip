@@ -352,7 +352,7 @@ static bool nt_dma_ok(int lda, int ldb, int M, int N, int K, const GemmEpi& e) {
          (!e.dgelu_pre || ((e.ld_pre & 7) == 0 && ((uintptr_t)e.dgelu_pre & 15) == 0)) && ((size_t)M * lda * 2 < (1ull << 31)) && ((size_t)N * ldb * 2 < (1ull << 31));
 }
 bool gemm_nt_rowdot_ok(int lda, int ldb, int M, int N, int K, const GemmEpi& e) {
-  const bool ring_shape = K <= 768 && N >= 1024;
+  const bool ring_shape = (K <= 768 && N >= 1024) || (K <= 1024 && N >= 2048);
   const bool ring = gemm_nt_ring_ok(lda, ldb, M, N, K, e) && !(g_variant & 256) && (ring_shape || (g_variant & 131072));
   return !ring && !(g_variant & 32) && nt_dma_ok(lda, ldb, M, N, K, e) && e.out_bf16 && (N % 64) == 0 && (e.ld_dot & 7) == 0;
 }
@@ -369,7 +369,7 @@ int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, in
   // Kernel choice, measured per shape on MI355X (tools/gemm_ab.py, profiles/r02_gemm_ab.txt): the ring kernel (256 x 128 tiles, two K slices in
   // flight per block, register epilogue) is 7-19 % ahead where the epilogue is heavy and K short - the GELU / dGELU products, the decoder's
   // K = 384 projections, the head - and 5-13 % behind the 128 x 128 kernel on long-K or narrow outputs, whose smaller tiles fill the chip better.
-  const bool ring_shape = K <= 768 && N >= 1024;
+  const bool ring_shape = (K <= 768 && N >= 1024) || (K <= 1024 && N >= 2048);
   if (gemm_nt_ring_ok(lda, ldb, M, N, K, e) && !(g_variant & 256) && (ring_shape || (g_variant & 131072)))
     return gemm_nt_ring(A, lda, B, ldb, M, N, K, e, (g_variant & 262144) ? 64 : ((g_variant & 512) ? 4 : 3), st, (g_variant >> 20) & 15);
   if (e.dot_out && (!e.dot_with || (e.dot_dh != 64 && e.dot_dh != 32) || e.dot_rows <= 0 || (((uintptr_t)e.dot_with | (uintptr_t)e.dot_with_lo) & 15) || !gemm_nt_rowdot_ok(lda, ldb, M, N, K, e))) {
