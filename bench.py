@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — MIM train-step throughput (volumes/s) of the MI355X-native path, ViT-base, 512x512x320, B=1 per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1 with no launcher: bench.py starts its N ranks itself, as child processes - self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step = forward + loss + backward (+ RCCL gradient all-reduce when N > 1) + global-norm clip + AdamW + zero_grad on one synthetic
@@ -425,6 +425,40 @@ def timed_region(step, steps, world, device):
     return float(t)
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` as the driver runs it (no launcher, WORLD_SIZE unset): start
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a CHILD process
+    (one rank per GPU, replacing `accelerate launch --config_file acc_configs/multi_gpu_config.yaml`, scripts/training/run_vjepa.sh:16), relay rank 0's JSON line
+    on stdout (everything else the ranks print goes to stderr) and return the launcher's exit code (non-zero when any rank failed).  The parent never touches
+    the GPU - no torch.cuda call, no libsmbv.so load - and never replaces itself: a process that has initialised HIP must not exec (and need not: it is a child)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")         # RCCL's kernels on high-priority streams: not queued behind 2-ms attention blocks (dp.py)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, cpu_threads() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    log("[bench] self-launch:", " ".join(cmd))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    lines = 0
+    for out in proc.stdout:
+        if out.lstrip().startswith('{"metric"'):
+            sys.stdout.write(out)
+            sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        log(f"[bench] the ranks exited 0 but printed {lines} JSON lines")
+        return 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -445,16 +479,19 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="attention forward on the block-scaled fp8 MFMA (config.smbv_attention_fp8; BASELINE config 5 with --vit-large) - diagnostic")
     ap.add_argument("--recompute", action="store_true", help="gradient checkpointing: per-layer recompute (config.smbv_recompute = always) - diagnostic")
     ap.add_argument("--debug-variant", type=int, default=0, help="smbv_debug_set_variant bits (kernel A/B; diagnostic, not the metric)")
+    ap.add_argument("--dp-grad-dtype", default="fp32", choices=("fp32", "bf16"), help="what the N>1 gradient all-reduce ships (bf16 = DDP's bf16_compress_hook; diagnostic)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only to rehearse the N>1 path on one GPU)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher: this process makes NO GPU call and starts the N ranks itself, as children
+        raise SystemExit(self_launch(args.gpus))
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch it with --nproc-per-node {args.gpus} (or with no launcher at all)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the MIM hot path has no CPU fallback")
     device = torch.device("cuda", local % torch.cuda.device_count())
@@ -464,6 +501,7 @@ def main():
         _lib.load().smbv_debug_set_variant(args.debug_variant)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -502,7 +540,7 @@ def main():
     dp = None
     if world > 1:
         from smb_vision_amd.dp import DataParallelEngine
-        dp = DataParallelEngine(model)
+        dp = DataParallelEngine(model, grad_dtype=args.dp_grad_dtype)
         dp.broadcast_parameters(model)
 
     def train(pixel_values, **mask_kw):

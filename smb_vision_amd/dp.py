@@ -56,10 +56,30 @@ def allreduce_mean_(flat: torch.Tensor, group=None, force: bool = False):
     return None
 
 
+def allreduce_mean_bf16_(flat: torch.Tensor, group=None, force: bool = False):
+    """The bf16-compressed exchange (DDP's ``bf16_compress_hook``): cast the fp32 slice to bf16, average THAT over the ranks, write the
+    result back as fp32 - half the bytes on the links (194 MB instead of 389 MB per ViT-base step).  Every rank receives the same bf16 values (one reduction
+    order per element in a ring / tree), so replicas stay bit-identical; against the fp32 average the result is off by the bf16 rounding of each rank's
+    addend and of the mean (relative 2^-8 per element at worst, tests/test_dp_cpu.py).  Stream-ordered: call it under the stream that should carry the casts."""
+    world = dist.get_world_size(group)
+    if world == 1 and not force:
+        return
+    buf = flat.to(torch.bfloat16)
+    if flat.is_cuda and "nccl" in str(dist.get_backend(group)).lower():
+        dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group, async_op=True).wait()  # the CURRENT stream waits for RCCL's stream; the host does not
+        flat.copy_(buf)
+    else:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(buf.float().mul_(1.0 / world).to(torch.bfloat16))  # the mean rounded to bf16, as the AVG collective delivers it
+
+
 class DataParallelEngine:
-    def __init__(self, model, group=None, bucket_bytes: int = 32 << 20, overlap: bool = True, force_collectives: bool = False):
+    def __init__(self, model, group=None, bucket_bytes: int = 32 << 20, overlap: bool = True, force_collectives: bool = False, grad_dtype: str = "fp32"):
         if not dist.is_initialized():
             raise RuntimeError("DataParallelEngine needs torch.distributed to be initialised (one process per GPU)")
+        if grad_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"grad_dtype must be 'fp32' or 'bf16', got {grad_dtype!r}")
+        self.grad_dtype = grad_dtype  # what travels over xGMI; the arena, the clip and AdamW stay fp32
         self.group = group
         self.world = dist.get_world_size(group)
         self.bucket_elems = max(1, bucket_bytes // 4)
@@ -104,7 +124,9 @@ class DataParallelEngine:
         self._ranges = ranges
         self._buckets = merge_ranges(ranges, self.bucket_elems)
         if model.flat_grads().is_cuda and self.overlap:
-            self.comm_stream = torch.cuda.Stream(device=model.flat_grads().device)
+            # highest priority: the casts / copies of the communication stream (and, with TORCH_NCCL_HIGH_PRIORITY=1 - bench.py and SmbTrainer set it before the
+            # process group exists - RCCL's own kernels) are dispatched ahead of the backward's queued blocks instead of behind 0.5-2 ms attention launches
+            self.comm_stream = torch.cuda.Stream(device=model.flat_grads().device, priority=-1)
             self._events = []
             for _ in ranges:
                 ev = torch.cuda.Event()
@@ -120,12 +142,6 @@ class DataParallelEngine:
             return None, 0
         return self._ev_array, len(self._events)
 
-    def record_all(self):
-        """For a model whose backward call does not record per-group events (V-JEPA): mark every group complete at this point of the
-        current stream, i.e. gate all buckets on the end of the backward."""
-        for ev in self._events:
-            ev.record(torch.cuda.current_stream())
-
     def prepare(self, model):
         if self._buckets is None:
             self._setup(model)
@@ -138,6 +154,10 @@ class DataParallelEngine:
             return
         force = self.force_collectives
         if self.comm_stream is None:  # no overlap (or CPU tensors in the gloo tests): plain bucketed all-reduce
+            if self.grad_dtype == "bf16":
+                for a, b, _ in self._buckets:
+                    allreduce_mean_bf16_(flat[a:b], self.group, force)
+                return
             works = [allreduce_mean_(flat[a:b], self.group, force) for a, b, _ in self._buckets]
             for w in works:
                 if w is not None:
@@ -154,7 +174,10 @@ class DataParallelEngine:
             for a, b, last in self._buckets:
                 self.enqueue_lead.append(not self._events[last].query())
                 self.comm_stream.wait_event(self._events[last])
-                works.append(allreduce_mean_(flat[a:b], self.group, force))
+                if self.grad_dtype == "bf16":
+                    allreduce_mean_bf16_(flat[a:b], self.group, force)  # cast -> AVG -> cast back, all ordered by the communication stream
+                else:
+                    works.append(allreduce_mean_(flat[a:b], self.group, force))
         with torch.cuda.stream(main):
             for w in works:
                 if w is not None:

@@ -98,8 +98,10 @@ def _is_native(model) -> bool:
 
 
 class SmbTrainer(Trainer):
-    def __init__(self, *args, dp_bucket_bytes: int = 32 << 20, **kwargs):
+    def __init__(self, *args, dp_bucket_bytes: int = 32 << 20, dp_grad_dtype: str = None, **kwargs):
         self._dp_bucket_bytes = dp_bucket_bytes
+        # what the gradient all-reduce ships: "fp32" (default, DDP's plain buckets) or "bf16" (DDP's bf16_compress_hook: half the xGMI bytes); SMBV_DP_GRAD_DTYPE
+        self._dp_grad_dtype = dp_grad_dtype or os.environ.get("SMBV_DP_GRAD_DTYPE", "fp32")
         self.dp_engine = None
         super().__init__(*args, **kwargs)
 
@@ -124,7 +126,8 @@ class SmbTrainer(Trainer):
         force = os.environ.get("SMBV_DP_FORCE_COLLECTIVES", "0") == "1"  # keep the collective path alive at world size 1 (a one-GPU rehearsal of the RCCL path)
         if _is_native(model) and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force) and self.dp_engine is None:
             overlap = "nccl" in str(dist.get_backend()).lower()  # the side-stream overlap needs RCCL's stream-ordered collectives
-            self.dp_engine = DataParallelEngine(model, bucket_bytes=self._dp_bucket_bytes, overlap=overlap, force_collectives=force)
+            self.dp_engine = DataParallelEngine(model, bucket_bytes=self._dp_bucket_bytes, overlap=overlap, force_collectives=force,
+                                                grad_dtype=self._dp_grad_dtype)
             self.dp_engine.broadcast_parameters(model)
         return out
 

@@ -229,6 +229,25 @@ def test_run_mim_under_a_two_process_launch_keeps_replicas_in_sync(tmp_path):
     assert moved > 0.9 * len(s0["final"])
 
 
+def test_bench_launches_its_own_ranks_without_a_launcher():
+    """`python3 bench.py --gpus 2 ...` exactly as the driver starts it - no torch.distributed.run in front, WORLD_SIZE unset: the parent (which makes no GPU
+    call) starts the two ranks as children, relays rank 0's ONE JSON line and returns their exit code.  gloo, both ranks on the one GPU (RCCL needs one
+    device per rank; the 8-GPU curve is the driver's)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--no-extra-configs", "--no-trainer", "--no-feed"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["replicas_in_sync"] is True and line["config"]["parallelism"] == "dp2"
+    assert line["steps"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and line["roofline"]["frac"] > 0
+    # a rank that fails must fail the launch: an unknown backend makes every rank raise in init_process_group
+    bad = subprocess.run([a if a != "gloo" else "no-such-backend" for a in cmd], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and not bad.stdout.strip()
+
+
 def _rccl_world1_worker(port, q, which):
     """One rank, backend "nccl" (= RCCL): the engine's overlap path with the collectives forced on at world size 1 - per-group HIP events recorded by
     smbv_*_backward, the communication stream waiting on them bucket by bucket, ``all_reduce(AVG, async_op=True)`` under that stream, the compute
@@ -241,7 +260,8 @@ def _rccl_world1_worker(port, q, which):
     try:
         from smb_vision_amd.dp import DataParallelEngine
         from smb_vision_amd.optim import SmbvAdamW
-        if which == "mim":
+        grad_dtype = "bf16" if which.endswith("-bf16") else "fp32"
+        if which.startswith("mim"):
             model = _mim_model(100)
             pix, mask = _mim_batch(10)
             fn = lambda: model(pixel_values=pix, bool_masked_pos=mask).loss
@@ -257,11 +277,14 @@ def _rccl_world1_worker(port, q, which):
             cm, tm = perm[: n // 2].sort().values[None].repeat(2, 1).cuda(), perm[n // 2:].sort().values[None].repeat(2, 1).cuda()
             fn = lambda: model(pixel_values_videos=pix, context_mask=[cm], target_mask=[tm]).predictor_output.last_hidden_state.square().mean()
         plain = _single_grads(model, fn)                                  # no engine attached
-        dp = DataParallelEngine(model, overlap=True, bucket_bytes=1 << 16, force_collectives=True)
+        dp = DataParallelEngine(model, overlap=True, bucket_bytes=1 << 16, force_collectives=True, grad_dtype=grad_dtype)
         dp.broadcast_parameters(model)                                     # RCCL broadcast (identity at world 1)
         through = _single_grads(model, fn)                                 # events -> comm stream -> all_reduce(AVG, async) -> join
         n_buckets = len(dp._buckets)
-        same = all(torch.equal(a, b) for a, b in zip(plain, through))
+        if grad_dtype == "bf16":   # cast -> AVG over one rank -> cast back: exactly the bf16 rounding of the fp32 gradients, still fp32 tensors
+            same = all(torch.equal(a.bfloat16().float(), b) and b.dtype == torch.float32 for a, b in zip(plain, through))
+        else:
+            same = all(torch.equal(a, b) for a, b in zip(plain, through))
         opt = SmbvAdamW(model.parameters(), lr=1e-3, max_grad_norm=1.0)
         before = [p.detach().clone() for p in model.parameters()]
         for _ in range(3):                                                 # three full steps: backward + collectives + optimizer, no deadlock
@@ -276,7 +299,7 @@ def _rccl_world1_worker(port, q, which):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("which", ["mim", "vjepa"])
+@pytest.mark.parametrize("which", ["mim", "vjepa", "mim-bf16"])
 def test_rccl_collective_path_runs_on_hardware_at_world_size_one(which):
     """the RCCL lines of dp.py (ReduceOp.AVG with async_op under the side stream, the event-gated bucket loop) execute on an MI355X:
     backend "nccl" at world size 1 with DataParallelEngine(force_collectives=True).  An averaging all-reduce over one rank is the identity, so the

@@ -105,6 +105,57 @@ def test_bucketed_allreduce_world2_gloo():
     assert len(sums) == 2 and abs(sums[0] - sums[1]) < 1e-5  # both ranks hold the same averaged gradients
 
 
+def _worker_bf16(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 1000
+        ranges = [(900, 1000), (700, 900), (600, 700), (300, 600), (100, 300), (0, 100)]
+        model = FakeModel(n, ranges)
+        eng = DataParallelEngine(model, bucket_bytes=4 * 250, grad_dtype="bf16")
+        local = torch.randn(n, generator=torch.Generator().manual_seed(100 + rank)) * (10.0 ** torch.randint(-6, 3, (n,), generator=torch.Generator().manual_seed(7)))
+        model.flat_grads().copy_(local)
+        eng.allreduce_after_backward(model)
+        got = model.flat_grads().clone()
+        ref = local.clone()
+        allreduce_mean_(ref)                      # the fp32 average
+        both = [torch.empty_like(got) for _ in range(world)]
+        dist.all_gather(both, got)
+        identical = all(torch.equal(both[0], b) for b in both)
+        # stated tolerance: each addend and the mean are rounded to bf16 (8 significant bits): |got - ref| <= 2^-8 (|g_0| + ... + |g_{w-1}|) / w + 2^-8 |ref|
+        mags = local.abs().clone()
+        allreduce_mean_(mags)
+        bound = 2.0 ** -8 * (mags + ref.abs()) + 1e-30
+        q.put((rank, identical, bool(((got - ref).abs() <= bound).all()), got.dtype == torch.float32,
+               float(((got - ref).norm() / ref.norm()))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_compressed_allreduce_world2_gloo_keeps_replicas_identical():
+    """grad_dtype="bf16" (the reference stack's DDP bf16_compress_hook option): replicas bit-identical, every element within the two bf16
+    roundings of the fp32 average, the arena itself stays fp32."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bf16, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = [q.get(timeout=10) for _ in range(2)]
+    for _, identical, within, fp32, rel in res:
+        assert identical and within and fp32
+        assert rel <= 2.0 ** -7
+
+
+def test_grad_dtype_is_validated():
+    with pytest.raises((RuntimeError, ValueError)):
+        DataParallelEngine(FakeModel(4, [(0, 4)]), grad_dtype="fp16")
+
+
 def test_engine_requires_process_group():
     with pytest.raises(RuntimeError):
         DataParallelEngine(FakeModel(4, [(0, 4)]))
