@@ -8,9 +8,11 @@ dataclasses → dataset → ``VideoMAEConfig`` patched with ``num_channels=1, nu
 
 * the model is ``SmbVideoMAEForPreTraining`` (HIP kernels behind the same interface) and the ``Trainer`` is ``SmbTrainer`` (``trainer.py``): under a
   one-process-per-GPU launch it averages gradients over RCCL itself (replacing ``acc_configs/multi_gpu_config.yaml``) and runs the fused optimizer tail;
-* the dataset here is synthetic and in-memory (``SyntheticVolumeDataset``: U[0,1) volumes in the post-``ScaleIntensityRanged`` range,
-  ``(D,1,H,W)`` layout of ``PermuteImage``, masks from the bit-exact ``MaskGenerator``): NIfTI/MONAI ingestion is out of scope
-  (SURVEY.md §2.1) and absent from this image; plug a real dataset in by returning the same two keys;
+* the dataset is either ``--volume_cache_dir`` (a directory of ``.smbvol`` files, ``volcache.py``: raw int16 volumes read into the feeder's page-locked ring,
+  uploaded and scaled / padded / cropped / permuted on the device - the role of ``--json_path`` / ``--cache_dir``, ``src/run_mim.py:61, 140-143, 279-290``)
+  or synthetic and in-memory (``SyntheticVolumeDataset``: U[0,1) volumes in the post-``ScaleIntensityRanged`` range, ``(D,1,H,W)`` layout of
+  ``PermuteImage``, masks from the bit-exact ``MaskGenerator``): NIfTI reading / resampling is out of scope (nibabel / MONAI are absent
+  from this image); any dataset returning the reference's two keys (``image``, ``mask``) plugs in as well;
 * nothing touches the network (no telemetry, no hub names: pass local paths only).
 
     python -m smb_vision_amd.run_mim --output_dir /tmp/mim --image_size 64 --depth 32 --patch_size 16 --mask_patch_size 16 \
@@ -54,6 +56,11 @@ class DataTrainingArguments:
     num_train_volumes: int = field(default=16, metadata={"help": "Synthetic volumes per epoch."})
     num_eval_volumes: int = field(default=2, metadata={"help": "Synthetic validation volumes (used with --do_eval / --eval_strategy)."})
     data_seed_offset: int = field(default=1234, metadata={"help": "Seed of the synthetic volumes."})
+    volume_cache_dir: Optional[str] = field(default=None, metadata={"help": "Directory of .smbvol files (smb_vision_amd.volcache) to train on instead of synthetic "
+                                            "volumes: the role of the reference's --json_path / --cache_dir (src/run_mim.py:61, 140-143, 279-290)."})
+    eval_volume_cache_dir: Optional[str] = field(default=None, metadata={"help": "Directory of .smbvol files for evaluation (else synthetic validation volumes)."})
+    fresh_masks: bool = field(default=False, metadata={"help": "With --volume_cache_dir: draw a new mask per visit from the global numpy stream instead of one "
+                                                       "fixed mask per sample (the reference's PersistentDataset caches the mask with the image)."})
 
 
 @dataclass
@@ -96,14 +103,30 @@ class SyntheticVolumeDataset(Dataset):
         return {"image": torch.rand(self.depth, 1, self.image_size, self.image_size, generator=g), "mask": mask}
 
 
+def unwrap_examples(examples):
+    """``src/run_mim.py:195-202`` / ``src/run_vjepa.py:145-152``: MONAI datasets hand items over wrapped in singleton lists (``[item]``, ``[[item]]``);
+    peel them until the dictionary appears."""
+    out = []
+    for ex in examples:
+        while isinstance(ex, (list, tuple)) and len(ex) == 1:
+            ex = ex[0]
+        out.append(ex)
+    return out
+
+
 def collate_fn(examples):
-    """``src/run_mim.py:194-219``."""
+    """``src/run_mim.py:194-219``.  Items that carry a raw cached volume (``"volume"``: ``volcache.CachedVolumeDataset``) instead of an ``"image"`` travel on
+    as ``feed.RAW_KEY``; the trainer's loader turns them into ``pixel_values`` on the device (``trainer.VolumeFeedLoader``)."""
+    examples = unwrap_examples(examples)
+    mask = torch.stack([e["mask"] for e in examples])
+    vis, msk = split_mask_indices_host(mask)
+    if "image" not in examples[0] and "volume" in examples[0]:
+        from .feed import RAW_KEY
+        return {RAW_KEY: [e["volume"] for e in examples], "bool_masked_pos": mask, "visible_index": vis, "masked_index": msk}
     # (a batch of one is a view, not a 335 MB copy: a page-locked volume stays page-locked for the upload)
     pixel_values = examples[0]["image"].unsqueeze(0) if len(examples) == 1 else torch.stack([e["image"] for e in examples])
-    mask = torch.stack([e["mask"] for e in examples])
     # extra keys for the HIP path: the two ascending token lists the reference derives with boolean indexing (spec :134-137, :811-812),
     # built here on the host from the mask that was just generated (the model otherwise sorts on the device every step)
-    vis, msk = split_mask_indices_host(mask)
     return {"pixel_values": pixel_values, "bool_masked_pos": mask, "visible_index": vis, "masked_index": msk}
 
 
@@ -122,9 +145,21 @@ def build_trainer(argv=None):
     gen = MaskGenerator(input_size=data_args.image_size, depth=data_args.depth, mask_patch_size=data_args.mask_patch_size,
                         model_patch_size=data_args.patch_size, mask_ratio=data_args.mask_ratio)
     np.random.seed(training_args.seed)
-    train = SyntheticVolumeDataset(data_args.num_train_volumes, data_args.image_size, data_args.depth, gen, data_args.data_seed_offset)
+    if not training_args.do_train and not training_args.do_eval:
+        training_args.do_train = True   # a bare invocation trains, as this harness always did; `--do_eval true` alone only evaluates (src/run_mim.py:439, 452)
+    if data_args.volume_cache_dir:      # real volumes from disk: raw int16 over PCIe, scaled / padded / cropped / permuted on the device (feed.py)
+        from .volcache import CachedVolumeDataset
+        train = CachedVolumeDataset(data_args.volume_cache_dir, mask_generator=gen, mask_seed=None if data_args.fresh_masks else data_args.data_seed_offset)
+        train.smbv_raw_volumes = True
+    else:
+        train = SyntheticVolumeDataset(data_args.num_train_volumes, data_args.image_size, data_args.depth, gen, data_args.data_seed_offset)
     evaluating = training_args.do_eval or str(getattr(training_args.eval_strategy, "value", training_args.eval_strategy)) != "no"
-    val = SyntheticVolumeDataset(data_args.num_eval_volumes, data_args.image_size, data_args.depth, gen, data_args.data_seed_offset + 1_000_003) if evaluating else None
+    val = None
+    if evaluating and data_args.eval_volume_cache_dir:
+        from .volcache import CachedVolumeDataset
+        val = CachedVolumeDataset(data_args.eval_volume_cache_dir, mask_generator=gen, mask_seed=data_args.data_seed_offset + 1_000_003)
+    elif evaluating:
+        val = SyntheticVolumeDataset(data_args.num_eval_volumes, data_args.image_size, data_args.depth, gen, data_args.data_seed_offset + 1_000_003)
 
     config = VideoMAEConfig.from_pretrained(model_args.config_name_or_path) if model_args.config_name_or_path else VideoMAEConfig()
     config.update({"num_channels": 1, "num_frames": data_args.depth, "tubelet_size": data_args.patch_size, "image_size": data_args.image_size,

@@ -70,11 +70,17 @@ class SmbVJEPATrainer(SmbTrainer):
 def collate_fn(examples, num_patches=0):
     """run_vjepa.py:144-160: stack the volumes; ONE random example's masks for every row; masks wrapped in 1-element lists.
     ``num_patches`` (the model's token count; the harness binds it with functools.partial): also ship the step's index arrays, see below."""
-    pixel_values = torch.stack([ex["image"] for ex in examples])
+    from .run_mim import unwrap_examples
+    examples = unwrap_examples(examples)   # run_vjepa.py:145-152: singleton-list wrappers of MONAI datasets
     ex = random.choice(examples)
     context_mask = torch.stack([ex["context_mask"] for _ in examples])
     target_mask = torch.stack([ex["target_mask"] for _ in examples])
-    batch = {"pixel_values_videos": pixel_values, "context_mask": [context_mask], "target_mask": [target_mask]}
+    if "image" not in examples[0] and "volume" in examples[0]:   # raw cached volumes (--volume_cache_dir): converted on the device by the trainer's loader
+        from .feed import RAW_KEY
+        batch = {RAW_KEY: [e["volume"] for e in examples]}
+    else:
+        batch = {"pixel_values_videos": torch.stack([e["image"] for e in examples])}
+    batch.update({"context_mask": [context_mask], "target_mask": [target_mask]})
     n_tokens = num_patches
     if n_tokens and context_mask.shape[1] < n_tokens and target_mask.shape[1] < n_tokens:
         # the index arithmetic of the step (sorted predictor slots, the encoder's [consumed | other] token order) done here, on the host, by the
@@ -106,6 +112,23 @@ class SyntheticVJEPADataset(Dataset):
             torch.random.set_rng_state(state)
 
 
+class _SeededMasks:
+    """``item_transform`` for ``volcache.CachedVolumeDataset``: the V-JEPA masks of a cached volume, one fixed pair per FILE (the generator draws from torch's
+    GLOBAL stream, transforms.py:168-170; seeded by the file's name so that the pair does not depend on the visiting order; the stream is left as found)."""
+
+    def __init__(self, gen, seed):
+        self.gen, self.seed = gen, seed
+
+    def __call__(self, item):
+        import zlib
+        state = torch.random.get_rng_state()
+        torch.manual_seed(self.seed + zlib.crc32(os.path.basename(item["volume"].path).encode()))
+        try:
+            return self.gen(item)
+        finally:
+            torch.random.set_rng_state(state)
+
+
 @dataclass
 class DataTrainingArguments:
     image_size: int = field(default=224, metadata={"help": "crop size (H == W)"})
@@ -114,6 +137,9 @@ class DataTrainingArguments:
     num_mask_blocks: int = field(default=3)
     num_train_volumes: int = field(default=16)
     num_eval_volumes: int = field(default=2)
+    volume_cache_dir: Optional[str] = field(default=None, metadata={"help": "Directory of .smbvol files (smb_vision_amd.volcache) to train on instead of synthetic "
+                                            "volumes: the role of the reference's --data_path / --cache_dir (src/run_vjepa.py:44, 69, 207-218)."})
+    eval_volume_cache_dir: Optional[str] = field(default=None)
 
 
 @dataclass
@@ -142,9 +168,21 @@ def main(argv=None):
     # grid in the model's token order (D', H', W'): see SURVEY.md Appendix A.8 on the reference generator's axis naming
     gen = VJEPAMaskGenerator(input_size=(dargs.depth, dargs.image_size, dargs.image_size), patch_size=(dargs.patch_size,) * 3,
                              pred_mask_scale=(0.2, 0.8), aspect_ratio=(0.3, 3.0), num_blocks=dargs.num_mask_blocks)
-    train = SyntheticVJEPADataset(dargs.num_train_volumes, dargs.image_size, dargs.depth, gen, 1234)
+    if not targs.do_train and not targs.do_eval:
+        targs.do_train = True   # a bare invocation trains; `--do_eval true` alone only evaluates (src/run_vjepa.py:259, 272)
+    if dargs.volume_cache_dir:
+        from .volcache import CachedVolumeDataset
+        train = CachedVolumeDataset(dargs.volume_cache_dir, item_transform=_SeededMasks(gen, 1234))
+        train.smbv_raw_volumes = True
+    else:
+        train = SyntheticVJEPADataset(dargs.num_train_volumes, dargs.image_size, dargs.depth, gen, 1234)
     evaluating = targs.do_eval or str(getattr(targs.eval_strategy, "value", targs.eval_strategy)) != "no"
-    val = SyntheticVJEPADataset(dargs.num_eval_volumes, dargs.image_size, dargs.depth, gen, 1_001_237) if evaluating else None
+    val = None
+    if evaluating and dargs.eval_volume_cache_dir:
+        from .volcache import CachedVolumeDataset
+        val = CachedVolumeDataset(dargs.eval_volume_cache_dir, item_transform=_SeededMasks(gen, 1_001_237))
+    elif evaluating:
+        val = SyntheticVJEPADataset(dargs.num_eval_volumes, dargs.image_size, dargs.depth, gen, 1_001_237)
     # eval_dataset / compute_metrics as src/run_vjepa.py:249-256; auto-resume and the train / save / evaluate tail as :191-205, 258-275 (the EMA target
     # encoder lives on the trainer and is NOT part of a checkpoint - the reference's behaviour: a resumed run re-copies it from the restored online weights)
     trainer = SmbVJEPATrainer(model=model, args=targs, train_dataset=train, eval_dataset=val, data_collator=functools.partial(collate_fn, num_patches=model.num_patches),

@@ -93,6 +93,50 @@ class DevicePrefetcher:
             pending = nxt
 
 
+class VolumeFeedLoader:
+    """Wraps a DataLoader whose batches carry RAW volumes (``feed.RAW_KEY``: tensors, arrays or ``volcache.VolumeRecord`` - what ``run_mim`` / ``run_vjepa``
+    build under ``--volume_cache_dir``, the role of the reference's ``--json_path`` / ``--cache_dir``: ``src/run_mim.py:61, 140-143, 279-290``) and uploads
+    them through ``feed.VolumeFeeder``: files are read straight into the feeder's page-locked ring by its host thread, travel over PCIe in their storage
+    dtype on the copy stream and are scaled / padded / cropped / permuted on the device (``smbv_prepare_volume``) one batch ahead of the step.  Yields
+    the loader's batch with ``out_key`` = fp32 ``[B, depth, 1, image_size, image_size]`` in place of the raw volumes and every other tensor on the device.
+    Length, sampler, ``set_epoch`` ... are the wrapped loader's."""
+
+    def __init__(self, loader, device, image_size, depth, out_key="pixel_values"):
+        from .feed import VolumeFeeder
+        self.loader, self.device, self.out_key = loader, torch.device(device), out_key
+        # fresh outputs: HF fetches every micro-batch of an accumulation step before computing the first, so several batches are alive at once
+        self.feeder = VolumeFeeder((), self.device, image_size, depth, record_window=True, fresh_outputs=True)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __getattr__(self, name):
+        return getattr(self.loader, name)
+
+    def __iter__(self):
+        from .feed import RAW_KEY
+
+        def source():
+            for batch in self.loader:
+                batch = dict(batch)
+                yield batch.pop(RAW_KEY), batch
+
+        def move(x):
+            if torch.is_tensor(x):
+                return x.to(self.device, non_blocking=True)
+            if isinstance(x, dict):
+                return {k: move(v) for k, v in x.items()}
+            if isinstance(x, (list, tuple)):
+                return type(x)(move(v) for v in x)
+            return x
+
+        self.feeder.source = source()
+        for pix, rest in self.feeder:
+            out = move(rest)          # masks and index lists: a few hundred KB on the compute stream
+            out[self.out_key] = pix
+            yield out
+
+
 def _is_native(model) -> bool:
     return hasattr(model, "flat_grads") and hasattr(model, "grad_group_ranges")
 
@@ -143,7 +187,40 @@ class SmbTrainer(Trainer):
             loader = super().get_train_dataloader()
         finally:
             self.accelerator.device_placement = placement
-        return DevicePrefetcher(loader, next(self.model.parameters()).device)
+        device = next(self.model.parameters()).device
+        if getattr(self.train_dataset, "smbv_raw_volumes", False):   # items are raw volumes / cache records: upload through the VolumeFeeder
+            size, depth, key = self._volume_geometry()
+            return VolumeFeedLoader(loader, device, size, depth, out_key=key)
+        return DevicePrefetcher(loader, device)
+
+    def _volume_geometry(self):
+        """(image_size, depth, name of the model's volume argument) from the model's config: VideoMAE names them image_size / num_frames
+        (``src/run_mim.py:302-330``), V-JEPA crop_size / frames_per_clip (``src/run_vjepa.py:221-233``)."""
+        c = self.model.config
+        if hasattr(c, "crop_size"):
+            return int(c.crop_size), int(c.frames_per_clip), "pixel_values_videos"
+        return int(c.image_size), int(c.num_frames), "pixel_values"
+
+    def _prepare_inputs(self, inputs):
+        """A batch that still carries raw volumes (evaluation; the first, partial epoch of a resumed run, for which HF rebuilds a plain DataLoader behind
+        the wrapper): the feeder's conversion inline on the compute stream - same kernel, same bits, no overlap."""
+        from .feed import RAW_KEY, raw_batch_to_device
+        if isinstance(inputs, dict) and RAW_KEY in inputs:
+            inputs = dict(inputs)
+            size, depth, key = self._volume_geometry()
+            inputs[key] = raw_batch_to_device(inputs.pop(RAW_KEY), next(self.model.parameters()).device, size, depth)
+        return super()._prepare_inputs(inputs)
+
+    def _save_checkpoint(self, *args, **kwargs):
+        """No checkpoint of weights a faulted step has touched: the library's sticky status word is set by a kernel that detects a fault it cannot
+        return (``smbv_device_status``); it is read here after a device synchronisation, BEFORE anything is written - an auto-resume must never pick up a
+        checkpoint whose last update consumed incomplete gradients."""
+        if _is_native(self.model) and next(self.model.parameters()).is_cuda:
+            from . import _lib, ops
+            torch.cuda.synchronize()
+            if ops.device_status() != 0:
+                raise _lib.SmbvError(f"refusing to write a checkpoint: a kernel of an earlier step recorded a fault on this device ({_lib.last_error()})")
+        return super()._save_checkpoint(*args, **kwargs)
 
     # -- decay grouping -------------------------------------------------------------------------------------------------------------------
     def get_decay_parameter_names(self, model):
@@ -210,7 +287,7 @@ def detect_last_checkpoint(training_args, logger=None):
     from transformers.trainer_utils import get_last_checkpoint
     last = None
     out = training_args.output_dir
-    if out and os.path.isdir(out) and not getattr(training_args, "overwrite_output_dir", False):
+    if out and os.path.isdir(out) and training_args.do_train and not getattr(training_args, "overwrite_output_dir", False):
         last = get_last_checkpoint(out)
         if last is None and len(os.listdir(out)) > 0 and hasattr(training_args, "overwrite_output_dir"):
             raise ValueError(f"Output directory ({out}) already exists and is not empty. Use --overwrite_output_dir to overcome.")
@@ -222,13 +299,15 @@ def detect_last_checkpoint(training_args, logger=None):
 def train_and_evaluate(trainer, training_args, last_checkpoint=None):
     """The tail both reference scripts share (``src/run_mim.py:439-455``, ``src/run_vjepa.py:258-275``): ``train(resume_from_checkpoint=...)`` with the
     explicit checkpoint first, the detected one second; ``save_model`` / metrics / state; ``evaluate()`` under ``--do_eval``."""
-    checkpoint = training_args.resume_from_checkpoint if training_args.resume_from_checkpoint is not None else last_checkpoint
-    result = trainer.train(resume_from_checkpoint=checkpoint)
-    trainer.save_model()
-    trainer.log_metrics("train", result.metrics)
-    trainer.save_metrics("train", result.metrics)
-    trainer.save_state()
-    metrics = dict(result.metrics)
+    metrics = {}
+    if training_args.do_train:   # src/run_mim.py:440 / src/run_vjepa.py:259: `--do_eval` alone evaluates, it neither trains nor overwrites output_dir
+        checkpoint = training_args.resume_from_checkpoint if training_args.resume_from_checkpoint is not None else last_checkpoint
+        result = trainer.train(resume_from_checkpoint=checkpoint)
+        trainer.save_model()
+        trainer.log_metrics("train", result.metrics)
+        trainer.save_metrics("train", result.metrics)
+        trainer.save_state()
+        metrics.update(result.metrics)
     if training_args.do_eval and trainer.eval_dataset is not None:
         ev = trainer.evaluate()
         trainer.log_metrics("eval", ev)

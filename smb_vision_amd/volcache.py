@@ -154,3 +154,47 @@ class CachedVolumeSource:
                     m = self.mask_generator()
                 yield rec, {"path": p, "mask": m}
             e += 1
+
+
+class CachedVolumeDataset(torch.utils.data.Dataset):
+    """Map-style dataset over a directory (or list) of ``.smbvol`` files: the role of ``MIMDataset(json_path, cache_dir).setup("train")``
+    (``src/run_mim.py:279-290``, ``src/dataloader/load.py:70-142``) for the harnesses' ``--volume_cache_dir``.  An item is
+    ``{"volume": VolumeRecord, "mask": bool[N]}`` - the RECORD, not the voxels: the trainer's loader (``trainer.VolumeFeedLoader``) reads the file straight
+    into the feeder's page-locked ring and scales / pads / crops / permutes on the device, so a DataLoader worker never touches (or pickles) 168-335 MB.
+
+    Masks: the one the file stores if it stores one (the reference's cached-mask behaviour); else, with ``mask_generator``, a draw from the legacy numpy
+    stream seeded with ``mask_seed + index`` (a fixed mask per sample as well - and what lets a resumed run see the uninterrupted run's batches), or a
+    fresh draw from the GLOBAL stream per visit when ``mask_seed`` is None.  ``item_transform`` (e.g. ``VJEPAMaskGenerator``) is applied to the item last."""
+
+    def __init__(self, source, mask_generator=None, mask_seed: Optional[int] = 0, item_transform=None):
+        if isinstance(source, (str, os.PathLike)):
+            d = os.fspath(source)
+            if not os.path.isdir(d):
+                raise FileNotFoundError(f"volume cache directory {d!r} does not exist")
+            self.paths = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".smbvol"))
+            if not self.paths:
+                raise FileNotFoundError(f"no .smbvol files in {d!r}")
+        else:
+            self.paths = [os.fspath(p) for p in source]
+        self.mask_generator, self.mask_seed, self.item_transform = mask_generator, mask_seed, item_transform
+
+    def __len__(self):
+        return len(self.paths)
+
+    def __getitem__(self, i):
+        rec = open_volume(self.paths[i])
+        item = {"volume": rec}
+        m = rec.mask()
+        if m is None and self.mask_generator is not None:
+            if self.mask_seed is None:
+                m = self.mask_generator()
+            else:
+                state = np.random.get_state()
+                np.random.seed((self.mask_seed + i) % (2 ** 32))
+                try:
+                    m = self.mask_generator()
+                finally:
+                    np.random.set_state(state)
+        if m is not None:
+            item["mask"] = m
+        return self.item_transform(item) if self.item_transform is not None else item

@@ -140,6 +140,99 @@ def test_trainer_with_gradient_accumulation_matches_manual_loop(tmp_path):
         assert float((a - b).norm()) <= 1e-2 * upd, (k, float((a - b).norm()), upd)
 
 
+def test_stock_transformers_trainer_trains_the_native_model_as_integration_promises(tmp_path):
+    """"keep Trainer(...) unchanged, swap the model class" - the UNMODIFIED ``transformers.Trainer`` (accelerate's bf16 autocast wrap and
+    backward, its ``clip_grad_norm_`` on the arena-view gradients, torch's own AdamW, ``zero_grad``) drives ``SmbVideoMAEForPreTraining`` for three steps and
+    lands where ``SmbTrainer`` (fused clip + AdamW, copy-stream uploads) lands from the same start on the same batches.  Tolerance: per tensor, the two
+    runs' three-step UPDATES differ by <= 1e-2 of the update (fused vs torch optimizer arithmetic differs by an ulp after step 1; a dropped clip, a missing
+    decay group or a stale gradient moves it by O(1))."""
+    from transformers import Trainer, TrainingArguments
+    from smb_vision_amd.run_mim import collate_fn
+    from smb_vision_amd.trainer import SmbTrainer
+    batches = [_mim_batch(s) for s in (1, 2, 3)]
+    data = [{"image": pix[i].cpu(), "mask": m[i].cpu()} for pix, m in batches for i in range(2)]
+
+    def run(cls, sub):
+        args = TrainingArguments(output_dir=str(tmp_path / sub), per_device_train_batch_size=2, max_steps=3, learning_rate=1e-3, lr_scheduler_type="constant",
+                                 weight_decay=0.05, max_grad_norm=1.0, report_to="none", save_strategy="no", bf16=True, dataloader_num_workers=0,
+                                 remove_unused_columns=False, logging_steps=1, seed=0, adam_beta2=0.95)
+        model = _mim_model(3)
+        start = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+        class InOrder(cls):
+            def _get_train_sampler(self, *a, **k):
+                return torch.utils.data.SequentialSampler(self.train_dataset)
+
+            def get_decay_parameter_names(self, m):   # the same decay split for both (SmbTrainer's: HF's own split of the reference classes, golden/decay_names.json)
+                return SmbTrainer.get_decay_parameter_names(self, m)
+
+        tr = InOrder(model=model, args=args, train_dataset=data, data_collator=collate_fn)
+        tr.train()
+        torch.cuda.synchronize()
+        losses = [h["loss"] for h in tr.state.log_history if "loss" in h]
+        norms = [h["grad_norm"] for h in tr.state.log_history if "grad_norm" in h]
+        return start, {k: v.detach().clone() for k, v in model.state_dict().items()}, losses, norms, tr
+
+    s0, stock, l_stock, n_stock, tr_stock = run(Trainer, "stock")
+    s1, ours, l_ours, n_ours, tr_ours = run(SmbTrainer, "smb")
+    from smb_vision_amd.optim import SmbvAdamW
+    assert not isinstance(getattr(tr_stock.optimizer, "optimizer", tr_stock.optimizer), SmbvAdamW)      # torch's optimizer really ran
+    assert isinstance(getattr(tr_ours.optimizer, "optimizer", tr_ours.optimizer), SmbvAdamW)
+    assert len(l_stock) == 3 and l_stock[0] == pytest.approx(l_ours[0], rel=1e-6) and l_stock[2] == pytest.approx(l_ours[2], rel=2e-3)
+    assert n_stock[0] == pytest.approx(n_ours[0], rel=1e-4)                                              # the same pre-clip global norm is logged
+    for k in s0:
+        assert torch.equal(s0[k], s1[k])
+        upd = float((stock[k] - s0[k]).norm())
+        assert upd > 0, k
+        assert float((stock[k] - ours[k]).norm()) <= 1e-2 * upd, (k, float((stock[k] - ours[k]).norm()), upd)
+
+
+def test_run_mim_trains_from_a_volume_cache_directory(tmp_path):
+    """``--volume_cache_dir`` (the role of the reference's --json_path / --cache_dir, src/run_mim.py:61, 140-143, 279-290): four steps over eight raw int16
+    volumes written by ``volcache`` (ragged shapes: padded and cropped on the device), read into the feeder's page-locked ring and uploaded through
+    ``VolumeFeeder``; the losses and the final weights equal - bit for bit - a run that is handed the SAME volumes as fp32 ``image`` tensors in memory
+    (prepared by the feed oracle) with the same masks.  Then an evaluation-only invocation over the same directory (raw batches converted inline)."""
+    from safetensors.torch import load_file
+    import oracle.feed_oracle as fo
+    from smb_vision_amd import run_mim, volcache as vc
+    cache = tmp_path / "cache"
+    os.makedirs(cache)
+    rng = np.random.default_rng(11)
+    raws = []
+    for i in range(8):
+        r = rng.integers(-1400, 1400, size=(56 + 5 * (i % 3), 70 - 4 * (i % 2), 28 + 3 * (i % 4)), dtype=np.int16)
+        vc.write_volume(str(cache / f"vol{i:02d}.smbvol"), r)
+        raws.append(r)
+    tiny = ["--image_size", "64", "--depth", "32", "--patch_size", "16", "--mask_patch_size", "16", "--mask_ratio", "0.6", "--per_device_train_batch_size", "2",
+            "--report_to", "none", "--bf16", "true", "--hidden_size", "128", "--num_hidden_layers", "2", "--num_attention_heads", "2", "--intermediate_size", "256",
+            "--decoder_hidden_size", "64", "--decoder_num_hidden_layers", "1", "--decoder_num_attention_heads", "1", "--decoder_intermediate_size", "128",
+            "--learning_rate", "1e-3", "--logging_steps", "1", "--max_grad_norm", "1.0", "--dataloader_num_workers", "0", "--save_strategy", "no", "--max_steps", "4",
+            "--seed", "3"]
+    tr_a = run_mim.build_trainer(["--output_dir", str(tmp_path / "a"), "--volume_cache_dir", str(cache), *tiny])
+    assert getattr(tr_a.train_dataset, "smbv_raw_volumes", False) and len(tr_a.train_dataset) == 8
+    from smb_vision_amd.trainer import VolumeFeedLoader
+    assert isinstance(tr_a.get_train_dataloader(), VolumeFeedLoader)
+    masks = [tr_a.train_dataset[i]["mask"] for i in range(8)]
+    tr_a.train()
+    tr_a.save_model()
+
+    tr_b = run_mim.build_trainer(["--output_dir", str(tmp_path / "b"), *tiny])
+    tr_b.train_dataset = [{"image": torch.from_numpy(fo.prepare_volume(raws[i], 64, 32)), "mask": masks[i]} for i in range(8)]
+    tr_b.train()
+    tr_b.save_model()
+    la = [h["loss"] for h in tr_a.state.log_history if "loss" in h]
+    lb = [h["loss"] for h in tr_b.state.log_history if "loss" in h]
+    assert len(la) == 4 and la == lb, (la, lb)
+    wa, wb = load_file(str(tmp_path / "a" / "model.safetensors")), load_file(str(tmp_path / "b" / "model.safetensors"))
+    assert all(torch.equal(wa[k], wb[k]) for k in wa)
+
+    # evaluation only: nothing trains, nothing is overwritten, the raw batches of the evaluation loader are converted inline
+    before = os.path.getmtime(tmp_path / "a" / "model.safetensors")
+    m = run_mim.main(["--output_dir", str(tmp_path / "a"), "--do_eval", "true", "--eval_volume_cache_dir", str(cache), "--model_name_or_path", str(tmp_path / "a"),
+                      "--per_device_eval_batch_size", "2", *tiny])
+    assert "train_loss" not in m and 0.0 < m["eval_loss"] < 2.0 and os.path.getmtime(tmp_path / "a" / "model.safetensors") == before
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -368,14 +368,81 @@ def test_resume_helpers_follow_the_reference_scripts(tmp_path):
     import types
     from transformers import EvalPrediction
     from smb_vision_amd.trainer import detect_last_checkpoint, keep_loss_only, loss_only_metrics
-    args = types.SimpleNamespace(output_dir=str(tmp_path / "run"), resume_from_checkpoint=None)
+    args = types.SimpleNamespace(output_dir=str(tmp_path / "run"), resume_from_checkpoint=None, do_train=True)
     assert detect_last_checkpoint(args) is None                           # no directory yet
     for n in (2, 10, 4):
         (tmp_path / "run" / f"checkpoint-{n}").mkdir(parents=True)
     assert detect_last_checkpoint(args).endswith("checkpoint-10")
+    args.do_train = False                                                  # src/run_mim.py:265: only a training run looks for checkpoints
+    assert detect_last_checkpoint(args) is None
+    args.do_train = True
     args.overwrite_output_dir = True                                       # (where the installed transformers still has the flag)
     assert detect_last_checkpoint(args) is None
     assert loss_only_metrics(EvalPrediction(predictions=(np.array([1.0, 3.0]), np.zeros((2, 4))), label_ids=None)) == {"loss": 2.0}
     assert loss_only_metrics(EvalPrediction(predictions=np.array([0.5]), label_ids=None)) == {"loss": 0.5}
     kept = keep_loss_only((torch.tensor(0.25), torch.zeros(2, 3, 4)), None)
     assert kept.shape == (1,) and float(kept[0]) == 0.25
+
+
+def test_collate_functions_unwrap_singleton_lists_as_the_reference_does(tmp_path):
+    """src/run_mim.py:195-202 / src/run_vjepa.py:145-152 ("common in MONAI/PyTorch datasets"): items arrive as ``item``, ``[item]`` or ``[[item]]``; a longer
+    list is NOT peeled (the reference's loop stops at len != 1).  Also: items that carry a cached-volume record instead of an image travel on as raw volumes."""
+    from smb_vision_amd import volcache as vc
+    from smb_vision_amd.feed import RAW_KEY
+    from smb_vision_amd.run_mim import collate_fn as mim_collate
+    from smb_vision_amd.run_vjepa import collate_fn as vj_collate
+    gen = MaskGenerator(32, 16, 16, 16, 0.5)
+    np.random.seed(0)
+    items = [{"image": torch.rand(16, 1, 32, 32, generator=torch.Generator().manual_seed(i)), "mask": gen()} for i in range(3)]
+    plain = mim_collate(items)
+    wrapped = mim_collate([[items[0]], [[items[1]]], (items[2],)])
+    assert set(plain) == {"pixel_values", "bool_masked_pos", "visible_index", "masked_index"}
+    assert all(torch.equal(plain[k], wrapped[k]) for k in plain)
+    assert plain["pixel_values"].shape == (3, 16, 1, 32, 32) and plain["bool_masked_pos"].dtype == torch.bool
+    with pytest.raises((TypeError, KeyError)):
+        mim_collate([[items[0], items[1]]])                                # a two-element list is not an item
+    one = mim_collate([[items[1]]])
+    assert torch.equal(one["pixel_values"][0], items[1]["image"]) and one["pixel_values"].shape[0] == 1
+
+    cm, tm = torch.arange(0, 5), torch.arange(5, 8)
+    vitems = [{"image": torch.rand(2, 1, 4, 4), "context_mask": cm, "target_mask": tm} for _ in range(2)]
+    a, b = vj_collate(vitems), vj_collate([[vitems[0]], [[vitems[1]]]])
+    assert torch.equal(a["pixel_values_videos"], b["pixel_values_videos"]) and torch.equal(a["context_mask"][0], b["context_mask"][0])
+
+    # raw cached volumes: the record travels, not the voxels
+    for i in range(2):
+        vc.write_volume(str(tmp_path / f"v{i}.smbvol"), np.full((8, 8, 4), i, dtype=np.int16))
+    ds = vc.CachedVolumeDataset(str(tmp_path), mask_generator=gen, mask_seed=3)
+    assert len(ds) == 2 and torch.equal(ds[1]["mask"], ds[1]["mask"]) and isinstance(ds[0]["volume"], vc.VolumeRecord)
+    raw = mim_collate([[ds[0]], ds[1]])
+    assert set(raw) == {RAW_KEY, "bool_masked_pos", "visible_index", "masked_index"} and [r.path for r in raw[RAW_KEY]] == ds.paths
+    with pytest.raises(FileNotFoundError):
+        vc.CachedVolumeDataset(str(tmp_path / "missing"))
+
+
+def test_eval_only_invocation_neither_trains_nor_looks_for_checkpoints(tmp_path):
+    """ADVICE r4 / src/run_mim.py:265, 439-455: `--do_eval true` without `--do_train` evaluates only."""
+    import types
+    from smb_vision_amd.trainer import train_and_evaluate
+
+    class T:
+        eval_dataset = [0]
+        calls = []
+
+        def train(self, **kw):
+            self.calls.append("train")
+            return types.SimpleNamespace(metrics={"train_loss": 1.0})
+
+        def evaluate(self):
+            self.calls.append("evaluate")
+            return {"eval_loss": 0.5}
+
+        def __getattr__(self, name):   # save_model, log_metrics, save_metrics, save_state
+            return lambda *a, **k: self.calls.append(name)
+
+    t = T()
+    m = train_and_evaluate(t, types.SimpleNamespace(do_train=False, do_eval=True, resume_from_checkpoint=None))
+    assert m == {"eval_loss": 0.5} and "train" not in t.calls and "save_model" not in t.calls and "evaluate" in t.calls
+    t.calls.clear()
+    m = train_and_evaluate(t, types.SimpleNamespace(do_train=True, do_eval=True, resume_from_checkpoint=None))
+    assert t.calls[0] == "train" and "save_model" in t.calls and m == {"train_loss": 1.0, "eval_loss": 0.5}

@@ -189,7 +189,7 @@ def test_hf_trainer_resumes_from_a_checkpoint_bit_identically_and_evaluates(tmp_
     assert os.path.isdir(a / "checkpoint-2") and os.path.isdir(a / "checkpoint-4")
     os.makedirs(b)
     shutil.copytree(a / "checkpoint-2", b / "checkpoint-2")
-    m_b = main(["--output_dir", str(b), "--max_steps", "4", "--save_strategy", "steps", "--save_steps", "2", "--do_eval", "true", "--num_eval_volumes", "4",
+    m_b = main(["--output_dir", str(b), "--max_steps", "4", "--save_strategy", "steps", "--save_steps", "2", "--do_train", "true", "--do_eval", "true", "--num_eval_volumes", "4",
                 "--per_device_eval_batch_size", "2", *_TINY_RUN])
     wa, wb = load_file(str(a / "model.safetensors")), load_file(str(b / "model.safetensors"))
     assert wa.keys() == wb.keys()

@@ -208,7 +208,7 @@ def test_hf_trainer_vjepa_resumes_and_evaluates(tmp_path):
     main(["--output_dir", str(a), "--max_steps", "4", *common])
     os.makedirs(b)
     shutil.copytree(a / "checkpoint-2", b / "checkpoint-2")
-    m = main(["--output_dir", str(b), "--max_steps", "4", "--do_eval", "true", "--per_device_eval_batch_size", "2", *common])
+    m = main(["--output_dir", str(b), "--max_steps", "4", "--do_train", "true", "--do_eval", "true", "--per_device_eval_batch_size", "2", *common])
     state = json.load(open(b / "trainer_state.json"))
     assert state["global_step"] == 4
     assert [h["step"] for h in state["log_history"] if "loss" in h][:4] == [1, 2, 3, 4]    # steps 1-2 restored from the checkpoint's history, 3-4 run here
