@@ -316,7 +316,7 @@ def vit_large_leg(device, steps=4, warmup=2):
     recompute; fwd + loss + bwd + clip + AdamW.  Returns ms per step."""
     from smb_vision_amd.optim import SmbvAdamW
     kw = dict(VIT_BASE, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, decoder_hidden_size=512,
-              decoder_num_hidden_layers=12, decoder_num_attention_heads=8, decoder_intermediate_size=2048, smbv_attention_fp8=True, smbv_recompute="always")
+              decoder_num_hidden_layers=12, decoder_num_attention_heads=8, decoder_intermediate_size=2048, smbv_attention_fp8="all", smbv_recompute="always")
     model, pix, mask, _ = build(0, device, kw)
     model.gradient_checkpointing_enable()
     opt = SmbvAdamW(list(model.parameters()), lr=1.5e-4, betas=(0.9, 0.95), weight_decay=0.05, max_grad_norm=1.0)
@@ -522,7 +522,7 @@ def main():
         cfg_kw.update(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, decoder_hidden_size=512,
                       decoder_num_hidden_layers=12, decoder_num_attention_heads=8, decoder_intermediate_size=2048)
     if args.fp8:
-        cfg_kw["smbv_attention_fp8"] = True
+        cfg_kw["smbv_attention_fp8"] = "all"
     if args.recompute:
         cfg_kw["smbv_recompute"] = "always"
     model, pix, mask, gen = build(rank, device, cfg_kw)

@@ -16,7 +16,9 @@
  *     smbv_last_error() returns the message of the calling thread's last failure; no C++ exception crosses the ABI;
  *   - stream-ordered; callable from any host thread (autograd's backward thread included), but the step / block / attention-backward entry
  *     points fork onto the per-device side streams below and are NOT safe to run from two host threads on the SAME device at once (the library
- *     serialises the fork / join bookkeeping with a per-device mutex; the side streams themselves are shared);
+ *     serialises EVERY record / wait on its per-device events with a per-device mutex - round 5: the deferred weight-gradient launches' completion
+ *     events included - so the runtime calls never overlap on one event and a re-recorded event only makes a wait cover a later point of the in-order side
+ *     stream; the side streams themselves are shared, i.e. two threads' steps serialise their side work and that is the extent of the support);
  *   - state inside the library: the immutable code object; a thread-local error string; per device, two private non-blocking side streams and a
  *     dozen events created on first use and kept for the life of the process (a block's weight-gradient products run as one grouped launch on a side
  *     stream beside the NEXT block's backward, the step forwards their weight casts beside the first kernels; everything forked is joined back into

@@ -1057,8 +1057,9 @@ struct PairHost {
 static PairHost g_pair_host[64];
 static std::mutex g_pair_mu;
 
-// returns the slot of (current device, st) and its next epoch, or -1 when all 8 slots of the device belong to other streams
-static int pair_slot_for(hipStream_t st, unsigned* epoch, bool reset = false) {
+// returns the slot of (current device, st), claiming a free one for a stream seen for the first time, or -1 when all 8 slots of the device belong to other
+// streams.  Does NOT consume a launch epoch: that happens in pair_epoch_take, immediately in front of the launch, after everything that can still fail.
+static int pair_slot_for(hipStream_t st, int* dev_out, bool reset = false) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
   std::lock_guard<std::mutex> lk(g_pair_mu);
@@ -1072,15 +1073,29 @@ static int pair_slot_for(hipStream_t st, unsigned* epoch, bool reset = false) {
     h.streams[slot] = st;
     h.epoch[slot] = 0;
   }
-  *epoch = h.epoch[slot];
-  h.epoch[slot] = (h.epoch[slot] + 1u) & 0xfffu;
+  if (dev_out) *dev_out = dev;
   return slot;
+}
+// The epoch the next launch of (dev, slot) must carry; the host counter moves on.  The device slot is re-stamped with epoch + 1 by the launch's last block,
+// so the counter may only advance for a launch that really is enqueued: pair_epoch_untake puts it back when the launch itself failed (an
+// argument error after the epoch was consumed left host and device one apart - every later launch on that stream then faulted with 0x5001).
+static unsigned pair_epoch_take(int dev, int slot) {
+  std::lock_guard<std::mutex> lk(g_pair_mu);
+  PairHost& h = g_pair_host[dev];
+  const unsigned e = h.epoch[slot];
+  h.epoch[slot] = (e + 1u) & 0xfffu;
+  return e;
+}
+static void pair_epoch_untake(int dev, int slot, unsigned e) {
+  std::lock_guard<std::mutex> lk(g_pair_mu);
+  PairHost& h = g_pair_host[dev];
+  if (h.epoch[slot] == ((e + 1u) & 0xfffu)) h.epoch[slot] = e;
 }
 
 int pair_state_debug(int op, hipStream_t st) {
   if (op != 0 && op != 1) { set_error("smbv_debug_pair_state: op %d (0 = reset, 1 = dirty)", op); return SMBV_ERR_ARG; }
   hipLaunchKernelGGL(pair_state_debug_kernel, dim3(8), dim3(256), 0, st, op);
-  if (op == 0) { unsigned e; pair_slot_for(nullptr, &e, true); }   // the host's epochs restart with the slots
+  if (op == 0) pair_slot_for(nullptr, nullptr, true);   // the host's epochs restart with the slots
   return check_launch("pair_state_debug");
 }
 
@@ -1104,9 +1119,10 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
   // both products: ONE launch with mixed block roles (attn_bwd_pair_kernel: -1.3 % encoder, -2.9 % decoder, -3.7 % at head_dim 32, -6.4 % at S = 20,480 x
   // 12 heads against the two launches side by side, bitwise the same gradients: tests/test_ops_gpu.py); debug bit 524288 keeps the two launches, and so
   // does a ninth stream of one device (every slot of the scheduling state is owned by another stream)
-  unsigned epoch = 0;
-  const int slot = ((parts & 6) == 6 && !(g_variant & 524288)) ? pair_slot_for(st, &epoch) : -1;
+  int dev = 0;
+  const int slot = ((parts & 6) == 6 && !(g_variant & 524288)) ? pair_slot_for(st, &dev) : -1;
   if (slot >= 0) {
+    // everything that can fail comes BEFORE the launch epoch is consumed: the tile-count check, the fp8 operand pre-pass (workspace size / alignment, its launches)
     const int blocks = (cdiv(S, 128) + cdiv(Sq, 128)) * H * B;
     if ((unsigned)blocks >= PAIR_COUNT_MASK) { set_error("attention_bwd: %d tiles exceed the pair launch's 20-bit tile counters", blocks); return SMBV_ERR_SHAPE; }
     unsigned* status = device_status_word_dev();   // host-mapped; null if it could not be created (faults then go unreported, as before round 4)
@@ -1114,6 +1130,7 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     Fp8BwdOps f8;
     const bool fp8q = f8ws != nullptr && Dh == 64 && !(g_variant & 8);   // (debug bit 8: bf16 query-owner blocks although fp8 operands were offered)
     if (fp8q) RC(attention_bwd_fp8_prepare(Q, K, V, ld, dO, ldo, B, S, H, scale, f8ws, f8ws_bytes, st, &f8));
+    const unsigned epoch = pair_epoch_take(dev, slot);
 #define SMBV_PAIR_LAUNCH(DHV, KIND) hipLaunchKernelGGL((attn_bwd_pair_kernel<DHV, KIND>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot, epoch, status, f8)
     if (fp8q) SMBV_PAIR_LAUNCH(64, 2);
     else if (Dh == 64 && q16) SMBV_PAIR_LAUNCH(64, 1);
@@ -1121,7 +1138,9 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     else if (q16) SMBV_PAIR_LAUNCH(32, 1);
     else SMBV_PAIR_LAUNCH(32, 0);
 #undef SMBV_PAIR_LAUNCH
-    return check_launch("attn_bwd_pair");
+    rc = check_launch("attn_bwd_pair");
+    if (rc) pair_epoch_untake(dev, slot, epoch);   // nothing was enqueued: the device slot still carries this epoch
+    return rc;
   }
   // dK/dV and dQ are independent (disjoint outputs, shared read-only inputs).  Their grids rarely fill a whole number of
   // block rounds (encoder: 672 blocks on 512 slots), so when both are requested they are forked onto two streams and run

@@ -64,6 +64,11 @@ ForkJoin* fork_join_for_current_device();
 // `to` waits for everything enqueued on `from` so far: hipEventRecord(ev, from) + hipStreamWaitEvent(to, ev) as ONE step under the device's mutex,
 // so that another host thread's re-record of the same event cannot fall between the two
 int stream_edge(ForkJoin* fj, hipEvent_t ev, hipStream_t from, hipStream_t to);
+// The two halves on their own, each under the same mutex (the wdone events of a WgradPipe are recorded at the end of a deferred launch and waited for two
+// blocks later: a second host thread stepping another model on the device may re-record the slot in between - the wait then covers a LATER point of the
+// in-order side stream, which is conservative - but the runtime calls on one hipEvent_t never overlap)
+int event_record_locked(ForkJoin* fj, hipEvent_t ev, hipStream_t on);
+int stream_wait_locked(ForkJoin* fj, hipStream_t st, hipEvent_t ev);
 
 // The library's per-device weight-gradient side stream (streams.hip).  begin(): work enqueued on `st` afterwards
 // starts only after everything enqueued on the caller's stream so far; end(): the caller's stream waits for all side work.  With the debug

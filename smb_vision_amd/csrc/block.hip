@@ -178,7 +178,7 @@ int WgradPipe::begin() {
 }
 int WgradPipe::wait_for(int launch, hipStream_t st) {
   if (!fj || launch < 0 || launch <= waited || launch < k - 4 || !deferred[launch & 3]) return SMBV_OK;
-  HIPRC(hipStreamWaitEvent(st, fj->wdone[launch & 3], 0));
+  RC(stream_wait_locked(fj, st, fj->wdone[launch & 3]));
   waited = launch;
   return SMBV_OK;
 }
@@ -349,7 +349,7 @@ int layer_bwd_core(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const Bl
     RC(layernorm_bwd_reduce(bf.ln2_part, Mq, w, gr.ln2_w, gr.ln2_b, fj->wside));
     RC(layernorm_bwd_reduce(bf.ln1_part, M, w, gr.ln1_w, gr.ln1_b, fj->wside));
     RC(gemm_tn_grouped(jobs, nj, fj->wside));
-    HIPRC(hipEventRecord(fj->wdone[launch_no & 3], fj->wside));
+    RC(event_record_locked(fj, fj->wdone[launch_no & 3], fj->wside));
     if (dp_event) HIPRC(hipEventRecord(dp_event, fj->wside));
     return SMBV_OK;
   }

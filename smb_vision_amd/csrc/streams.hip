@@ -84,6 +84,17 @@ int stream_edge(ForkJoin* fj, hipEvent_t ev, hipStream_t from, hipStream_t to) {
   return SMBV_OK;
 }
 
+int event_record_locked(ForkJoin* fj, hipEvent_t ev, hipStream_t on) {
+  std::lock_guard<std::mutex> lk(*(std::mutex*)fj->mu);
+  HIPRC(hipEventRecord(ev, on));
+  return SMBV_OK;
+}
+int stream_wait_locked(ForkJoin* fj, hipStream_t st, hipEvent_t ev) {
+  std::lock_guard<std::mutex> lk(*(std::mutex*)fj->mu);
+  HIPRC(hipStreamWaitEvent(st, ev, 0));
+  return SMBV_OK;
+}
+
 int SideStream::begin(hipStream_t caller) {
   if (!impl) {
     ForkJoin* fj = (g_variant & 16384) ? nullptr : fork_join_for_current_device();

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import collections.abc
 import ctypes as C
+import logging
 import os
 import weakref
 from dataclasses import dataclass
@@ -25,6 +26,8 @@ from transformers.utils import ModelOutput
 
 from . import _lib
 from .masking import split_mask_indices
+
+logger = logging.getLogger(__name__)
 
 
 def _residual_wanted(config, default: bool = False) -> bool:
@@ -279,8 +282,17 @@ class SmbVideoMAEForPreTraining(PreTrainedModel):
         s.ln_eps = c.layer_norm_eps
         s.dec_norm_eps = 1e-5
         s.recompute = int(self._use_recompute(s))
-        f8 = getattr(c, "smbv_attention_fp8", False)   # True / "all": forward + the backward's recomputed S / dP products (BASELINE config 5); "forward": forward only
-        s.attn_fp8 = 0 if not f8 else (1 if f8 == "forward" else 3)
+        # True / "forward": the attention FORWARD's QK^T / PV on the fp8 MFMA (what the flag has meant since round 2); "all": also the backward's recomputed
+        # S / dP products (round 4) - explicit, because it changes the backward's numerics (dQ 5.8e-2 rms from exact instead of 3e-3, tests/test_fp8_gpu.py) and
+        # switches the attention residual off; training CONVERGENCE with it is unpinned (per-step gradient bounds against the oracle are what is tested)
+        f8 = getattr(c, "smbv_attention_fp8", False)
+        if f8 not in (False, None, 0, True, "forward", "all"):
+            raise ValueError(f"config.smbv_attention_fp8 must be False, True / 'forward' or 'all', got {f8!r}")
+        s.attn_fp8 = 0 if not f8 else (3 if f8 == "all" else 1)
+        if s.attn_fp8 and getattr(self, "_fp8_mode_logged", None) != s.attn_fp8:
+            self._fp8_mode_logged = s.attn_fp8
+            logger.info("smb_vision_amd: fp8 attention %s", "forward + backward recomputation of S / dP (smbv_attention_fp8='all')" if s.attn_fp8 == 3
+                        else "forward only (smbv_attention_fp8=True / 'forward')")
         # delta = rowsum(dO * O) from the attention output to 16 significant bits (smbv_mim_cfg.attn_o_resid; one more bf16 activation per block)
         s.attn_o_resid = int(_residual_wanted(c) and not s.attn_fp8)
         return s

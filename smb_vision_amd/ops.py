@@ -171,8 +171,9 @@ def attention_fwd_fp8(qkv, B, S, H, scale=None, Sq=0, q_off=0):
     return O, lse
 
 
-def attention_bwd(qkv, O, dO, lse, B, S, H, scale=None, parts=7, out=None, Sq=0, q_off=0, Dh=64, O_lo=None, fp8=False):
-    """fp8: the query-owner blocks recompute S and dP on the block-scaled fp8 MFMA (smbv_attention_bwd_fp8; head_dim 64)."""
+def attention_bwd(qkv, O, dO, lse, B, S, H, scale=None, parts=7, out=None, Sq=0, q_off=0, Dh=64, O_lo=None, fp8=False, fp8_ws_short=0):
+    """fp8: the query-owner blocks recompute S and dP on the block-scaled fp8 MFMA (smbv_attention_bwd_fp8; head_dim 64).  fp8_ws_short: declare the
+    workspace that many bytes smaller than it is (the error-path test)."""
     _need_gpu(qkv, O, dO, lse)
     lib = _lib.load()
     w = H * Dh
@@ -182,7 +183,7 @@ def attention_bwd(qkv, O, dO, lse, B, S, H, scale=None, parts=7, out=None, Sq=0,
     if fp8:
         ws = _ws(lib.smbv_attention_bwd_fp8_workspace_bytes(B, S, H), qkv.device)
         check(lib.smbv_attention_bwd_fp8(base, base + 2 * w, base + 4 * w, qkv.stride(0), _p(O), _p(O_lo), _p(dO), w, _p(lse), _p(delta), dbase, dbase + 2 * w,
-                                         dbase + 4 * w, dqkv.stride(0), B, S, H, Dh, scale, parts, Sq, q_off, _p(ws), ws.numel(), _stream()), "smbv_attention_bwd_fp8")
+                                         dbase + 4 * w, dqkv.stride(0), B, S, H, Dh, scale, parts, Sq, q_off, _p(ws), ws.numel() - fp8_ws_short, _stream()), "smbv_attention_bwd_fp8")
         return dqkv, delta
     check(lib.smbv_attention_bwd(base, base + 2 * w, base + 4 * w, qkv.stride(0), _p(O), _p(O_lo), _p(dO), w, _p(lse), _p(delta), dbase, dbase + 2 * w,
                                  dbase + 4 * w, dqkv.stride(0), B, S, H, Dh, scale, parts, Sq, q_off, _stream()), "smbv_attention_bwd")

@@ -103,9 +103,9 @@ def test_attention_bwd_fp8_recompute_products(B, S, H, Sq, qoff, amp):
         assert float(d_f8.float().view(B, S, 3 * w)[:, outside.cuda(), :w].abs().max()) == 0.0   # no dQ outside the query range
 
 
-@pytest.mark.parametrize("mode", [True, "forward"])
+@pytest.mark.parametrize("mode", ["all", True, "forward"])
 def test_mim_step_with_fp8_attention_and_recompute(mode):
-    """config.smbv_attention_fp8 = True (forward + the backward's recomputed products; "forward": round 3's forward-only form) + per-layer recompute: the
+    """config.smbv_attention_fp8 = "all" (forward + the backward's recomputed products; True / "forward": the forward-only form) + per-layer recompute: the
     whole step against the fp32 oracle, tolerances in the module docstring."""
     from transformers import VideoMAEConfig
     from oracle.mim_oracle import MIMConfig, init_params, mim_step
@@ -124,7 +124,7 @@ def test_mim_step_with_fp8_attention_and_recompute(mode):
     model.load_state_dict(params)
     model = model.cuda().train()
     model.gradient_checkpointing_enable()
-    assert model._cfg_struct(2, int(mask[0].sum())).attn_fp8 == (3 if mode is True else 1)
+    assert model._cfg_struct(2, int(mask[0].sum())).attn_fp8 == (3 if mode == "all" else 1)
     out = model(pixel_values=pix.cuda(), bool_masked_pos=mask.cuda())
     out.loss.backward()
     torch.cuda.synchronize()

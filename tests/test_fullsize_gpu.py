@@ -120,7 +120,10 @@ def test_mim_vit_base_512x512x320_step_matches_oracle():
     assert abs(float(o2.loss) - 0.5 * (float(la) + float(lb))) <= 1e-6 * float(la)
 
 
-@pytest.mark.parametrize("qk_scale", [1.0])   # (3.0 - round 3's only case, a softmax that attends - also passes: profiles/r04 logs; one case keeps the suite's wall time down)
+# qk_scale 3.0 - round 3's only case, a softmax that attends - is a SECOND parameter, run under SMBV_FULL=1 (it adds ~100 s of CPU oracle time to the suite's
+# wall clock; `SMBV_FULL=1 python -m pytest tests/test_fullsize_gpu.py -m gpu -k vjepa`; its round-5 log: profiles/r05_fullsize_tests.txt)
+@pytest.mark.parametrize("qk_scale", [1.0, pytest.param(3.0, marks=pytest.mark.skipif(__import__("os").environ.get("SMBV_FULL", "0") != "1",
+                                                                                       reason="second full-size V-JEPA regime: set SMBV_FULL=1"))])
 def test_vjepa_vit_base_512x512x320_matches_oracle(qk_scale):
     from transformers import VJEPA2Config
     from smb_vision_amd.masking import VJEPAMaskGenerator
@@ -201,7 +204,7 @@ def test_vjepa_vit_base_512x512x320_matches_oracle(qk_scale):
     notkb = lambda k: not k.endswith("attention.key.bias")
     worst, n = _cmp_grads(grads_lin, ref_grads, 5e-2, 0.998, only=notkb, label="V-JEPA (oracle's upstream gradient)")
     kb, _ = _cmp_grads(grads_lin, ref_grads, 2e-1, 0.97, only=lambda k: k.endswith("attention.key.bias"), label="V-JEPA key biases")
-    worst_loss, _ = _cmp_grads(grads, ref_grads, 1.2e-1, 0.99, only=notkb, label="V-JEPA (own L1 sign pattern)")
+    worst_loss, _ = _cmp_grads(grads, ref_grads, 5e-2, 0.998, only=notkb, label="V-JEPA (own L1 sign pattern)")   # measured worst 1.7e-2 / 0.9999 (rounds 3-5)
     print(f"full-size V-JEPA: sign(pred - target) differs on {flips:.2%} of the elements; loss-driven gradients worst {worst_loss}")
     assert n >= 360                                  # 15 tensors x (12 predictor + 12 encoder layers) + embeddings / norms / head (key biases: below)
     missing = [k for k, _ in model.named_parameters() if k not in ref_grads and k != "predictor.embeddings.mask_tokens"]
@@ -242,7 +245,7 @@ def test_vit_large_512x512x320_fp8_attention_and_recompute_match_oracle_forward(
         return res
 
     l_bf, g_bf, gr_bf, ws_bf = run()
-    l_f8, g_f8, gr_f8, ws_f8 = run(smbv_attention_fp8=True, smbv_recompute="always")
+    l_f8, g_f8, gr_f8, ws_f8 = run(smbv_attention_fp8="all", smbv_recompute="always")
     l_rc, g_rc, gr_rc, ws_rc = run(smbv_recompute="always")
     assert l_rc == l_bf and torch.equal(g_rc, g_bf) and all(torch.equal(gr_rc[k], gr_bf[k]) for k in gr_bf)   # recompute: identical
     assert ws_rc < 0.5 * ws_bf

@@ -596,6 +596,31 @@ def test_attention_backward_scheduling_fault_is_an_error_not_wrong_gradients(ops
     assert torch.equal(again, want) and ops.device_status() == 0
 
 
+def test_attention_backward_argument_error_does_not_poison_the_stream(ops):
+    """an attention backward that returns an error AFTER its stream's scheduling slot was looked up - here smbv_attention_bwd_fp8 with a
+    workspace one byte short: SMBV_ERR_WORKSPACE from the operand pre-pass - must not consume the slot's launch epoch: the next (valid) launch on the same
+    stream finds the device slot stamped with the epoch it carries, gives the right gradients and leaves the status word clean.  (Before: host and device
+    were one epoch apart from then on, every later pair launch on that stream ran no tile and raised 0x5001 - a recoverable argument error had become a
+    permanent SMBV_ERR_STATE.)"""
+    from smb_vision_amd import _lib
+    qkv, O, lse, dO = _bwd_case(ops, 1, 1024, 2, 64, 0, 0, seed=43)
+    want, _ = ops.attention_bwd(qkv, O, dO, lse, 1, 1024, 2)
+    torch.cuda.synchronize()
+    assert ops.device_status() == 0
+    for _ in range(3):   # several failures in a row: each one must leave the epoch where it was
+        with pytest.raises(_lib.SmbvError, match=r"rc=-4"):
+            ops.attention_bwd(qkv, O, dO, lse, 1, 1024, 2, fp8=True, fp8_ws_short=1)
+    again, _ = ops.attention_bwd(qkv, O, dO, lse, 1, 1024, 2)
+    torch.cuda.synchronize()
+    assert ops.device_status() == 0, _lib.last_error()
+    assert torch.equal(again, want)
+    f8, _ = ops.attention_bwd(qkv, O, dO, lse, 1, 1024, 2, fp8=True)     # and the fp8 form itself still runs on that stream
+    torch.cuda.synchronize()
+    assert ops.device_status() == 0 and torch.isfinite(f8.float()).all()
+    w = 2 * 64
+    assert torch.equal(f8[:, w:], want[:, w:])                             # dK, dV are the bf16 blocks' (bit-identical by construction)
+
+
 def _attn_bwd_emulated(qkv, O, dO, lse, B, S, H, Dh, Sq, qoff, rounding=True, O_lo=None):
     """fp32 torch restatement of attn_dkv2_kernel / attn_dq2_kernel WITH their bf16 rounding points (attention_bwd.hip): the key-owner kernel scores
     bf16(K * c) against Q, the query-owner kernel bf16(Q * c) against K (c = scale * log2 e), P = exp2(s' - lse * log2 e) is rounded to bf16 for the

@@ -190,7 +190,7 @@ def test_random_fp8_step_configuration_matches_oracle(seed):
     c = dict(image_size=128, num_frames=r.choice([32, 48, 64]), patch_size=16, tubelet_size=16, hidden_size=hid,
              num_hidden_layers=r.randint(1, 3), num_attention_heads=hid // 64, intermediate_size=r.choice([128, 256, 320, 512]), decoder_hidden_size=dec,
              decoder_num_hidden_layers=r.randint(1, 3), decoder_num_attention_heads=dec // 64, decoder_intermediate_size=r.choice([128, 192, 256]))
-    B, ratio, mode, recompute = r.randint(1, 3), r.uniform(0.3, 0.8), r.choice([True, "forward"]), r.random() < 0.6
+    B, ratio, mode, recompute = r.randint(1, 3), r.uniform(0.3, 0.8), r.choice(["all", "forward"]), r.random() < 0.6
     cfg = MIMConfig(**c)
     params = init_params(cfg, seed=400 + seed, nonzero_small=True)
     np.random.seed(seed)
