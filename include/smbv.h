@@ -53,7 +53,7 @@ typedef uint16_t smbv_bf16;
  * major) and minor >= the newest entry point it calls.  2000: every *_cfg struct opens with `struct_bytes` (= sizeof of the caller's struct, checked
  * by the library: a binding compiled against a shorter or longer layout is refused with SMBV_ERR_ARG instead of being read past its end);
  * 1000-1002 (round 1-2) had no such guard and grew smbv_mim_cfg / smbv_vjepa_cfg in place.  3000 (round 4): smbv_attention_fwd / smbv_attention_bwd take
- * the residual output O_lo, the *_cfg structs end with attn_o_resid. */
+ * the residual output O_lo, the *_cfg structs end with attn_o_resid.  3001 (round 5, additive): smbv_gemm_nt_splitk + its workspace query. */
 #define SMBV_ABI_MAJOR 3
 int smbv_version(void);
 int smbv_last_error(char* buf, size_t len);               /* copies the thread's last error text; returns its length */
@@ -94,6 +94,16 @@ typedef struct smbv_gemm_epi {
  * :801-803, :720-722) with B = the HF weight [out,in]; and their input gradients with B = a transposed bf16 copy. */
 int smbv_gemm_nt(const smbv_bf16* A, int lda, const smbv_bf16* B, int ldb, int M, int N, int K, const smbv_gemm_epi* epi,
                  smbv_stream stream);
+/* The same product as 256 x 128 output tiles with the K range as TWO halves per tile (ABI 3001; built for the long-K / narrow-N Linears - fc2 forward,
+ * spec :384-386, and the input gradients of fc1 and of the fused q | k | v projection - measured SLOWER there than smbv_gemm_nt's own selection and
+ * therefore NOT what the steps run, profiles/r05_splitk_ab.txt; kept as a tested op): the halves are computed by two
+ * workgroups, the first publishing its fp32 partial tile through `ws`, the second adding it and running the epilogue (two addends: run-to-run
+ * identical; the result differs from smbv_gemm_nt's in the last fp32 bit of the K-sum, nothing else).  ws: smbv_gemm_nt_splitk_workspace_bytes(M, N),
+ * 256-byte aligned, contents arbitrary (the call clears its flag words on `stream`).  SMBV_ERR_SHAPE when the product is not one this form is built for
+ * (N multiple of 128, K multiple of 64 and >= 1152, 96..256 tiles, a plain epilogue: no GELU / dGELU). */
+int smbv_gemm_nt_splitk(const smbv_bf16* A, int lda, const smbv_bf16* B, int ldb, int M, int N, int K, const smbv_gemm_epi* epi, void* ws, size_t ws_bytes,
+                        smbv_stream stream);
+size_t smbv_gemm_nt_splitk_workspace_bytes(int M, int N);
 /* out[N1,N2] (fp32) = sum_m X[m,N1] · Y[m,N2]: the weight gradients of the same Linears (autograd of the above). */
 int smbv_gemm_tn(const smbv_bf16* X, int ldx, const smbv_bf16* Y, int ldy, int M, int N1, int N2, float* out, void* ws,
                  size_t ws_bytes, smbv_stream stream);

@@ -10,7 +10,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsmbv.so")
 MAX_LAYERS = 48
-ABI_MAJOR, ABI_MINOR_NEEDED = 3, 0  # include/smbv.h SMBV_ABI_MAJOR; the newest entry point these bindings call
+ABI_MAJOR, ABI_MINOR_NEEDED = 3, 1  # include/smbv.h SMBV_ABI_MAJOR; the newest entry point these bindings call
 
 c_f = C.c_void_p  # all device pointers travel as void*
 
@@ -116,6 +116,8 @@ _SIGS = {
     "smbv_gemm_nt": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GemmEpi), c_f]),
     "smbv_gemm_tn": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f, C.c_size_t, c_f]),
     "smbv_gemm_tn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "smbv_gemm_nt_splitk": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GemmEpi), c_f, C.c_size_t, c_f]),
+    "smbv_gemm_nt_splitk_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "smbv_gemm_tn_grouped": (C.c_int, [C.POINTER(TnJob), C.c_int, c_f]),
     "smbv_gemm_tn_bias": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f, c_f, C.c_size_t, c_f]),
     "smbv_layernorm_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_float, C.c_long, C.c_long, C.c_long, c_f]),

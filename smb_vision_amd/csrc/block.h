@@ -103,21 +103,30 @@ struct Carver {
   }
 };
 
+extern int g_variant;  // debug hook, capi.hip (smbv_debug_set_variant)
 struct PrepList {
   std::vector<PrepJob> jobs;
   int tiles = 0;
-  void add(const float* src, void* dst, int R, int C, int lds, int ldd, int kind) {
+  void add(const float* src, void* dst, int R, int C, int lds, int ldd, int kind, void* dst2 = nullptr, int ldd2 = 0) {
     PrepJob j;
-    j.src = src; j.dst = dst; j.R = R; j.C = C; j.ldd = ldd; j.kind = kind; j.tile0 = tiles; j.lds = lds;
+    j.src = src; j.dst = dst; j.dst2 = dst2; j.R = R; j.C = C; j.ldd = ldd; j.kind = kind; j.tile0 = tiles; j.lds = lds; j.ldd2 = ldd2;
     jobs.push_back(j);
-    tiles += cdiv(R, 32) * cdiv(C, 32);
+    tiles += prep_job_tiles(j);
   }
-  void cast(const float* src, bf16_t* dst, int R, int C) { add(src, dst, R, C, C, C, 0); }
-  void tcast(const float* src, bf16_t* dst, int R, int C, int ldd) { add(src, dst, R, C, C, ldd, 1); }
+  void cast(const float* src, bf16_t* dst, int R, int C) { both(src, dst, C, nullptr, 0, R, C); }
+  void tcast(const float* src, bf16_t* dst, int R, int C, int ldd) { both(src, nullptr, 0, dst, ldd, R, C); }
+  // fp32 master [R, C] -> bf16 copy dst [R, ldd] and / or transposed bf16 copy dstT [C, lddT], the master read ONCE (kind 4) when the shapes allow the
+  // vector accesses (every shipped width does); otherwise the scalar 32 x 32 jobs, one per copy
+  void both(const float* src, bf16_t* dst, int ldd, bf16_t* dstT, int lddT, int R, int C) {
+    const bool vec = C % 4 == 0 && R % 4 == 0 && !((uintptr_t)src & 15) && (!dst || (ldd % 4 == 0 && !((uintptr_t)dst & 7))) &&
+                     (!dstT || (lddT % 4 == 0 && !((uintptr_t)dstT & 7)));
+    if (vec && !(g_variant & 1)) { add(src, dst, R, C, C, ldd, 4, dstT, lddT); return; }   // (debug bit 1: the round-4 scalar jobs, A/B)
+    if (dst) add(src, dst, R, C, C, ldd, 0);
+    if (dstT) add(src, dstT, R, C, C, lddT, 1);
+  }
 };
 
 void carve_layer(Carver& c, LayerWs& L, const BlockDims& d, const LayerWs* share_acts = nullptr);
-size_t layer_prep_job_count(const BlockDims& d);
 // appends this block's weight-preparation jobs; for padded heads also enqueues the zero fills of the padded buffers on `st`
 int prep_layer(PrepList& pl, const BlockPtrs& p, LayerWs& L, const BlockDims& d, hipStream_t st);
 struct BwdNeeds {  // running maxima over the blocks of a model (elements, except scratch / wscratch: bytes)

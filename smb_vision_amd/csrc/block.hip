@@ -3,6 +3,7 @@
 
 namespace smbv {
 extern int g_variant;
+extern int g_ab;
 
 void carve_layer(Carver& c, LayerWs& L, const BlockDims& d, const LayerWs* share_acts) {
   const size_t w = d.w, wa = d.wa(), ff = d.ff, rows = d.rows;
@@ -32,20 +33,14 @@ void carve_layer(Carver& c, LayerWs& L, const BlockDims& d, const LayerWs* share
   L.x_mid = c.take<float>(rows * w);
 }
 
-size_t layer_prep_job_count(const BlockDims& d) { return d.padded() ? (size_t)(16 + 11 * d.H) : 16; }
-
 int prep_layer(PrepList& pl, const BlockPtrs& p, LayerWs& L, const BlockDims& d, hipStream_t st) {
   const int w = d.w, ff = d.ff, wa = d.wa(), Dh = d.Dh, hs = d.slot();
   const size_t ww = (size_t)w * w;
   if (!d.padded()) {
-    pl.cast(p.q_w, L.wqkv, w, w);
-    pl.cast(p.k_w, L.wqkv + ww, w, w);
-    pl.cast(p.v_w, L.wqkv + 2 * ww, w, w);
-    pl.tcast(p.q_w, L.wqkv_t, w, w, 3 * w);
-    pl.tcast(p.k_w, L.wqkv_t + w, w, w, 3 * w);
-    pl.tcast(p.v_w, L.wqkv_t + 2 * w, w, w, 3 * w);
-    pl.cast(p.proj_w, L.proj, w, w);
-    pl.tcast(p.proj_w, L.proj_t, w, w, w);
+    pl.both(p.q_w, L.wqkv, w, L.wqkv_t, 3 * w, w, w);
+    pl.both(p.k_w, L.wqkv + ww, w, L.wqkv_t + w, 3 * w, w, w);
+    pl.both(p.v_w, L.wqkv + 2 * ww, w, L.wqkv_t + 2 * w, 3 * w, w, w);
+    pl.both(p.proj_w, L.proj, w, L.proj_t, w, w, w);
     pl.add(p.q_b, L.bqkv, 1, w, w, w, 2);
     if (p.k_b) pl.add(p.k_b, L.bqkv + w, 1, w, w, w, 2);
     else pl.add(nullptr, L.bqkv + w, 1, w, w, w, 3);  // VideoMAE: key has no bias (spec :261)
@@ -72,10 +67,8 @@ int prep_layer(PrepList& pl, const BlockPtrs& p, LayerWs& L, const BlockDims& d,
       pl.add(p.proj_w + h * Dh, L.proj_t + (size_t)h * hs * w, w, Dh, w, w, 1);
     }
   }
-  pl.cast(p.fc1_w, L.fc1, ff, w);
-  pl.tcast(p.fc1_w, L.fc1_t, ff, w, ff);
-  pl.cast(p.fc2_w, L.fc2, w, ff);
-  pl.tcast(p.fc2_w, L.fc2_t, w, ff, w);
+  pl.both(p.fc1_w, L.fc1, w, L.fc1_t, ff, ff, w);
+  pl.both(p.fc2_w, L.fc2, ff, L.fc2_t, w, w, ff);
   return SMBV_OK;
 }
 
@@ -304,9 +297,11 @@ int layer_bwd_core(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const Bl
   if (d.rope_grid > 0) RC(rope3d(bf.d_qkv, 3 * wa, wa, M, S, H, d.slot(), d.Dh, d.rope_grid, d.pos, d.rope_table, 1, st));
   // ---- QKV ----
   if (!defer) {
-    // (the three products forked above had the whole attention backward to finish: joining them here costs nothing and makes every later
-    // write on `st` - LN1 backward may rewrite gb - safe whatever the scheduling of the two queues)
-    RC(side.end(st));
+    // (round 3 joined the three products forked above here.  Since round 4 every buffer they read - gb_in, gb_mid, d_act, d_qkv, the saved activations -
+    // is a ring entry or an activation that nothing on `st` rewrites before the block's final join: LN1 backward writes g, gb_OUT and its own partials, the
+    // QKV input-gradient product writes sc.d_ln, which no side product reads.  Without the join the block's tail no longer waits for a weight-gradient
+    // product that the attention backward starved: what makes the inline form the right one for the LAST block of a backward, mim_step.hip.)
+    if (g_ab & 1) RC(side.end(st));   // A/B: the round-3 join
     RC(side.begin(st));  // d_qkv is ready
   }
   const size_t ww = (size_t)w * w;
@@ -377,6 +372,10 @@ int layer_bwd(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const BlockDi
   const bool shapes_ok = w % 128 == 0 && ff % 128 == 0 && Mmax * (size_t)std::max(ff, 3 * w) * 2 < (1ull << 31);
   (void)ww;   // (q / k / v weight gradients that are not adjacent in the arena become three jobs of the grouped launch instead of one)
   const bool defer = pipe.fj && pipe.allow_defer && !(g_variant & 4) && !d.padded() && shapes_ok && !(ranged && d.B > 1) && !(g_variant & 32);
+  // (Round 5 tried two other forms for the LAST block of a backward, whose deferred launch - ~200 us on 108 CUs - is what the optimizer waits for: every
+  // product inline, and the MLP pair grouped beside the block's own attention backward with the projection / QKV products token-split at the end.  Both null
+  // in the step, profiles/r05_tail_block_ab.txt: a 512-thread weight-gradient block beside 1,344 attention tiles is starved - 490-630 us for what takes 200 -
+  // so the tail only moves from behind the last launch to behind the join.)
   const int rc = layer_bwd_core(p, gr, L, d, sc, x_in, bf, Sq, qoff, st, defer ? &pipe : nullptr, k, dp_event, &pipe);
   if (rc) return rc;
   pipe.deferred[k & 3] = defer;

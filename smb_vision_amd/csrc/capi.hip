@@ -42,6 +42,9 @@ static GemmEpi to_epi(const smbv_gemm_epi* s) {
 }
 
 int g_variant = 0;  // smbv_debug_set_variant (include/smbv.h): kernel selection for A/B tools and equivalence tests; 0 on the product path
+// second A/B word (the first one's 31 bits are taken): environment SMBV_DEBUG_AB, read once at load; 0 / unset on the product path.  Bits: 1 the inline
+// block backward keeps round 3's join in front of its QKV products; (tools/step_ab2.sh)
+int g_ab = [] { const char* e = getenv("SMBV_DEBUG_AB"); return e ? atoi(e) : 0; }();
 
 }  // namespace smbv
 
@@ -49,7 +52,7 @@ using namespace smbv;
 
 extern "C" {
 
-int smbv_version(void) { return 3000; }  // 3000: O_lo in smbv_attention_fwd / _bwd, attn_o_resid in the *_cfg structs; see include/smbv.h
+int smbv_version(void) { return 3001; }  // 3000: O_lo in smbv_attention_fwd / _bwd, attn_o_resid in the *_cfg structs; see include/smbv.h
 void smbv_debug_set_variant(int bits) { smbv::g_variant = bits; }
 int smbv_device_status(int clear) { return smbv::device_status(clear != 0); }
 int smbv_debug_pair_state(int op, smbv_stream stream) { return smbv::pair_state_debug(op, (hipStream_t)stream); }
@@ -68,6 +71,22 @@ int smbv_gemm_nt(const smbv_bf16* A, int lda, const smbv_bf16* B, int ldb, int M
   if (!A || !B || !epi || (!epi->out_bf16 && !epi->out_f32)) { set_error("smbv_gemm_nt: null operand / no output"); return SMBV_ERR_ARG; }
   return gemm_nt(A, lda, B, ldb, M, N, K, to_epi(epi), (hipStream_t)stream);
 }
+int smbv_gemm_nt_splitk(const smbv_bf16* A, int lda, const smbv_bf16* B, int ldb, int M, int N, int K, const smbv_gemm_epi* epi, void* ws, size_t ws_bytes,
+                        smbv_stream stream) {
+  if (!A || !B || !epi || (!epi->out_bf16 && !epi->out_f32) || !ws) { set_error("smbv_gemm_nt_splitk: null operand / no output / no workspace"); return SMBV_ERR_ARG; }
+  GemmEpi e = to_epi(epi);
+  e.splitk_ws = ws;
+  e.splitk_ws_bytes = ws_bytes;
+  if (!gemm_nt_splitk_wanted(lda, ldb, M, N, K, e)) {
+    set_error("smbv_gemm_nt_splitk: %d x %d x %d is not a product the split-K form takes (or the workspace is short / misaligned: %zu < %zu)", M, N, K, ws_bytes,
+              gemm_nt_splitk_workspace_bytes(M, N));
+    return SMBV_ERR_SHAPE;
+  }
+  hipError_t he = hipMemsetAsync(ws, 0, SPLITK_SYNC_BYTES, (hipStream_t)stream);
+  if (he != hipSuccess) { set_error("smbv_gemm_nt_splitk: memset: %s", hipGetErrorString(he)); return (int)he; }
+  return gemm_nt(A, lda, B, ldb, M, N, K, e, (hipStream_t)stream);
+}
+size_t smbv_gemm_nt_splitk_workspace_bytes(int M, int N) { return gemm_nt_splitk_workspace_bytes(M, N); }
 int smbv_gemm_tn(const smbv_bf16* X, int ldx, const smbv_bf16* Y, int ldy, int M, int N1, int N2, float* out, void* ws, size_t ws_bytes, smbv_stream stream) {
   if (!X || !Y || !out) { set_error("smbv_gemm_tn: null operand"); return SMBV_ERR_ARG; }
   return gemm_tn(X, ldx, Y, ldy, M, N1, N2, out, ws, ws_bytes, (hipStream_t)stream);

@@ -56,7 +56,8 @@ struct PrepBatch {
 };
 
 __global__ __launch_bounds__(256) void prep_weights_kernel(const PrepBatch batch) {
-  __shared__ float tile[32][33];
+  __shared__ float tile64[64][65];
+  float (*tile)[33] = (float (*)[33])&tile64[0][0];   // the scalar kinds' 32 x 33 view of the same memory
   int lo = 0, hi = batch.n - 1;
   const int b = blockIdx.x;
   while (lo < hi) {
@@ -65,6 +66,44 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const PrepBatch batch
   }
   const PrepJob j = batch.jobs[lo];
   const int tl = b - j.tile0;
+  if (j.kind == 4) {
+    // ONE read of the fp32 master per step: a 64 x 64 tile as 16-byte loads (256-byte row segments), the bf16 copy as 8-byte stores, the transposed
+    // copy through LDS (row stride 65: both the row writes and the column reads spread over all banks) as 8-byte stores along the transposed rows
+    const int tc64 = (j.C + 63) >> 6;
+    const int r0 = (tl / tc64) * 64, c0 = (tl % tc64) * 64;
+    const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int r = r0 + lr + 16 * i, c = c0 + lc;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const bool in = r < j.R && c < j.C;   // (C % 4 == 0: a 4-column group is inside or outside as a whole)
+      if (in) v = *(const f32x4*)(j.src + (size_t)r * j.lds + c);
+      if (in && j.dst) {
+        u32x2 o;
+        o[0] = pack_bf16(v[0], v[1]);
+        o[1] = pack_bf16(v[2], v[3]);
+        *(u32x2*)((bf16_t*)j.dst + (size_t)r * j.ldd + c) = o;
+      }
+      if (j.dst2) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) tile64[lr + 16 * i][lc + e] = v[e];
+      }
+    }
+    if (j.dst2) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int c = lr + 16 * i, r = lc;   // transposed row c0 + c, its columns r0 + r .. r0 + r + 3
+        if (c0 + c < j.C && r0 + r < j.R) {  // (R % 4 == 0)
+          u32x2 o;
+          o[0] = pack_bf16(tile64[r][c], tile64[r + 1][c]);
+          o[1] = pack_bf16(tile64[r + 2][c], tile64[r + 3][c]);
+          *(u32x2*)((bf16_t*)j.dst2 + (size_t)(c0 + c) * j.ldd2 + r0 + r) = o;
+        }
+      }
+    }
+    return;
+  }
   const int tiles_c = (j.C + 31) >> 5;
   const int r0 = (tl / tiles_c) * 32, c0 = (tl % tiles_c) * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -100,7 +139,7 @@ int prep_weights(const PrepJob* jobs, int njobs, hipStream_t st) {
     for (int i = 0; i < b.n; i++) {
       b.jobs[i] = jobs[j0 + i];
       b.jobs[i].tile0 -= base;
-      tiles = b.jobs[i].tile0 + cdiv(b.jobs[i].R, 32) * cdiv(b.jobs[i].C, 32);
+      tiles = b.jobs[i].tile0 + prep_job_tiles(b.jobs[i]);
     }
     for (int i = b.n; i < 64; i++) b.jobs[i] = b.jobs[b.n - 1];
     if (tiles <= 0) continue;

@@ -366,6 +366,8 @@ int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, in
       (e.dgelu_pre && ((e.ld_pre & 3) || ((uintptr_t)e.dgelu_pre & 7))) || (e.aux_pre && ((e.ld_aux & 3) || ((uintptr_t)e.aux_pre & 7)))) {
     set_error("gemm_nt: epilogue operand alignment/stride"); return SMBV_ERR_ALIGN;
   }
+  // long-K products whose 256 x 128 tiles leave CUs idle: two K halves per tile (gemm_nt_ring.hip, round 5) when the caller handed over split-K scratch
+  if (gemm_nt_splitk_wanted(lda, ldb, M, N, K, e) && !(g_variant & (256 | 131072))) return gemm_nt_ring_splitk(A, lda, B, ldb, M, N, K, e, st);
   // Kernel choice, measured per shape on MI355X (tools/gemm_ab.py, profiles/r02_gemm_ab.txt): the ring kernel (256 x 128 tiles, two K slices in
   // flight per block, register epilogue) is 7-19 % ahead where the epilogue is heavy and K short - the GELU / dGELU products, the decoder's
   // K = 384 projections, the head - and 5-13 % behind the 128 x 128 kernel on long-K or narrow outputs, whose smaller tiles fill the chip better.

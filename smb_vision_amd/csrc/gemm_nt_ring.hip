@@ -22,6 +22,7 @@
 #include "smbv_kernels.h"
 
 namespace smbv {
+unsigned* device_status_word_dev();
 
 static constexpr int RBM = 256, RBN = 128, RBK = 32;
 static constexpr int RSLOT = (RBM + RBN) * RBK * 2;  // 24 KiB
@@ -116,30 +117,51 @@ __device__ __forceinline__ void ring_epilogue(const f32x4 (&acc)[4][4], const Ge
   }
 }
 
-template <int NS, int EPI>
+// one 16-byte store that writes through to the memory side (sc1): a partial tile another workgroup will read must not sit dirty in this XCD's L2
+template <int OFF>   // (the byte offset travels as the instruction's immediate: one address register pair serves four stores)
+__device__ __forceinline__ void store16_sc1(f32x4* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1" ::"v"(p), "v"(v), "i"(OFF) : "memory"); }
+__device__ void splitk_fault(unsigned* status) {
+  if (status) __hip_atomic_store(status, 0x6001u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// KS = 2 (round 5): the product's K range as two halves per output tile - 2 T workgroups for T tiles, meant for the N = 768 / 384 products with K >= 1,152
+// (168 / 240 tiles of 256 x 128: one block on SOME of the 256 CUs), to fill one round of the chip's 512 block slots with tiles of 85 FLOP per staged byte
+// instead of 128 x 128 tiles (64).  MEASURED NULL - kept as the op smbv_gemm_nt_splitk with its hand-off test, not selected by the steps
+// (profiles/r05_splitk_ab.txt: +0.6 ms per MIM step): 336 half-tile blocks on 256 CUs put two on 80 CUs and one on the rest, so the busiest CU still does
+// one whole tile's work - the makespan of the unsplit 168-tile launch - while the mixed 128 x 128 / 128 x 64 launch gives its busiest CU 0.75 of a tile.  Roles are fixed: block b < T computes K half 0 of tile(b) and PUBLISHES its fp32 accumulators (register order, 1 KiB per
+// wave-instruction, write-through stores, every wave drained, workgroup barrier, then one flag word); block T + b computes half 1, waits for that flag
+// (one lane polls; agent-scope acquire; barrier), adds the partial and runs the epilogue.  Two addends: fp32 addition commutes, there is no ordering to
+// fix - run-to-run identical.  A consumer waits only for a producer and producers wait for nothing: no cycle; the producers are the LOWER block ids,
+// dispatched first.  The flag is cleared by its consumer; the step zeroes the flag words once per forward (a zero-fill job of the weight-preparation
+// launch), a spin that outlasts ~1 s raises the device status word (smbv_device_status 0x6001) and ends.
+template <int NS, int EPI, int KS>
 __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_nt_ring_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
-                                                                          int M, int N, int K, int tiles_m, int tiles_n, GemmEpi e_in, int dbg) {
+                                                                          int M, int N, int K, int tiles_m, int tiles_n, GemmEpi e_in, int dbg, unsigned* status) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * RSLOT];
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = w >> 1, wn = w & 1;
   // bijective XCD remap (blocks b, b+8, ... share an XCD): XCD x owns a contiguous chunk of the tile list, tile_n fastest, so its L2 keeps
   // an A panel while it sweeps the weight matrix
-  const int nwg = tiles_m * tiles_n, bid = blockIdx.x;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x, kh = 0;
+  if constexpr (KS == 2) { kh = bid >= nwg ? 1 : 0; bid -= kh * nwg; }
   const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
   const int tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
   const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
   const int m0 = tile_m * RBM, n0 = tile_n * RBN;
-  const int nks = K / RBK;
+  const int Kh = K / KS;              // this block's K range: [kh * Kh, (kh + 1) * Kh)
+  const int nks = Kh / RBK;
+  const int k0b = kh * Kh * 2;        // its byte offset inside an operand row
 
   const i32x4 ra = dma_rsrc(A, (unsigned)(((size_t)(M - 1) * lda + K) * 2));
   const i32x4 rb = dma_rsrc(B, (unsigned)(((size_t)(N - 1) * ldb + K) * 2));
   // copy side: piece = 16 LDS rows x 64 B; lane -> (row l >> 2, physical chunk l & 3) holding logical chunk (l & 3) ^ f, f = (-(row >> 2)) & 3
   const int prow = l >> 2;
   const int csrc = (l & 3) ^ ((-(l >> 4)) & 3);
-  const int oa0 = ((m0 + 32 * w + prow) * lda + csrc * 8) * 2;             // A rows 32 w .. + 15
+  const int oa0 = ((m0 + 32 * w + prow) * lda + csrc * 8) * 2 + k0b;       // A rows 32 w .. + 15
   const int oa1 = oa0 + 16 * lda * 2;                                       //        32 w + 16 .. + 31
-  const int ob0 = ((n0 + 64 * (w >> 2) + 4 * prow + (w & 3)) * ldb + csrc * 8) * 2;  // LDS B row 16 w + prow <- weight row 64 (w >> 2) + 4 prow + (w & 3)
+  const int ob0 = ((n0 + 64 * (w >> 2) + 4 * prow + (w & 3)) * ldb + csrc * 8) * 2 + k0b;  // LDS B row 16 w + prow <- weight row 64 (w >> 2) + 4 prow + (w & 3)
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((int)lds_addr_of(smem));
   const unsigned la = lds0 + (unsigned)w * 2048, lb = lds0 + RBM * RBK * 2 + (unsigned)w * 1024;
   auto stage = [&](int s) __attribute__((always_inline)) {
@@ -201,6 +223,48 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_nt_ring_kernel(cons
   if (dbg & 1) {  // ablation: no epilogue traffic
     if (acc[0][0][0] == 1234.5f) e_in.out_f32[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3];
     return;
+  }
+  if constexpr (KS == 2) {
+    unsigned* flag = (unsigned*)e_in.splitk_ws + tile;
+    // partial tile: [8 waves][16 accumulators][64 lanes] x 16 B - every wave-instruction moves 1 KiB contiguous, a wave's 16 pieces sit 1 KiB apart
+    f32x4* part = (f32x4*)((char*)e_in.splitk_ws + SPLITK_SYNC_BYTES) + (size_t)tile * (RBM * RBN / 4) + w * 1024 + l;
+    if (kh == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        f32x4* pi = part + i * 256;
+        store16_sc1<0>(pi, acc[i][0]);
+        store16_sc1<1024>(pi, acc[i][1]);
+        store16_sc1<2048>(pi, acc[i][2]);
+        store16_sc1<3072>(pi, acc[i][3]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its own stores ...
+      __syncthreads();                                    // ... before the ONE flag store that speaks for all of them
+      if (t == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    __shared__ int ok;
+    if (t == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(8); spins++; }
+      ok = spins < (1 << 22);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (!ok) { if (t == 0) splitk_fault(status); return; }   // (never on a healthy run: the producer waits for nothing)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {   // four loads in flight at a time: sixteen would not fit beside the 64 accumulator registers at 128 per lane
+      f32x4 pv[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) pv[j] = part[(i * 4 + j) * 64];
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] += pv[j];
+      // the sums exist HERE (hipcc otherwise keeps all sixteen addends alive and sinks the additions into the epilogue: 40 spilled registers), and the next
+      // group's loads stay behind this point
+      asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3])::"memory");
+    }
+    __syncthreads();   // every wave holds its addends (the loads above were waited for by their uses) before the flag goes back to 0 for the next launch
+    if (t == 0) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   ring_epilogue<EPI>(acc, e_in, m0, n0, wm, wn, l, M);
 }
@@ -303,9 +367,30 @@ template <int NS>
 static void launch_ring(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, int dbg, hipStream_t st) {
   const int tm = cdiv(M, RBM), tn = N / RBN;
   const dim3 grid(tm * tn), block(512);
-  if (e.act_gelu) hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 1>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg);
-  else if (e.dgelu_pre) hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 2>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg);
-  else hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 0>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg);
+  unsigned* nostatus = nullptr;
+  if (e.act_gelu) hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 1, 1>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg, nostatus);
+  else if (e.dgelu_pre) hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 2, 1>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg, nostatus);
+  else hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 0, 1>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg, nostatus);
+}
+
+size_t gemm_nt_splitk_workspace_bytes(int M, int N) {
+  if (M <= 0 || N <= 0 || N % RBN) return 0;
+  return SPLITK_SYNC_BYTES + (size_t)cdiv(M, RBM) * (N / RBN) * RBM * RBN * sizeof(float);
+}
+
+// What the split-K form takes: 256 x 128 tiles that leave CUs idle (<= 256 tiles) while two halves per tile still fit one round of the 512 block slots, each
+// half with enough K steps to amortise the hand-off; plain epilogues only (bias / row addend / remap / outputs).
+bool gemm_nt_splitk_wanted(int lda, int ldb, int M, int N, int K, const GemmEpi& e) {
+  if (!e.splitk_ws || ((uintptr_t)e.splitk_ws & 255) || e.act_gelu || e.dgelu_pre || e.dot_out) return false;
+  if (N % RBN || K % (2 * RBK) || K < 1152 || !gemm_nt_ring_ok(lda, ldb, M, N, K, e)) return false;
+  const int tiles = cdiv(M, RBM) * (N / RBN);
+  return tiles >= 96 && tiles <= 256 && (size_t)tiles * 4 <= SPLITK_SYNC_BYTES && e.splitk_ws_bytes >= gemm_nt_splitk_workspace_bytes(M, N);
+}
+
+int gemm_nt_ring_splitk(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, hipStream_t st) {
+  const int tm = cdiv(M, RBM), tn = N / RBN;
+  hipLaunchKernelGGL((gemm_nt_ring_kernel<3, 0, 2>), dim3(2 * tm * tn), dim3(512), 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, 0, device_status_word_dev());
+  return check_launch("gemm_nt_ring_splitk");
 }
 
 int gemm_nt_ring(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, int slots, hipStream_t st, int dbg) {

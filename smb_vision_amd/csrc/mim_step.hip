@@ -121,17 +121,19 @@ static int mim_forward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const s
   {
     PrepList pl;
     pl.cast(p.pe_w, W.pe_w, c.d, K);
-    for (int l = 0; l < c.layers; l++) RC(prep_layer(pl, to_block(p.enc[l]), W.enc[l], de, st));
-    pl.cast(p.e2d_w, W.e2d, c.dd, c.d);
-    pl.tcast(p.e2d_w, W.e2d_t, c.dd, c.d, c.dd);
+    int first_block_end = 0;   // jobs [0, first_block_end): the patch-embedding weight and the first block's copies
+    for (int l = 0; l < c.layers; l++) {
+      RC(prep_layer(pl, to_block(p.enc[l]), W.enc[l], de, st));
+      if (l == 0) first_block_end = (int)pl.jobs.size();
+    }
+    pl.both(p.e2d_w, W.e2d, c.d, W.e2d_t, c.dd, c.dd, c.d);
     for (int l = 0; l < c.dlayers; l++) RC(prep_layer(pl, to_block(p.dec[l]), W.dec[l], dd, st));
-    pl.cast(p.head_w, W.head, K, c.dd);
-    pl.tcast(p.head_w, W.head_t, K, c.dd, K);
+    pl.both(p.head_w, W.head, c.dd, W.head_t, K, K, c.dd);
     // Only what the first kernels read goes ahead of them on `st`: the patch-embedding weight and the first block's copies (17 jobs, ~30 us; round 2 put
     // the first 64 jobs there, 113 us of the critical path).  Everything else - in the order the forward reaches it - runs on the library's side stream
     // beside the brick gather, the patch-embedding product and the first block, and is joined in front of the second block (0.3 ms of HBM-bound casts
     // against ~0.5 ms of main-stream work; head-padded configurations keep everything on `st`: prep_layer's zero fills are ordered on it)
-    const int njobs = (int)pl.jobs.size(), first = std::min(njobs, 1 + (int)layer_prep_job_count(de));
+    const int njobs = (int)pl.jobs.size(), first = std::min(njobs, first_block_end);
     const bool split = njobs > first && !de.padded() && !dd.padded();
     RC(prep_weights(pl.jobs.data(), split ? first : njobs, st));
     if (split) {

@@ -35,13 +35,23 @@ struct GemmEpi {
   float* dot_out = nullptr;
   int dot_dh = 64, dot_rows = 0;
   int dot_heads = 0;                // (filled in by gemm_nt: N / dot_dh)
+  // split-K scratch (gemm_nt_ring.hip, round 5): when set (gemm_nt_splitk_workspace_bytes, 256-byte aligned, its first 4 KiB ZERO at launch) gemm_nt runs a
+  // long-K product whose 256 x 128 tiles do not fill the chip as two K halves per tile; null: never.  Only smbv_gemm_nt_splitk sets it: in the steps the
+  // form measured SLOWER than the mixed-tile 128 x 128 launch (profiles/r05_splitk_ab.txt) and is not selected
+  void* splitk_ws = nullptr;
+  size_t splitk_ws_bytes = 0;
 };
+// split-K form of the ring kernel: is it the selection for this product, and what it needs
+bool gemm_nt_splitk_wanted(int lda, int ldb, int M, int N, int K, const GemmEpi& e);
+size_t gemm_nt_splitk_workspace_bytes(int M, int N);
+static constexpr size_t SPLITK_SYNC_BYTES = 4096;   // flag words in front of the partial tiles
 bool gemm_nt_rowdot_ok(int lda, int ldb, int M, int N, int K, const GemmEpi& e);
 
 int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, hipStream_t st);
 // second-generation NT kernel (gemm_nt_ring.hip): 256 x 128 tiles, LDS ring of K slices, register epilogue; gemm_nt dispatches to it
 bool gemm_nt_ring_ok(int lda, int ldb, int M, int N, int K, const GemmEpi& e);
 int gemm_nt_ring(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, int slots, hipStream_t st, int dbg = 0);
+int gemm_nt_ring_splitk(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e, hipStream_t st);
 // optional by-product of gemm_tn: the column sums of X over the M rows (the bias gradient of the linear whose weight gradient this is),
 // written as up to three segments of `seg` columns (fused q | k | v: three bias tensors; a null destination drops its segment)
 struct TnColsum {
@@ -109,11 +119,17 @@ int mse_bwd(const float* pix, const int* idx, int rows, int per_batch, const flo
 struct PrepJob {
   const float* src;
   void* dst;
+  void* dst2; // kind 4: the transposed bf16 copy [C, ldd2] (null: none)
   int R, C, ldd;
-  int kind;   // 0 cast, 1 cast + transpose, 2 fp32 copy of C elements, 3 zero-fill of C floats
+  int kind;   // 0 cast, 1 cast + transpose, 2 fp32 copy of C elements, 3 zero-fill of C floats, 4 ONE read of the fp32 master -> bf16 copy (dst, may be null) AND
+              // transposed bf16 copy (dst2, may be null), 64 x 64 tiles, 16-byte loads / 8-byte stores (round 5)
   int tile0;  // first block of this job
   int lds;    // source leading dimension (elements)
+  int ldd2;   // leading dimension of dst2
 };
+static inline int prep_job_tiles(const PrepJob& j) {
+  return j.kind == 4 ? (int)(((j.R + 63) / 64) * ((j.C + 63) / 64)) : (int)(((j.R + 31) / 32) * ((j.C + 31) / 32));
+}
 int prep_weights(const PrepJob* jobs_host, int njobs, hipStream_t st);  // jobs travel in the kernel arguments, 64 per launch
 int cast_f32_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st);
 int transpose_cast_f32_bf16(const float* src, bf16_t* dst, int R, int C, int ldd, hipStream_t st);

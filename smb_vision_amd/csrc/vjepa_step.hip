@@ -146,17 +146,19 @@ static int vjepa_forward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, c
   {
     PrepList pl;
     pl.cast(p.pe_w, W.pe_w, c.d, K);
-    for (int l = 0; l < c.layers; l++) RC(prep_layer(pl, vblock(p.enc[l]), W.enc[l], de, st));
+    int first_block_end = 0;   // jobs [0, first_block_end): the patch-embedding weight and the first block's copies
+    for (int l = 0; l < c.layers; l++) {
+      RC(prep_layer(pl, vblock(p.enc[l]), W.enc[l], de, st));
+      if (l == 0) first_block_end = (int)pl.jobs.size();
+    }
     if (with_pred) {
-      pl.cast(p.pemb_w, W.pemb, c.pd, c.d);
-      pl.tcast(p.pemb_w, W.pemb_t, c.pd, c.d, c.pd);
-      pl.cast(p.pproj_w, W.pproj, c.d, c.pd);
-      pl.tcast(p.pproj_w, W.pproj_t, c.d, c.pd, c.d);
+      pl.both(p.pemb_w, W.pemb, c.d, W.pemb_t, c.pd, c.pd, c.d);
+      pl.both(p.pproj_w, W.pproj, c.pd, W.pproj_t, c.d, c.d, c.pd);
       for (int l = 0; l < c.players; l++) RC(prep_layer(pl, vblock(p.pred[l]), W.pred[l], dp, st));
     }
     // as in mim_step.hip: what the first kernels read (patch-embedding weight + the first block's copies) on `st`, the rest on the side stream beside the
     // brick gather, the patch-embedding product and the first block, joined in front of the second block
-    const int njobs = (int)pl.jobs.size(), first = std::min(njobs, 1 + (int)layer_prep_job_count(de));
+    const int njobs = (int)pl.jobs.size(), first = std::min(njobs, first_block_end);
     const bool split = njobs > first && !de.padded() && !(with_pred && dp.padded());
     RC(prep_weights(pl.jobs.data(), split ? first : njobs, st));
     if (split) {

@@ -30,9 +30,10 @@ def _ws(nbytes, dev):
 
 
 def gemm_nt(A, B, *, bias=None, rowadd=None, rowidx=None, gelu=False, save_pre=False, dgelu_pre=None, out_bf16=True, out_f32=False,
-            alpha=1.0, grp=None, out_rows=None, reuse=None):
+            alpha=1.0, grp=None, out_rows=None, reuse=None, splitk=False):
     """C = epi(A[M,K] @ B[N,K]^T).  Returns dict with 'bf16', 'f32', 'pre' entries as requested.  reuse: a dict returned by an earlier call of the
-    same shape - its tensors are written again instead of allocating (and zero-filling) new ones (timing loops)."""
+    same shape - its tensors are written again instead of allocating (and zero-filling) new ones (timing loops).  splitk: smbv_gemm_nt_splitk (two K
+    halves per 256 x 128 tile; raises ValueError for a product that form does not take)."""
     _need_gpu(A, B)
     lib = _lib.load()
     M, K = A.shape
@@ -56,6 +57,13 @@ def gemm_nt(A, B, *, bias=None, rowadd=None, rowidx=None, gelu=False, save_pre=F
         e.out_f32, e.ld_of = res["f32"].data_ptr(), N
     if grp:
         e.grp_in, e.grp_out = grp
+    if splitk:
+        ws = (reuse or {}).get("splitk_ws")
+        if ws is None:
+            ws = _ws(lib.smbv_gemm_nt_splitk_workspace_bytes(M, N), A.device)
+        res["splitk_ws"] = ws
+        check(lib.smbv_gemm_nt_splitk(_p(A), A.stride(0), _p(B), B.stride(0), M, N, K, C.byref(e), _p(ws), ws.numel(), _stream()), "smbv_gemm_nt_splitk")
+        return res
     check(lib.smbv_gemm_nt(_p(A), A.stride(0), _p(B), B.stride(0), M, N, K, C.byref(e), _stream()), "smbv_gemm_nt")
     return res
 

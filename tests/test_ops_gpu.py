@@ -440,6 +440,47 @@ def test_gemm_nt_ring_kernel_matches_reference_and_first_generation(ops, M, N, K
                 assert torch.equal(a[k], b[k]), (v, k)
 
 
+@pytest.mark.parametrize("M,N,K", [(7168, 768, 3072), (7168, 768, 2304), (20480, 384, 1536), (20480, 384, 1152), (7168, 1024, 4096), (6200, 768, 1152)])
+def test_gemm_nt_splitk_hand_off_is_exact_and_leaves_no_state(ops, M, N, K):
+    """Round 5: the long-K / narrow-N products (fc2 forward, d_fc1 and d_qkv input gradients) as two K halves per 256 x 128 tile, the first half's fp32
+    partial handed to the second workgroup through scratch (gemm_nt_ring.hip KS = 2).  Checked against fp32 PyTorch at the ring kernel's tolerance and
+    against the unsplit product (same tiles, same MFMA: only the association of the K sum differs - a few fp32 ulps); and, as the guide asks of every
+    inter-workgroup hand-off, under REUSE of the scratch with CHANGING data: 24 launches alternating between two operand sets through one workspace, each
+    of which must reproduce its own first result bit for bit (a consumer that read a stale partial - last launch's, from a cache - or a flag left set
+    would show as the other set's numbers), with the device status word clean at the end.  A ragged last row of tiles (M = 6200) included."""
+    from smb_vision_amd import _lib
+    sets = []
+    for sd in (1, 11):
+        A = rnd(M, K, seed=sd).bfloat16()
+        B = rnd(N, K, seed=sd + 1, scale=0.05).bfloat16()
+        sets.append((A, B, rnd(N, seed=sd + 2), rnd(M, N, seed=sd + 3)))
+    firsts, reuse = [], None
+    for A, B, bias, resid in sets:
+        r = ops.gemm_nt(A, B, bias=bias, rowadd=resid, out_bf16=True, out_f32=True, splitk=True, reuse=None if reuse is None else {"bf16": torch.empty_like(reuse["bf16"]),
+                                                                                                              "f32": torch.empty_like(reuse["f32"]), "splitk_ws": reuse["splitk_ws"]})
+        reuse = r
+        ref = A.float() @ B.float().t() + bias + resid
+        assert rel_err(r["f32"], ref) < 1e-5 * math.sqrt(K) + 1e-5
+        plain = ops.gemm_nt(A, B, bias=bias, rowadd=resid, out_bf16=True, out_f32=True)
+        assert rel_err(r["f32"], plain["f32"]) < 2e-6 and float((r["bf16"].float() - plain["bf16"].float()).abs().max()) <= 2 ** -7 * float(plain["bf16"].float().abs().max())
+        firsts.append((r["f32"].clone(), r["bf16"].clone()))
+    out = {"bf16": torch.empty_like(reuse["bf16"]), "f32": torch.empty_like(reuse["f32"]), "splitk_ws": reuse["splitk_ws"]}
+    for it in range(24):
+        A, B, bias, resid = sets[it & 1]
+        r = ops.gemm_nt(A, B, bias=bias, rowadd=resid, out_bf16=True, out_f32=True, splitk=True, reuse=out)
+        assert torch.equal(r["f32"], firsts[it & 1][0]) and torch.equal(r["bf16"], firsts[it & 1][1]), it
+    torch.cuda.synchronize()
+    assert ops.device_status() == 0, _lib.last_error()
+    assert int(out["splitk_ws"][:4096].max()) == 0                      # every consumer cleared its flag
+    # other epilogues of the plain kind: scaled fp32 only, output-row remap
+    r = ops.gemm_nt(A, B, out_bf16=False, out_f32=True, alpha=0.5, splitk=True)
+    assert rel_err(r["f32"], 0.5 * (A.float() @ B.float().t())) < 1e-5 * math.sqrt(K) + 1e-5
+    with pytest.raises(ValueError):
+        ops.gemm_nt(A[:512], B, splitk=True)                              # 2 x 6 tiles: not a product this form takes
+    with pytest.raises(ValueError):
+        ops.gemm_nt(A, B, gelu=True, save_pre=True, splitk=True)          # GELU epilogues stay with the unsplit kernels
+
+
 @pytest.mark.parametrize("M,N,K", [(7168, 768, 768), (7168, 768, 3072), (13312, 384, 4096), (7000, 768, 320), (6450, 768, 64)])
 def test_gemm_nt_mixed_tile_launch_is_bitwise_the_plain_one(ops, M, N, K):
     """Grids of 257..384 tiles are launched with their last tile rows cut into 128 x 64 halves (gemm.hip: at most 1.5 tiles of work on any CU instead of
