@@ -6,7 +6,7 @@ reference's bf16-autocast policy (bf16 GEMM/attention operands, fp32 accumulatio
 goldens are pure fp32, so the comparison carries bf16 operand rounding (2^-9 relative per operand):
   loss   : |d| <= 5e-3 * |loss|
   logits : max|d| <= 3e-2 * max|logits|, rms(d) <= 1e-2 * rms(logits)
-  grads  : per tensor, ||d||_2 <= 6e-2 * ||g||_2  (and cosine >= 0.998)
+  grads  : per tensor, ||d||_2 <= 3.5e-2 * ||g||_2 (2.5e-2 for the golden fixtures; measured worst 1.7e-2 / 1.2e-2) and cosine >= 0.998
 """
 import os
 
@@ -47,7 +47,7 @@ def run_step(model, pix, mask, scale=None):
     return out.loss.detach().cpu(), out.logits.detach().float().cpu(), {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
 
 
-def check_against(loss, logits, grads, ref_loss, ref_logits, ref_grads, tl=5e-3, tg=6e-2):
+def check_against(loss, logits, grads, ref_loss, ref_logits, ref_grads, tl=5e-3, tg=3.5e-2):   # tg: 2 x the worst any configuration measures (1.7e-2: the step sweep's seed 8, round 5)
     assert abs(float(loss) - float(ref_loss)) <= tl * abs(float(ref_loss)), (float(loss), float(ref_loss))
     d = logits - ref_logits
     assert float(d.abs().max()) <= 3e-2 * float(ref_logits.abs().max())
@@ -76,7 +76,7 @@ def test_step_matches_reference_golden(name):
     pix, mask = blob["in.pixel_values"], blob["in.bool_masked_pos"].bool()
     loss, logits, grads = run_step(model, pix, mask)
     ref_grads = {k[5:]: v for k, v in blob.items() if k.startswith("grad.")}
-    worst = check_against(loss, logits, grads, blob["out.loss"], blob["out.logits"], ref_grads)
+    worst = check_against(loss, logits, grads, blob["out.loss"], blob["out.logits"], ref_grads, tg=2.5e-2)   # measured worst 1.16e-2 / 9.4e-3 (round 5)
     print(name, "loss", float(loss), "ref", float(blob["out.loss"]), "worst grad", worst)
 
 
