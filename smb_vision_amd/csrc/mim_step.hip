@@ -141,6 +141,8 @@ static int mim_forward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const s
       RC(prep_weights(pl.jobs.data() + first, njobs - first, prep_side.st));
       prep_join_layer = 1;
       // the target statistics depend on the volume and the mask only: same side stream, long done when the loss needs them
+      // (round 5 tried it elsewhere - forked beside the decoder's first blocks: +0.08 ms, profiles/r05_adamw_order_ab.txt; fused into the loss kernel, one pass over
+      // the masked bricks for both: +0.08 ms, profiles/r05_stats_loss_fused_ab.txt - the head of the step is HBM-bound anyway and absorbs these 218 MB best)
       RC(brick_stats(io.pixel_values, io.mask_idx, (int)Rm, c.Nmask, W.bmean, W.brinv, c.T, c.H, c.W, c.ts, c.ps, prep_side.st));
     }
   }

@@ -9,6 +9,7 @@
 #include "../../include/smbv.h"
 
 namespace smbv {
+extern int g_ab;
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
   v = wave_sum(v);
@@ -41,8 +42,11 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
   if (threadIdx.x == 0) *out = tot;
 }
 
-__global__ __launch_bounds__(256) void adamw_kernel(const smbv_adam_chunk* __restrict__ chunks, smbv_adam_hyper h, const float* __restrict__ gnorm_sq) {
-  const smbv_adam_chunk c = chunks[blockIdx.x];
+// (rev: the chunks in REVERSE table order.  The squared-norm pass in front of this kernel streams the gradient arena front to back, so what the 256-MiB
+// Infinity Cache still holds when the update starts is the arena's END: read first, those ~2/3 of the gradients come from the cache instead of HBM while the
+// other three streams - p, m, v - take the memory channels; profiles/r05_adamw_order_ab.txt)
+__global__ __launch_bounds__(256) void adamw_kernel(const smbv_adam_chunk* __restrict__ chunks, smbv_adam_hyper h, const float* __restrict__ gnorm_sq, int rev) {
+  const smbv_adam_chunk c = chunks[rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x];
   float coef = 1.0f;
   if (gnorm_sq && h.max_grad_norm > 0.f) coef = fminf(1.0f, h.max_grad_norm / (sqrtf(*gnorm_sq) + 1e-6f));
   const float lr = h.lr[c.group], wd = h.weight_decay[c.group];
@@ -87,7 +91,7 @@ int smbv_grad_sqnorm(const smbv_adam_chunk* chunks_dev, int nchunks, float* part
 int smbv_adamw_step(const smbv_adam_chunk* chunks_dev, int nchunks, const smbv_adam_hyper* h, const float* gnorm_sq, smbv_stream stream) {
   if (!chunks_dev || nchunks <= 0 || !h) { set_error("smbv_adamw_step: bad argument"); return SMBV_ERR_ARG; }
   if (h->bias_corr1 <= 0.f || h->bias_corr2 <= 0.f) { set_error("smbv_adamw_step: bias corrections must be positive"); return SMBV_ERR_ARG; }
-  hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, chunks_dev, *h, gnorm_sq);
+  hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, chunks_dev, *h, gnorm_sq, (gnorm_sq && !(g_ab & 2)) ? 1 : 0);
   return check_launch("adamw");
 }
 
