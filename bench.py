@@ -365,11 +365,13 @@ def b4_leg(model, opt, gen, pix, device, steps=5, warmup=2):
     return ms / B, info
 
 
-def reference_class_on_gpu(device, steps=3, warmup=2):
+def reference_class_on_gpu(device, steps=4, warmup=4):
     """The reference's model class on the SAME GPU, for scale (a diagnostic beside the metric; nothing of it is on the product path):
     transformers.VideoMAEForPreTraining (src/run_mim.py:13-21) on the bench workload under bf16 autocast (the Trainer's --bf16) with torch clip + fused
     AdamW, once with PyTorch-ROCm's own scaled_dot_product_attention ("sdpa": what the reference stack runs on an MI355X; flash-attn is not installed)
-    and once with only the attention swapped for the HIP kernels through transformers' attention registry ("smbv", smb_vision_amd/attention_plugin.py)."""
+    and once with only the attention swapped for the HIP kernels through transformers' attention registry ("smbv", smb_vision_amd/attention_plugin.py).
+    (Four warm-up steps: MIOpen benchmarks its Conv3d candidates - 113-ms naive kernels among them - during the class's first calls; with two warm-up steps that search
+    reached into the timed region and the leg read 56-71 ms for 'smbv' instead of 47, tools/r05_plugin_after_trainer.py.)"""
     from transformers import VideoMAEConfig, VideoMAEForPreTraining
     from smb_vision_amd.masking import MaskGenerator
     from smb_vision_amd import attention_plugin

@@ -66,6 +66,8 @@ int smbv_last_error(char* buf, size_t len);               /* copies the thread's
  * units of the attention kernels (forward default 2, backward 0), 1<<29 no stagger; 1<<30 the library's side streams at the lowest priority (read once, when
  * they are created). */
 void smbv_debug_set_variant(int bits);
+/* (A second A/B word, for tools only, is read ONCE from the environment variable SMBV_DEBUG_AB when the library is loaded - csrc/capi.hip lists its bits; unset
+ * / 0 on the product path.) */
 /* The device's sticky status (ABI 3000).  A kernel that detects a fault it cannot return - today: the attention backward's block scheduler finding a
  * scheduling word of another launch (0x5001 / 0x5003) or both of its tile queues exhausted (0x5002: a tile was skipped) - stores a code into 4 bytes of
  * host-mapped memory; every smbv_*_forward / _backward / smbv_attention_bwd call on that device then returns SMBV_ERR_STATE instead of enqueueing more

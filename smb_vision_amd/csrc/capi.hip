@@ -43,7 +43,7 @@ static GemmEpi to_epi(const smbv_gemm_epi* s) {
 
 int g_variant = 0;  // smbv_debug_set_variant (include/smbv.h): kernel selection for A/B tools and equivalence tests; 0 on the product path
 // second A/B word (the first one's 31 bits are taken): environment SMBV_DEBUG_AB, read once at load; 0 / unset on the product path.  Bits: 1 the inline
-// block backward keeps round 3's join in front of its QKV products; (tools/step_ab2.sh)
+// block backward keeps round 3's join in front of its QKV products; 2 adamw_kernel walks its chunk table front to back (tools/step_ab2.sh)
 int g_ab = [] { const char* e = getenv("SMBV_DEBUG_AB"); return e ? atoi(e) : 0; }();
 
 }  // namespace smbv
