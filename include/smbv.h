@@ -53,7 +53,7 @@ typedef uint16_t smbv_bf16;
  * major) and minor >= the newest entry point it calls.  2000: every *_cfg struct opens with `struct_bytes` (= sizeof of the caller's struct, checked
  * by the library: a binding compiled against a shorter or longer layout is refused with SMBV_ERR_ARG instead of being read past its end);
  * 1000-1002 (round 1-2) had no such guard and grew smbv_mim_cfg / smbv_vjepa_cfg in place.  3000 (round 4): smbv_attention_fwd / smbv_attention_bwd take
- * the residual output O_lo, the *_cfg structs end with attn_o_resid.  3001 (round 5, additive): smbv_gemm_nt_splitk + its workspace query. */
+ * the residual output O_lo, the *_cfg structs end with attn_o_resid.  3001 (round 5, additive): smbv_gemm_nt_splitk + its workspace query; 3002 (round 5, additive): smbv_attention_bwd_split + its workspace query. */
 #define SMBV_ABI_MAJOR 3
 int smbv_version(void);
 int smbv_last_error(char* buf, size_t len);               /* copies the thread's last error text; returns its length */
@@ -152,6 +152,17 @@ int smbv_attention_fwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* 
 size_t smbv_attention_fp8_workspace_bytes(int B, int S, int H);
 int smbv_attention_fwd_fp8(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, smbv_bf16* O, int ldo, float* LSE, int B, int S, int H,
                            int Dh, float scale, int Sq, int q_off, void* ws, size_t ws_bytes, smbv_stream stream);
+/* smbv_attention_bwd as the steps run it since round 5 (ABI 3002): given scratch, the one mixed-role launch runs the LAST tiles of each role - 192 of each when the
+ * role has at least twice as many - as TWO half sweeps by two workgroups (a key-owner tile over the first / second half of the query tiles, a query-owner tile over the
+ * first / second half of the key tiles), the first publishing its fp32 accumulators through ws, the second adding them and storing the gradients: the launch's
+ * partial last round of whole ~170-us tiles becomes half as coarse (-0.33 ms per ViT-base MIM step).  Two addends: run-to-run identical; against smbv_attention_bwd the
+ * split tiles' sums associate differently in fp32, before the one bf16 rounding.  ws: smbv_attention_bwd_split_workspace_bytes(B, S, H, Dh) bytes (0 when the shape is
+ * too small for any split), 256-B aligned, contents arbitrary; ws = NULL: exactly smbv_attention_bwd.  fp8_ws (may be NULL): as smbv_attention_bwd_fp8's ws - the query-owner blocks then
+ * recompute S and dP on the fp8 MFMA, half sweeps included. */
+size_t smbv_attention_bwd_split_workspace_bytes(int B, int S, int H, int Dh);
+int smbv_attention_bwd_split(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* O_lo, const smbv_bf16* dO,
+                             int ldo, const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S, int H, int Dh,
+                             float scale, int parts, int Sq, int q_off, void* ws, size_t ws_bytes, void* fp8_ws, size_t fp8_ws_bytes, smbv_stream stream);
 /* smbv_attention_bwd with the query-owner blocks' two recomputed products (S, dP) on the block-scaled fp8 MFMA (head_dim 64, parts = 6 or 7): Q, K, V, dO are
  * quantised to e4m3 rows with E8M0 scales per (token, head, 32 channels) into ws (smbv_attention_bwd_fp8_workspace_bytes, 256-B aligned) by four small
  * launches in front of the pair launch. */

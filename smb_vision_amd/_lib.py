@@ -10,7 +10,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsmbv.so")
 MAX_LAYERS = 48
-ABI_MAJOR, ABI_MINOR_NEEDED = 3, 1  # include/smbv.h SMBV_ABI_MAJOR; the newest entry point these bindings call
+ABI_MAJOR, ABI_MINOR_NEEDED = 3, 2  # include/smbv.h SMBV_ABI_MAJOR; the newest entry point these bindings call
 
 c_f = C.c_void_p  # all device pointers travel as void*
 
@@ -127,6 +127,9 @@ _SIGS = {
     "smbv_attention_fp8_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "smbv_attention_fwd_fp8": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, c_f, C.c_size_t, c_f]),
     "smbv_attention_bwd": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, c_f]),
+    "smbv_attention_bwd_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "smbv_attention_bwd_split": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                           C.c_int, C.c_int, c_f, C.c_size_t, c_f, C.c_size_t, c_f]),
     "smbv_attention_bwd_fp8_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "smbv_attention_bwd_fp8": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                          C.c_int, C.c_int, c_f, C.c_size_t, c_f]),

@@ -16,6 +16,8 @@
 #include "smbv_kernels.h"
 #include "block.h"
 #include <mutex>
+#include <cstring>
+#include <utility>
 #include <type_traits>
 
 namespace smbv {
@@ -111,6 +113,69 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // The next 128-query tile is copied into the other LDS buffer by LDS-DMA during sub-tiles 0..2 (two barriers per iteration: at the
 // top "everyone has left the previous tile", after sub-tile 2 "the new tile has landed"), so the last sub-tile prefetches across
 // the tile seam as well and the staging costs no registers.
+// ---- split sweeps (round 5) ------------------------------------------------------------------------------------------------------------------------
+// A tile of the pair launch is one whole sweep: ~170 us for an encoder tile, and 1,344 of them on 512 block slots leave the chip a partial last round
+// (profiles/r04_attn_pair_rounds.txt: ~10 % of the encoder launch).  The LAST tiles of each role can therefore run as two half sweeps - a key-owner tile over
+// the first / second half of the query tiles, a query-owner tile over the first / second half of the key tiles - by two workgroups: the first (`part` 0)
+// publishes its fp32 accumulators through scratch (register order, 1 KiB per wave-instruction, write-through stores, every wave drained, barrier, ONE flag
+// word), the second (`part` 1) waits for the flag (one lane polls, agent-scope acquire, barrier), adds them to its own and stores the gradients.  Roles are
+// fixed, two addends commute: run-to-run identical; against the whole sweep the association of the sum differs (fp32, before the one bf16 rounding).
+// Producers precede their consumers in the tile queue, wait for nothing, and a unit is only ever claimed by a RUNNING block: no cycle.
+struct SweepPart {
+  int t0 = 0, t1 = 0;            // sub-range of the swept tiles (t1 = 0: the whole sweep)
+  int part = -1;                 // -1 whole sweep, 0 producer half, 1 consumer half
+  f32x4* scratch = nullptr;      // this tile's partial accumulators
+  unsigned* flag = nullptr;      // 0 -> 1 by the producer, back to 0 by the consumer
+  unsigned* status = nullptr;    // the device's sticky fault word (a consumer that gives up waiting)
+};
+template <int OFF>
+__device__ __forceinline__ void bwd_store16_sc1(f32x4* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1" ::"v"(p), "v"(v), "i"(OFF) : "memory"); }
+// NV 16-byte pieces per lane: piece i of wave w at scratch[(w * NV + i) * 64 + lane]
+template <int NV>
+__device__ __forceinline__ void sweep_publish(const SweepPart& sp, const f32x4 (&v)[NV], int t, int w, int l) {
+  static_assert(NV % 4 == 0, "pieces go out four to an address register pair");
+  f32x4* p = sp.scratch + (size_t)w * (NV * 64) + l;
+#pragma unroll
+  for (int i = 0; i < NV; i += 4) {
+    bwd_store16_sc1<0>(p + i * 64, v[i]);
+    bwd_store16_sc1<1024>(p + i * 64, v[i + 1]);
+    bwd_store16_sc1<2048>(p + i * 64, v[i + 2]);
+    bwd_store16_sc1<3072>(p + i * 64, v[i + 3]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(sp.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// returns false (after raising the fault word) if the producer's flag never came; `ok` lives in LDS the block no longer uses
+template <int NV>
+__device__ __forceinline__ bool sweep_collect(const SweepPart& sp, f32x4 (&v)[NV], int t, int w, int l, int* ok) {
+  if (t == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(sp.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(8); spins++; }
+    *ok = spins < (1 << 22);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (!*ok) {
+    if (t == 0 && sp.status) __hip_atomic_store(sp.status, 0x5004u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return false;
+  }
+  const f32x4* p = sp.scratch + (size_t)w * (NV * 64) + l;
+#pragma unroll
+  for (int i = 0; i < NV; i += 4) {
+    f32x4 a[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) a[j] = p[(i + j) * 64];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[i + j] += a[j];
+    asm volatile("" : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3])::"memory");
+  }
+  __syncthreads();   // every wave holds its addends before the flag goes back to 0 for the next launch
+  if (t == 0) __hip_atomic_store(sp.flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
 template <int QT, int DH>
 struct DkvLds { static constexpr int BUF = 2 * QT * 2 * DH + 2 * QT * 4, BYTES = 2 * BUF; };
 
@@ -120,7 +185,8 @@ __device__ __forceinline__ void attn_dkv2_block(const bf16_t* __restrict__ Q, co
                                                 const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO,
                                                 int ldo, const float* __restrict__ LSE, const float* __restrict__ delta,
                                                 bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int ldd, int S, int Sq, int qoff,
-                                                int H, float scale, const int tile_x, const int head, const int b, unsigned char* smem) {
+                                                int H, float scale, const int tile_x, const int head, const int b, unsigned char* smem,
+                                                const SweepPart sp = SweepPart()) {
   static_assert(QT == 128, "the mid-iteration hand-over is written for 4 sub-tiles");
   static_assert(DH == 64 || DH == 32, "head widths with a native build");
   constexpr int NS = QT / 32;
@@ -197,7 +263,8 @@ __device__ __forceinline__ void attn_dkv2_block(const bf16_t* __restrict__ Q, co
     }
   };
 
-  const int nq = (Sq + QT - 1) / QT;
+  const int nq = sp.t1 > 0 ? sp.t1 : (Sq + QT - 1) / QT;   // this block sweeps query tiles [q_first, nq)
+  const int q_first = sp.t1 > 0 ? sp.t0 : 0;
   const int g1 = (l >> 4) & 1, qq = (l >> 2) & 3, pp = l & 3;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   // transposed fragment (s2, dt) of a row-major image: rows 16*s2 + 4*h2 + qq (+8), 16-byte chunk 4*dt + 2*g1 + (pp>>1)
@@ -211,8 +278,8 @@ __device__ __forceinline__ void attn_dkv2_block(const bf16_t* __restrict__ Q, co
     return __builtin_bit_cast(bf16x8, aa);
   };
 
-  stage(0, 0);
-  landed(0);
+  stage(0, q_first);
+  landed(q_first);
   put_stats(0);
   __syncthreads();
   bf16x8 qa[KS], da[KS];
@@ -227,8 +294,8 @@ __device__ __forceinline__ void attn_dkv2_block(const bf16_t* __restrict__ Q, co
     s = *(const f32x16*)((const float*)(sq + 2 * QT * RB) + 16 * h2);
     dp = *(const f32x16*)((const float*)(sq + 2 * QT * RB) + QT + 16 * h2);
   }
-  for (int qt = 0; qt < nq; qt++) {
-    const int buf = qt & 1;
+  for (int qt = q_first; qt < nq; qt++) {
+    const int buf = (qt - q_first) & 1;
     const bool more = qt + 1 < nq;
     __syncthreads();  // every wave has left the previous tile: its buffer may be overwritten
     if (more) stage(buf ^ 1, qt + 1);
@@ -329,6 +396,25 @@ __device__ __forceinline__ void attn_dkv2_block(const bf16_t* __restrict__ Q, co
     }
   }
 
+  if (sp.part >= 0) {   // half a sweep: the accumulators travel as 4 DT pieces of 16 bytes per lane (dK^T tiles, then dV^T tiles)
+    f32x4 pv[8 * DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        pv[4 * dt + rg] = (f32x4){dkt[dt][4 * rg], dkt[dt][4 * rg + 1], dkt[dt][4 * rg + 2], dkt[dt][4 * rg + 3]};
+        pv[4 * DT + 4 * dt + rg] = (f32x4){dvt[dt][4 * rg], dvt[dt][4 * rg + 1], dvt[dt][4 * rg + 2], dvt[dt][4 * rg + 3]};
+      }
+    __syncthreads();   // (the tile loop's LDS is dead: its first word carries the consumer's verdict)
+    if (sp.part == 0) { sweep_publish<8 * DT>(sp, pv, t, w, l); return; }
+    if (!sweep_collect<8 * DT>(sp, pv, t, w, l, (int*)smem)) return;
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) { dkt[dt][4 * rg + e] = pv[4 * dt + rg][e]; dvt[dt][4 * rg + e] = pv[4 * DT + 4 * dt + rg][e]; }
+  }
   if (key < S) {
     bf16_t* kp = dK + (row0 + key) * ldd + hoff;
     bf16_t* vp = dV + (row0 + key) * ldd + hoff;
@@ -572,7 +658,7 @@ __device__ __forceinline__ void attn_dq3_block(const bf16_t* __restrict__ Q, con
                                                const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO, int ldo,
                                                const float* __restrict__ LSE, const float* __restrict__ delta,
                                                bf16_t* __restrict__ dQ, int ldd, int S, int Sq, int qoff, int H, float scale,
-                                               const int tile_x, const int head, const int b, unsigned char* smem) {
+                                               const int tile_x, const int head, const int b, unsigned char* smem, const SweepPart sp = SweepPart()) {
   static_assert(KT == 128, "bodies are unrolled for 4 sub-tiles per tile");
   static_assert(DH == 64 || DH == 32, "head widths with a native build");
   constexpr int KK = DH / 32, DTN = DH / 16, RB = 2 * DH;
@@ -617,8 +703,11 @@ __device__ __forceinline__ void attn_dq3_block(const bf16_t* __restrict__ Q, con
 #pragma unroll
     for (int qi = 0; qi < 2; qi++) dqt[dt][qi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const i32x4 rsk = dma_rsrc(K + row0 * ld + hoff, (unsigned)(((size_t)(S - 1) * ld + DH) * 2));
-  const i32x4 rsv = dma_rsrc(V + row0 * ld + hoff, (unsigned)(((size_t)(S - 1) * ld + DH) * 2));
+  // half a sweep (sp.t1 > 0): key tiles [sp.t0, sp.t1) - the descriptors start at the first of them and end with the last (rows past it read zeros: no contribution)
+  const int k_first = sp.t1 > 0 ? sp.t0 * KT : 0;
+  const int Sk = (sp.t1 > 0 ? min(S, sp.t1 * KT) : S) - k_first;
+  const i32x4 rsk = dma_rsrc(K + (row0 + k_first) * ld + hoff, (unsigned)(((size_t)(Sk - 1) * ld + DH) * 2));
+  const i32x4 rsv = dma_rsrc(V + (row0 + k_first) * ld + hoff, (unsigned)(((size_t)(Sk - 1) * ld + DH) * 2));
   int og[NPC];
 #pragma unroll
   for (int i = 0; i < NPC; i++) og[i] = dma_src_off<DH>(w, i, l, ld);
@@ -666,7 +755,7 @@ __device__ __forceinline__ void attn_dq3_block(const bf16_t* __restrict__ Q, con
           o.v[kj][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kj][kk], bq[qi][kk], kk == 0 ? init[qi] : o.v[kj][qi], 0, 0, 0);
   };
 
-  const int nt = (S + KT - 1) / KT;
+  const int nt = (Sk + KT - 1) / KT;
   stage(0, 0);
   if (nt > 1) stage(1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -758,6 +847,20 @@ __device__ __forceinline__ void attn_dq3_block(const bf16_t* __restrict__ Q, con
     if (kt + 1 < nt) tile(kt + 1, 1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+  if (sp.part >= 0) {   // half a sweep: dQ^T as 2 DTN pieces of 16 bytes per lane
+    f32x4 pv[2 * DTN];
+#pragma unroll
+    for (int dt = 0; dt < DTN; dt++)
+#pragma unroll
+      for (int qi = 0; qi < 2; qi++) pv[2 * dt + qi] = dqt[dt][qi];
+    __syncthreads();
+    if (sp.part == 0) { sweep_publish<2 * DTN>(sp, pv, t, w, l); return; }
+    if (!sweep_collect<2 * DTN>(sp, pv, t, w, l, (int*)smem)) return;
+#pragma unroll
+    for (int dt = 0; dt < DTN; dt++)
+#pragma unroll
+      for (int qi = 0; qi < 2; qi++) dqt[dt][qi] = pv[2 * dt + qi];
+  }
 
 #pragma unroll
   for (int qi = 0; qi < 2; qi++) {
@@ -788,7 +891,7 @@ typedef int v8i_b __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void attn_dq_fp8_block(const Fp8BwdOps f8, const bf16_t* __restrict__ K, int ld, const float* __restrict__ LSE,
                                                   const float* __restrict__ delta, bf16_t* __restrict__ dQ, int ldd, int S, int Sq, int qoff, int H, float scale,
-                                                  const int tile_x, const int head, const int b, unsigned char* smem) {
+                                                  const int tile_x, const int head, const int b, unsigned char* smem, const SweepPart sp = SweepPart()) {
   constexpr int SLOT = DqF8Lds::SLOT;
   const int t = threadIdx.x, l = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -846,7 +949,9 @@ __device__ __forceinline__ void attn_dq_fp8_block(const Fp8BwdOps f8, const bf16
   };
   const int g1 = (l >> 4) & 1, qq = (l >> 2) & 3, pp = l & 3;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
-  const int nt = (S + 63) >> 6;
+  const int nt = (S + 63) >> 6;                                    // 64-key tiles of the sequence
+  const int kt_first = sp.t1 > 0 ? 2 * sp.t0 : 0;                  // half a sweep (sp counts 128-key tiles): this block's 64-key tiles [kt_first, kt_end)
+  const int kt_end = sp.t1 > 0 ? min(nt, 2 * sp.t1) : nt;
   // One 64-key tile out of ring slot `slot` (a literal: the loop below is unrolled over the ring, so every LDS read is a per-lane base hoisted out of the
   // loop plus an immediate - with the slot computed from kt the loop carried ~45 address adds per tile next to its 80 exponentials / multiplies / converts,
   // in a block that is vector-issue bound)
@@ -909,22 +1014,38 @@ __device__ __forceinline__ void attn_dq_fp8_block(const Fp8BwdOps f8, const bf16
     asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
-  stage(0, 0);
-  stage(1, 1);
-  for (int kt = 0; kt < nt; kt += 3) {
+  stage(kt_first, 0);
+  stage(kt_first + 1, 1);
+  for (int kt = kt_first; kt < kt_end; kt += 3) {
     landed();
     stage(kt + 2, 2);
     tile(kt, std::integral_constant<int, 0>{});
-    if (kt + 1 >= nt) break;
+    if (kt + 1 >= kt_end) break;
     landed();
     stage(kt + 3, 0);
     tile(kt + 1, std::integral_constant<int, 1>{});
-    if (kt + 2 >= nt) break;
+    if (kt + 2 >= kt_end) break;
     landed();
     stage(kt + 4, 1);
     tile(kt + 2, std::integral_constant<int, 2>{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+  if (sp.part >= 0) {   // half a sweep: dQ^T as 8 pieces of 16 bytes per lane (the layout of the 16x16x32 block's hand-off: same scratch size)
+    f32x4 pv[8];
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) pv[4 * dt + rg] = (f32x4){dqt[dt][4 * rg], dqt[dt][4 * rg + 1], dqt[dt][4 * rg + 2], dqt[dt][4 * rg + 3]};
+    __syncthreads();
+    if (sp.part == 0) { sweep_publish<8>(sp, pv, t, wv, l); return; }
+    if (!sweep_collect<8>(sp, pv, t, wv, l, (int*)smem)) return;
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) dqt[dt][4 * rg + e] = pv[4 * dt + rg][e];
+  }
   if (qok) {
     bf16_t* qp = dQ + ((size_t)b * S + qoff + q) * ldd + head * 64;
 #pragma unroll
@@ -958,11 +1079,13 @@ __global__ __launch_bounds__(256, 2) void attn_dq2_kernel(const bf16_t* __restri
 // the role the ticket's parity names - the CU's two resident blocks are then one of each kind whenever both kinds have tiles left - and claims the next
 // tile of that role from a device-side queue (or of the other role once its own is exhausted).  Which block computes which tile does not change a single
 // bit of the result: every tile's arithmetic is self-contained.
+static constexpr int PAIR_SPLIT_MAX = 256;   // at most this many tiles of each role run as two half sweeps
 struct PairState {            // one slot of the library's device-side scheduling state; a slot belongs to ONE stream of its device (attention_bwd, below)
   unsigned head[2];           // next unclaimed tile: [0] key-owner tiles, [1] query-owner tiles   } each word = (launch epoch & 0xfff) << 20 | count:
   unsigned done;              // blocks of the running launch that have ended                      } a launch only accepts words stamped with ITS epoch
   unsigned pad[13];
   unsigned cu_ticket[2048];   // arrival counter per CU, indexed by (XCC id, SE id, SH id, CU id): 3 + 3 + 1 + 4 bits (parity only: roles, never results)
+  unsigned split_flag[2][PAIR_SPLIT_MAX];   // hand-off flags of the split sweeps (SweepPart): zero at module load, cleared again by every consumer
 };
 __device__ PairState g_pair_state[8];
 static constexpr unsigned PAIR_COUNT_MASK = 0xfffffu;
@@ -978,12 +1101,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __r
                                                                const bf16_t* __restrict__ dO, int ldo, const float* __restrict__ LSE,
                                                                const float* __restrict__ delta, bf16_t* __restrict__ dQ, bf16_t* __restrict__ dK,
                                                                bf16_t* __restrict__ dV, int ldd, int B, int S, int Sq, int qoff, int H, float scale, int slot,
-                                                               unsigned epoch, unsigned* __restrict__ status, Fp8BwdOps f8) {
+                                                               unsigned epoch, unsigned* __restrict__ status, Fp8BwdOps f8, int xk, int xq, f32x4* __restrict__ split_ws) {
   constexpr int LDS = DkvLds<128, DH>::BYTES > DqLds<128, DH>::BYTES ? DkvLds<128, DH>::BYTES : DqLds<128, DH>::BYTES;
   static_assert(DqF8Lds::BYTES <= DkvLds<128, 64>::BYTES, "the fp8 query-owner block's ring fits the key-owner block's LDS");
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS];
   PairState& ps = g_pair_state[slot];
-  const unsigned n_kv = (unsigned)(((S + 127) / 128) * H * B), n_q = (unsigned)(((Sq + 127) / 128) * H * B);
+  // units of work per role: every tile once, except the LAST xk key-owner / xq query-owner tiles, which are two half sweeps each (SweepPart): the xk (xq)
+  // producer halves first, then the consumer halves - the queue's claim order
+  const unsigned t_kv = (unsigned)(((S + 127) / 128) * H * B), t_q = (unsigned)(((Sq + 127) / 128) * H * B);
+  const unsigned n_kv = t_kv + (unsigned)xk, n_q = t_q + (unsigned)xq;
   int* bc = (int*)smem;  // (the decision travels through LDS before any tile data does)
   if (threadIdx.x == 0) {
     const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
@@ -1009,15 +1135,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __r
     bc[1] = (int)tile;
   }
   __syncthreads();
-  const int role = bc[0], tile = bc[1];
+  const int role = bc[0];
+  int tile = bc[1];
   __syncthreads();  // everybody has read the decision before the tile data overwrites it
+  SweepPart sp;
+  if (role < 2) {   // a unit past the whole tiles is half a sweep of one of the role's last tiles
+    const int whole = (int)(role ? t_q : t_kv) - (role ? xq : xk), x = role ? xq : xk;
+    if (tile >= whole) {
+      const int j = tile - whole;
+      sp.part = j >= x ? 1 : 0;
+      const int js = j - sp.part * x;                                  // which of the split tiles
+      tile = whole + js;
+      const int swept = role ? (S + 127) / 128 : (Sq + 127) / 128;     // tiles of the sweep: a key-owner tile sweeps the query tiles, a query-owner tile the key tiles
+      sp.t0 = sp.part ? swept / 2 : 0;
+      sp.t1 = sp.part ? swept : swept / 2;
+      // scratch: key-owner partials (8 DH / 32 pieces x 256 lanes x 16 B each) first, then the query-owner partials (DH / 8 pieces)
+      constexpr int KV_F4 = 8 * (DH / 32) * 256, Q_F4 = (DH / 8) * 256;
+      sp.scratch = split_ws + (role ? (size_t)xk * KV_F4 + (size_t)js * Q_F4 : (size_t)js * KV_F4);
+      sp.flag = &ps.split_flag[role][js];
+      sp.status = status;
+    }
+  }
   if (role == 0) {
     const int nt = (S + 127) / 128;
-    attn_dkv2_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
+    attn_dkv2_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem, sp);
   } else if (role == 1) {
     const int nt = (Sq + 127) / 128;
-    if constexpr (QKIND == 2 && DH == 64) attn_dq_fp8_block(f8, K, ld, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
-    else if constexpr (QKIND == 1) attn_dq3_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
+    if constexpr (QKIND == 2 && DH == 64) attn_dq_fp8_block(f8, K, ld, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem, sp);
+    else if constexpr (QKIND == 1) attn_dq3_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem, sp);
     else attn_dq2_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
   }
   // the block that ends last (every other block has claimed its tile long ago) hands the slot over stamped with the NEXT epoch: no memset node in front of
@@ -1099,9 +1244,46 @@ int pair_state_debug(int op, hipStream_t st) {
   return check_launch("pair_state_debug");
 }
 
+// how many tiles of each role the pair launch runs as two half sweeps: 192 of each (in-box A/B at the step's shapes, profiles/r05_pair_split_ab.txt: 0 / 128 / 192 /
+// 256 -> 25.66 / 25.53 / 25.32 / 25.49 ms per step); tuning override: environment SMBV_PAIR_SPLIT = "x" or "xk,xq", read once; 0 = none
+static void pair_split_request(int& wk, int& wq) {
+  static const std::pair<int, int> v = [] {
+    const char* e = getenv("SMBV_PAIR_SPLIT");
+    int a = 192, b = 192;
+    if (e) { a = b = atoi(e); const char* c = strchr(e, ','); if (c) b = atoi(c + 1); }
+    return std::make_pair(std::max(0, std::min(a, PAIR_SPLIT_MAX)), std::max(0, std::min(b, PAIR_SPLIT_MAX)));
+  }();
+  wk = v.first; wq = v.second;
+}
+// the split of one launch: a role is split only if its sweep has at least four tiles (two per half) and it has at least twice as many tiles as are split - and
+// nothing is split when the launch's tiles fill a whole number of rounds of the chip's block slots anyway (two blocks per CU at head_dim 64, three at 32): there the
+// halves only add their prologues and the hand-off (ViT-large's decoder, 2,560 tiles = 5.0 rounds: +0.6 ms per step with the split, profiles/r05_pair_split_ab.txt)
+void attention_bwd_split_counts(int B, int S, int Sq, int H, int Dh, bool q_splittable, int& xk, int& xq) {
+  int wk, wq;
+  pair_split_request(wk, wq);
+  const int t_kv = cdiv(S, 128) * H * B, t_q = cdiv(Sq, 128) * H * B;
+  const int slots = 256 * (Dh == 64 ? 2 : 3), last = (t_kv + t_q) % slots;
+  if (last < slots / 32 && t_kv + t_q >= slots) { xk = xq = 0; return; }
+  xk = (cdiv(Sq, 128) >= 4 && t_kv >= 2 * wk) ? wk : 0;
+  xq = (q_splittable && cdiv(S, 128) >= 4 && t_q >= 2 * wq) ? wq : 0;
+}
+size_t attention_bwd_split_workspace_bytes(int Dh, int xk, int xq) {
+  return ((size_t)xk * 8 * (Dh / 32) * 256 + (size_t)xq * (Dh / 8) * 256) * sizeof(f32x4);
+}
+// what a block of these dimensions can ask for (its launches may sweep a query sub-range: fewer tiles, never more)
+size_t attention_bwd_split_workspace_max(int B, int S, int H, int Dh) {
+  int xk, xq;
+  int wk, wq;
+  pair_split_request(wk, wq);   // (an upper bound over the launches of a block of these dimensions: a ranged launch has fewer tiles and another round count)
+  const int t = cdiv(S, 128) * H * B;
+  xk = t >= 2 * wk ? wk : 0;
+  xq = t >= 2 * wq ? wq : 0;
+  return attention_bwd_split_workspace_bytes(Dh, xk, xq);
+}
+
 int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
                   float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st,
-                  const bf16_t* O_lo, void* f8ws, size_t f8ws_bytes) {
+                  const bf16_t* O_lo, void* f8ws, size_t f8ws_bytes, void* split_ws, size_t split_ws_bytes) {
   if (Sq <= 0) { Sq = S; qoff = 0; }
   if (qoff < 0 || qoff + Sq > S) { set_error("attention_bwd: query range outside the sequence"); return SMBV_ERR_SHAPE; }
   if (Dh != 64 && Dh != 32) { set_error("attention_bwd: head_dim %d not supported (64 or 32; other widths run zero-padded in 64-wide slots, block.h)", Dh); return SMBV_ERR_SHAPE; }
@@ -1123,7 +1305,16 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
   const int slot = ((parts & 6) == 6 && !(g_variant & 524288)) ? pair_slot_for(st, &dev) : -1;
   if (slot >= 0) {
     // everything that can fail comes BEFORE the launch epoch is consumed: the tile-count check, the fp8 operand pre-pass (workspace size / alignment, its launches)
-    const int blocks = (cdiv(S, 128) + cdiv(Sq, 128)) * H * B;
+    // the last tiles of each role as two half sweeps (SweepPart) when the caller handed over scratch: as many as keep the launch's last round fine-grained
+    int xk = 0, xq = 0;
+    const int t_kv = cdiv(S, 128) * H * B, t_q = cdiv(Sq, 128) * H * B;
+    if (split_ws && !((uintptr_t)split_ws & 255) && !(g_variant & 16)) {
+      // (the 32x32x16 query-owner block - debug bit 2 - sweeps whole: the shipped 16x16x32 block and the fp8 block have the half-sweep form)
+      const bool fp8_blocks = f8ws != nullptr && Dh == 64 && !(g_variant & 8);
+      attention_bwd_split_counts(B, S, Sq, H, Dh, fp8_blocks || !(g_variant & 2), xk, xq);
+      if (attention_bwd_split_workspace_bytes(Dh, xk, xq) > split_ws_bytes) xk = xq = 0;
+    }
+    const int blocks = t_kv + t_q + xk + xq;
     if ((unsigned)blocks >= PAIR_COUNT_MASK) { set_error("attention_bwd: %d tiles exceed the pair launch's 20-bit tile counters", blocks); return SMBV_ERR_SHAPE; }
     unsigned* status = device_status_word_dev();   // host-mapped; null if it could not be created (faults then go unreported, as before round 4)
     const bool q16 = !(g_variant & 2);   // A/B: bit 1 = the query-owner block on the 32x32x16 MFMA (attn_dq2_block)
@@ -1131,7 +1322,7 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     const bool fp8q = f8ws != nullptr && Dh == 64 && !(g_variant & 8);   // (debug bit 8: bf16 query-owner blocks although fp8 operands were offered)
     if (fp8q) RC(attention_bwd_fp8_prepare(Q, K, V, ld, dO, ldo, B, S, H, scale, f8ws, f8ws_bytes, st, &f8));
     const unsigned epoch = pair_epoch_take(dev, slot);
-#define SMBV_PAIR_LAUNCH(DHV, KIND) hipLaunchKernelGGL((attn_bwd_pair_kernel<DHV, KIND>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot, epoch, status, f8)
+#define SMBV_PAIR_LAUNCH(DHV, KIND) hipLaunchKernelGGL((attn_bwd_pair_kernel<DHV, KIND>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot, epoch, status, f8, xk, xq, (f32x4*)split_ws)
     if (fp8q) SMBV_PAIR_LAUNCH(64, 2);
     else if (Dh == 64 && q16) SMBV_PAIR_LAUNCH(64, 1);
     else if (Dh == 64) SMBV_PAIR_LAUNCH(64, 0);

@@ -51,6 +51,8 @@ struct BwdScratch {  // sized for the widest block of the model (d_act, d_qkv an
   size_t f8ws_bytes = 0;
   void* wscratch;       // gemm_tn slabs + column-sum partials of the weight-gradient products that run on the side stream
   size_t wscratch_bytes;
+  void* attn_split = nullptr;   // partial accumulators of the attention backward's split sweeps (attention_bwd.hip SweepPart)
+  size_t attn_split_bytes = 0;
 };
 
 struct ForkJoin {  // streams.hip
@@ -130,7 +132,7 @@ void carve_layer(Carver& c, LayerWs& L, const BlockDims& d, const LayerWs* share
 // appends this block's weight-preparation jobs; for padded heads also enqueues the zero fills of the padded buffers on `st`
 int prep_layer(PrepList& pl, const BlockPtrs& p, LayerWs& L, const BlockDims& d, hipStream_t st);
 struct BwdNeeds {  // running maxima over the blocks of a model (elements, except scratch / wscratch: bytes)
-  size_t act = 0, we = 0, qkv = 0, gpad = 0, gpad_b = 0, delta = 0, scratch = 0, wscratch = 0, f8 = 0;
+  size_t act = 0, we = 0, qkv = 0, gpad = 0, gpad_b = 0, delta = 0, scratch = 0, wscratch = 0, f8 = 0, attn_split = 0;
 };
 void bwd_scratch_requirements(const BlockDims& d, BwdNeeds& n);
 void carve_bwd_scratch(Carver& cv, BwdScratch& sc, const BwdNeeds& n);  // everything of BwdScratch except gath0 / gath1

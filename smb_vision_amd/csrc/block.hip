@@ -82,6 +82,7 @@ void bwd_scratch_requirements(const BlockDims& d, BwdNeeds& n) {
   auto tn = [&](size_t M, size_t n1, size_t n2) { n.wscratch = std::max(n.wscratch, gemm_tn_workspace_bytes((int)M, (int)n1, (int)n2)); };
   tn(rows, w, ff); tn(rows, ff, w); tn(rows, w, wa); tn(rows, 3 * wa, w); tn(rows, w, w);
   n.scratch = std::max(n.scratch, layernorm_bwd_workspace_bytes((int)rows, (int)w));
+  n.attn_split = std::max(n.attn_split, attention_bwd_split_workspace_max(d.B, d.S, d.H, d.slot()));
   if (d.attn_fp8) n.f8 = std::max(n.f8, attention_fp8_workspace_bytes(d.B, d.S, d.H));
   if (d.attn_fp8 & 2) n.f8 = std::max(n.f8, attention_bwd_fp8_workspace_bytes(d.B, d.S, d.H));
 }
@@ -98,6 +99,8 @@ void carve_bwd_scratch(Carver& cv, BwdScratch& sc, const BwdNeeds& n) {
   sc.wscratch_bytes = n.wscratch;
   sc.f8ws = n.f8 ? cv.take<char>(n.f8) : nullptr;
   sc.f8ws_bytes = n.f8;
+  sc.attn_split = n.attn_split ? cv.take<char>(n.attn_split) : nullptr;
+  sc.attn_split_bytes = n.attn_split;
 }
 
 int layer_fwd(const BlockPtrs& p, LayerWs& L, const BlockDims& d, BwdScratch& sc, const float* x_in, float* x_out, bf16_t* x_out_bf16, int Sq, int qoff,
@@ -293,7 +296,7 @@ int layer_bwd_core(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const Bl
   // ---- attention (dQ exists only for the ranged queries; dK/dV for every token) ----
   if (ranged) HIPRC(hipMemsetAsync(bf.d_qkv, 0, (size_t)M * 3 * wa * sizeof(bf16_t), st));
   RC(attention_bwd(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, sc.d_o, wa, L.lse, sc.delta, bf.d_qkv, bf.d_qkv + wa, bf.d_qkv + 2 * wa, 3 * wa, B,
-                   S, H, d.slot(), d.scale(), delta_fused ? 6 : 7, Sq, qoff, st, L.attn_o_lo, (d.attn_fp8 & 2) && d.slot() == 64 ? sc.f8ws : nullptr, sc.f8ws_bytes));
+                   S, H, d.slot(), d.scale(), delta_fused ? 6 : 7, Sq, qoff, st, L.attn_o_lo, (d.attn_fp8 & 2) && d.slot() == 64 ? sc.f8ws : nullptr, sc.f8ws_bytes, sc.attn_split, sc.attn_split_bytes));
   if (d.rope_grid > 0) RC(rope3d(bf.d_qkv, 3 * wa, wa, M, S, H, d.slot(), d.Dh, d.rope_grid, d.pos, d.rope_table, 1, st));
   // ---- QKV ----
   if (!defer) {

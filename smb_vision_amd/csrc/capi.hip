@@ -52,7 +52,7 @@ using namespace smbv;
 
 extern "C" {
 
-int smbv_version(void) { return 3001; }  // 3000: O_lo in smbv_attention_fwd / _bwd, attn_o_resid in the *_cfg structs; see include/smbv.h
+int smbv_version(void) { return 3002; }  // 3000: O_lo in smbv_attention_fwd / _bwd, attn_o_resid in the *_cfg structs; see include/smbv.h
 void smbv_debug_set_variant(int bits) { smbv::g_variant = bits; }
 int smbv_device_status(int clear) { return smbv::device_status(clear != 0); }
 int smbv_debug_pair_state(int op, smbv_stream stream) { return smbv::pair_state_debug(op, (hipStream_t)stream); }
@@ -139,6 +139,20 @@ int smbv_attention_bwd(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* 
   if (!Q || !K || !V || !O || !dO || !LSE || !delta || !dQ || !dK || !dV) { set_error("smbv_attention_bwd: null operand"); return SMBV_ERR_ARG; }
   SMBV_CHECK_DEVICE_STATE();
   return attention_bwd(Q, K, V, ld, O, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, H, Dh, scale, parts, Sq, q_off, (hipStream_t)stream, O_lo);
+}
+
+size_t smbv_attention_bwd_split_workspace_bytes(int B, int S, int H, int Dh) { return (Dh == 64 || Dh == 32) ? attention_bwd_split_workspace_max(B, S, H, Dh) : 0; }
+int smbv_attention_bwd_split(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* O_lo, const smbv_bf16* dO, int ldo,
+                             const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S, int H, int Dh, float scale,
+                             int parts, int Sq, int q_off, void* ws, size_t ws_bytes, void* fp8_ws, size_t fp8_ws_bytes, smbv_stream stream) {
+  if (!Q || !K || !V || !O || !dO || !LSE || !delta || !dQ || !dK || !dV) { set_error("smbv_attention_bwd_split: null operand"); return SMBV_ERR_ARG; }
+  if (fp8_ws && (Dh != 64 || (parts & 6) != 6)) { set_error("smbv_attention_bwd_split: the fp8 query-owner blocks need head_dim 64 and both gradient parts"); return SMBV_ERR_SHAPE; }
+  if (ws && (((uintptr_t)ws & 255) || ws_bytes < smbv_attention_bwd_split_workspace_bytes(B, S, H, Dh))) {
+    set_error("smbv_attention_bwd_split: workspace short or misaligned (%zu < %zu)", ws_bytes, smbv_attention_bwd_split_workspace_bytes(B, S, H, Dh));
+    return SMBV_ERR_WORKSPACE;
+  }
+  SMBV_CHECK_DEVICE_STATE();
+  return attention_bwd(Q, K, V, ld, O, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, H, Dh, scale, parts, Sq, q_off, (hipStream_t)stream, O_lo, fp8_ws, fp8_ws_bytes, ws, ws_bytes);
 }
 
 size_t smbv_attention_bwd_fp8_workspace_bytes(int B, int S, int H) { return attention_bwd_fp8_workspace_bytes(B, S, H); }

@@ -89,7 +89,10 @@ int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf1
                   float scale, int Sq, int qoff, hipStream_t st, bf16_t* O_lo = nullptr);
 int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
                   float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st,
-                  const bf16_t* O_lo = nullptr, void* f8ws = nullptr, size_t f8ws_bytes = 0);
+                  const bf16_t* O_lo = nullptr, void* f8ws = nullptr, size_t f8ws_bytes = 0, void* split_ws = nullptr, size_t split_ws_bytes = 0);
+// split_ws (256-byte aligned, attention_bwd_split_workspace_max bytes): the pair launch runs the last tiles of each role as two half sweeps (attention_bwd.hip SweepPart)
+size_t attention_bwd_split_workspace_bytes(int Dh, int xk, int xq);
+size_t attention_bwd_split_workspace_max(int B, int S, int H, int Dh);
 // f8ws != null (head_dim 64, the one-launch pair): the query-owner blocks recompute S and dP on the block-scaled fp8 MFMA (BASELINE config 5)
 
 // fp8 operands of the attention backward's query-owner blocks (attention_fp8.hip attention_bwd_fp8_prepare -> attention_bwd.hip attn_dq_fp8_block)

@@ -179,19 +179,27 @@ def attention_fwd_fp8(qkv, B, S, H, scale=None, Sq=0, q_off=0):
     return O, lse
 
 
-def attention_bwd(qkv, O, dO, lse, B, S, H, scale=None, parts=7, out=None, Sq=0, q_off=0, Dh=64, O_lo=None, fp8=False, fp8_ws_short=0):
+def attention_bwd(qkv, O, dO, lse, B, S, H, scale=None, parts=7, out=None, Sq=0, q_off=0, Dh=64, O_lo=None, fp8=False, fp8_ws_short=0, split=None):
     """fp8: the query-owner blocks recompute S and dP on the block-scaled fp8 MFMA (smbv_attention_bwd_fp8; head_dim 64).  fp8_ws_short: declare the
-    workspace that many bytes smaller than it is (the error-path test)."""
+    workspace that many bytes smaller than it is (the error-path test).  split: True (a fresh scratch) or a uint8 scratch tensor - smbv_attention_bwd_split, the
+    form the steps run (the last tiles of each role as two half sweeps)."""
     _need_gpu(qkv, O, dO, lse)
     lib = _lib.load()
     w = H * Dh
     scale = scale if scale is not None else Dh ** -0.5
     dqkv, delta = out if out is not None else (torch.zeros_like(qkv), torch.empty(B, H, Sq if Sq > 0 else S, dtype=torch.float32, device=qkv.device))
     base, dbase = qkv.data_ptr(), dqkv.data_ptr()
-    if fp8:
+    if fp8 and (split is None or split is False):
         ws = _ws(lib.smbv_attention_bwd_fp8_workspace_bytes(B, S, H), qkv.device)
         check(lib.smbv_attention_bwd_fp8(base, base + 2 * w, base + 4 * w, qkv.stride(0), _p(O), _p(O_lo), _p(dO), w, _p(lse), _p(delta), dbase, dbase + 2 * w,
                                          dbase + 4 * w, dqkv.stride(0), B, S, H, Dh, scale, parts, Sq, q_off, _p(ws), ws.numel() - fp8_ws_short, _stream()), "smbv_attention_bwd_fp8")
+        return dqkv, delta
+    if split is not None and split is not False:
+        ws = split if torch.is_tensor(split) else _ws(max(256, lib.smbv_attention_bwd_split_workspace_bytes(B, S, H, Dh)), qkv.device)
+        f8 = _ws(lib.smbv_attention_bwd_fp8_workspace_bytes(B, S, H), qkv.device) if fp8 else None
+        check(lib.smbv_attention_bwd_split(base, base + 2 * w, base + 4 * w, qkv.stride(0), _p(O), _p(O_lo), _p(dO), w, _p(lse), _p(delta), dbase, dbase + 2 * w,
+                                           dbase + 4 * w, dqkv.stride(0), B, S, H, Dh, scale, parts, Sq, q_off, _p(ws), ws.numel(), _p(f8), f8.numel() if fp8 else 0,
+                                           _stream()), "smbv_attention_bwd_split")
         return dqkv, delta
     check(lib.smbv_attention_bwd(base, base + 2 * w, base + 4 * w, qkv.stride(0), _p(O), _p(O_lo), _p(dO), w, _p(lse), _p(delta), dbase, dbase + 2 * w,
                                  dbase + 4 * w, dqkv.stride(0), B, S, H, Dh, scale, parts, Sq, q_off, _stream()), "smbv_attention_bwd")

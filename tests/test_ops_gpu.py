@@ -637,6 +637,53 @@ def test_attention_backward_scheduling_fault_is_an_error_not_wrong_gradients(ops
     assert torch.equal(again, want) and ops.device_status() == 0
 
 
+@pytest.mark.parametrize("B,S,H,Dh,Sq,qoff", [(1, 7168, 12, 64, 0, 0), (1, 20480, 6, 64, 13312, 7168), (2, 4096, 6, 64, 0, 0), (1, 7168, 12, 32, 0, 0), (1, 6100, 8, 64, 0, 0)])
+def test_attention_backward_split_sweeps_hand_off_exactly(ops, B, S, H, Dh, Sq, qoff):
+    """Round 5: smbv_attention_bwd_split - the pair launch's last 192 tiles of each role as two half sweeps whose fp32 accumulators are handed from one workgroup to
+    the next through scratch (attention_bwd.hip SweepPart).  Against the unsplit launch the split tiles' sums only associate differently before the one bf16
+    rounding: every gradient within a bf16 ulp of its row's scale, and NOT a single element different outside the split tiles' rows would be too strong a claim
+    to test cheaply - the norm bound is what is pinned.  And, as for every inter-workgroup hand-off: 16 launches alternating two operand sets through ONE scratch
+    buffer, each reproducing its own first result bit for bit (a stale partial or a flag left set would show as the other set's numbers), the status word clean.
+    Shapes: the encoder grid, the ranged decoder block (13,312 of 20,480 queries), batch 2, head_dim 32, a ragged last tile."""
+    from smb_vision_amd import _lib
+    lib = _lib.load()
+    need = lib.smbv_attention_bwd_split_workspace_bytes(B, S, H, Dh)
+    assert need > 0                                                # these grids are large enough to split (384+ tiles per role)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    sets = [_bwd_case(ops, B, S, H, Dh, Sq, qoff, seed=sd) for sd in (61, 71)]
+    firsts = []
+    for qkv, O, lse, dO in sets:
+        whole, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh)
+        split, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh, split=ws)
+        torch.cuda.synchronize()
+        assert ops.device_status() == 0, _lib.last_error()
+        d = (split.float() - whole.float())
+        assert float(d.norm()) <= 2e-3 * float(whole.float().norm())                      # measured ~3e-4: bf16 re-rounding of sums that differ in their last fp32 bits
+        assert float(d.abs().max()) <= 2.0 ** -6 * float(whole.float().abs().max())
+        firsts.append(split.clone())
+    out = (torch.empty_like(firsts[0]), torch.empty(B, H, Sq if Sq > 0 else S, dtype=torch.float32, device="cuda"))
+    for it in range(16):
+        qkv, O, lse, dO = sets[it & 1]
+        if Sq > 0:
+            out[0].zero_()                                                                # (rows outside the query range carry no dQ: the op leaves them as it finds them)
+        got, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh, split=ws, out=out)
+        assert torch.equal(got, firsts[it & 1]), it
+    torch.cuda.synchronize()
+    assert ops.device_status() == 0, _lib.last_error()
+    with pytest.raises(_lib.SmbvError, match="rc=-4"):
+        ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh, split=ws[: need - 256])
+    if Dh == 64:   # the fp8 query-owner blocks' half sweeps (config 5): dK / dV are the bf16 blocks' and stay bit-identical to the bf16 split launch, dQ within e4m3 noise of it
+        f8_whole, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh, fp8=True)
+        f8_split, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh, fp8=True, split=ws)
+        again, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh, fp8=True, split=ws)
+        torch.cuda.synchronize()
+        assert ops.device_status() == 0, _lib.last_error()
+        w = H * Dh
+        assert torch.equal(f8_split, again) and torch.equal(f8_split[:, w:], firsts[1][:, w:])
+        dq = f8_split[:, :w].float() - f8_whole[:, :w].float()
+        assert float(dq.norm()) <= 2e-3 * float(f8_whole[:, :w].float().norm())
+
+
 def test_attention_backward_argument_error_does_not_poison_the_stream(ops):
     """an attention backward that returns an error AFTER its stream's scheduling slot was looked up - here smbv_attention_bwd_fp8 with a
     workspace one byte short: SMBV_ERR_WORKSPACE from the operand pre-pass - must not consume the slot's launch epoch: the next (valid) launch on the same
