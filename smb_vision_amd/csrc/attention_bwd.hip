@@ -121,60 +121,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // word), the second (`part` 1) waits for the flag (one lane polls, agent-scope acquire, barrier), adds them to its own and stores the gradients.  Roles are
 // fixed, two addends commute: run-to-run identical; against the whole sweep the association of the sum differs (fp32, before the one bf16 rounding).
 // Producers precede their consumers in the tile queue, wait for nothing, and a unit is only ever claimed by a RUNNING block: no cycle.
-struct SweepPart {
-  int t0 = 0, t1 = 0;            // sub-range of the swept tiles (t1 = 0: the whole sweep)
-  int part = -1;                 // -1 whole sweep, 0 producer half, 1 consumer half
-  f32x4* scratch = nullptr;      // this tile's partial accumulators
-  unsigned* flag = nullptr;      // 0 -> 1 by the producer, back to 0 by the consumer
-  unsigned* status = nullptr;    // the device's sticky fault word (a consumer that gives up waiting)
-};
-template <int OFF>
-__device__ __forceinline__ void bwd_store16_sc1(f32x4* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1" ::"v"(p), "v"(v), "i"(OFF) : "memory"); }
-// NV 16-byte pieces per lane: piece i of wave w at scratch[(w * NV + i) * 64 + lane]
-template <int NV>
-__device__ __forceinline__ void sweep_publish(const SweepPart& sp, const f32x4 (&v)[NV], int t, int w, int l) {
-  static_assert(NV % 4 == 0, "pieces go out four to an address register pair");
-  f32x4* p = sp.scratch + (size_t)w * (NV * 64) + l;
-#pragma unroll
-  for (int i = 0; i < NV; i += 4) {
-    bwd_store16_sc1<0>(p + i * 64, v[i]);
-    bwd_store16_sc1<1024>(p + i * 64, v[i + 1]);
-    bwd_store16_sc1<2048>(p + i * 64, v[i + 2]);
-    bwd_store16_sc1<3072>(p + i * 64, v[i + 3]);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (t == 0) __hip_atomic_store(sp.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// returns false (after raising the fault word) if the producer's flag never came; `ok` lives in LDS the block no longer uses
-template <int NV>
-__device__ __forceinline__ bool sweep_collect(const SweepPart& sp, f32x4 (&v)[NV], int t, int w, int l, int* ok) {
-  if (t == 0) {
-    int spins = 0;
-    while (__hip_atomic_load(sp.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(8); spins++; }
-    *ok = spins < (1 << 22);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-  if (!*ok) {
-    if (t == 0 && sp.status) __hip_atomic_store(sp.status, 0x5004u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return false;
-  }
-  const f32x4* p = sp.scratch + (size_t)w * (NV * 64) + l;
-#pragma unroll
-  for (int i = 0; i < NV; i += 4) {
-    f32x4 a[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) a[j] = p[(i + j) * 64];
-#pragma unroll
-    for (int j = 0; j < 4; j++) v[i + j] += a[j];
-    asm volatile("" : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3])::"memory");
-  }
-  __syncthreads();   // every wave holds its addends before the flag goes back to 0 for the next launch
-  if (t == 0) __hip_atomic_store(sp.flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return true;
-}
+// (SweepPart and its hand-off helpers - sweep_publish / sweep_collect - live in smbv_common.h: the forward kernel splits its last tiles the same way)
 
 template <int QT, int DH>
 struct DkvLds { static constexpr int BUF = 2 * QT * 2 * DH + 2 * QT * 4, BYTES = 2 * BUF; };
