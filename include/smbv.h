@@ -53,7 +53,8 @@ typedef uint16_t smbv_bf16;
  * major) and minor >= the newest entry point it calls.  2000: every *_cfg struct opens with `struct_bytes` (= sizeof of the caller's struct, checked
  * by the library: a binding compiled against a shorter or longer layout is refused with SMBV_ERR_ARG instead of being read past its end);
  * 1000-1002 (round 1-2) had no such guard and grew smbv_mim_cfg / smbv_vjepa_cfg in place.  3000 (round 4): smbv_attention_fwd / smbv_attention_bwd take
- * the residual output O_lo, the *_cfg structs end with attn_o_resid.  3001 (round 5, additive): smbv_gemm_nt_splitk + its workspace query; 3002 (round 5, additive): smbv_attention_bwd_split + its workspace query. */
+ * the residual output O_lo, the *_cfg structs end with attn_o_resid.  3001 (round 5, additive): smbv_gemm_nt_splitk + its workspace query; 3002 (round 5, additive): smbv_attention_bwd_split + its workspace query;
+ * 3003 (round 5, additive): smbv_gemm_tn_grouped_split + its workspace query; 3004 (round 5, additive): smbv_rope3d_cfg, smbv_gemm_nt_rope, smbv_attention_bwd_rope. */
 #define SMBV_ABI_MAJOR 3
 int smbv_version(void);
 int smbv_last_error(char* buf, size_t len);               /* copies the thread's last error text; returns its length */
@@ -126,6 +127,13 @@ typedef struct smbv_tn_job {
   int reserved;                   /* set by the library */
 } smbv_tn_job;
 int smbv_gemm_tn_grouped(const smbv_tn_job* jobs /* host */, int njobs, smbv_stream stream);
+/* The same launch with every tile's token range run as two halves by two workgroups (ABI 3003): for a launch that has the chip to itself and fewer tiles than
+ * half its CUs - the steps run the LAST block's weight gradients this way, the optimizer waits for nothing else (profiles/r05_tn_split_ab.txt).  The
+ * first half's workgroup hands its fp32 tile and column sums through ws (write-through stores, one flag per tile), the second adds its own and writes
+ * the result: the same two addends in the same order on every run.  Every N1, N2 a multiple of 256, every M >= 256, at most 128 tiles in all
+ * (the workspace query returns 0 otherwise and the call SMBV_ERR_SHAPE); ws 256-byte aligned; one such launch in flight per device. */
+size_t smbv_gemm_tn_grouped_split_workspace_bytes(const smbv_tn_job* jobs /* host */, int njobs);
+int smbv_gemm_tn_grouped_split(const smbv_tn_job* jobs /* host */, int njobs, void* ws, size_t ws_bytes, smbv_stream stream);
 
 /* nn.LayerNorm over the last dim (spec :402-403, :412, :423, :676/:721); y is the bf16 GEMM operand.
  * Input rows are read at (row / grp_in) * grp_out + row % grp_in + row_off when grp_in > 0. */
@@ -163,6 +171,15 @@ size_t smbv_attention_bwd_split_workspace_bytes(int B, int S, int H, int Dh);
 int smbv_attention_bwd_split(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* O_lo, const smbv_bf16* dO,
                              int ldo, const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S, int H, int Dh,
                              float scale, int parts, int Sq, int q_off, void* ws, size_t ws_bytes, void* fp8_ws, size_t fp8_ws_bytes, smbv_stream stream);
+/* smbv_attention_bwd_split for an attention whose q and k went through the rotary map `rope` (smbv_rope3d_cfg below the V-JEPA kernels; ABI 3004): dQ and dK - the
+ * q | k sections of one [B * S, ldd] gradient matrix - leave through the TRANSPOSED map, applied to the bf16-rounded gradients in the kernel's stores: bitwise
+ * what smbv_attention_bwd_split followed by smbv_rope3d(dQ, ldd, dK - dQ, ..., transpose = 1) leaves (the fp8 blocks and the debug forms run exactly those two).
+ * rope->head_stride = Dh (the attention's head slot), rope->Dh = the real head_dim (<= the slot), parts = 6 or 7; ws / fp8_ws as smbv_attention_bwd_split. */
+struct smbv_rope3d_cfg;
+int smbv_attention_bwd_rope(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* O_lo, const smbv_bf16* dO,
+                            int ldo, const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S, int H, int Dh,
+                            float scale, int parts, int Sq, int q_off, void* ws, size_t ws_bytes, void* fp8_ws, size_t fp8_ws_bytes,
+                            const struct smbv_rope3d_cfg* rope, smbv_stream stream);
 /* smbv_attention_bwd with the query-owner blocks' two recomputed products (S, dP) on the block-scaled fp8 MFMA (head_dim 64, parts = 6 or 7): Q, K, V, dO are
  * quantised to e4m3 rows with E8M0 scales per (token, head, 32 channels) into ws (smbv_attention_bwd_fp8_workspace_bytes, 256-B aligned) by four small
  * launches in front of the pair launch. */
@@ -341,6 +358,19 @@ int smbv_adamw_step(const smbv_adam_chunk* chunks_dev, int nchunks, const smbv_a
  * the transposed map (gradient). */
 int smbv_rope3d(smbv_bf16* qkv, int ld, int k_off, long rows, int S, int H, int head_stride, int Dh, int grid, const int32_t* pos,
                 const float* table, int transpose, smbv_stream stream);
+/* The same map as a by-product of the launches either side of it (ABI 3004; what the V-JEPA steps run since round 5 - the stand-alone launches were 2.2 ms of
+ * kernel time per step, 36 passes over the q | k sections).  One description of the map for both: */
+typedef struct smbv_rope3d_cfg {
+  const float* table;              /* as smbv_rope3d */
+  const int32_t* pos;              /* int32 [rows] or NULL (= row % S) */
+  int S, grid, Dh, head_stride;
+} smbv_rope3d_cfg;
+/* smbv_gemm_nt whose bf16 output [M, N] holds q in columns [0, wa) and k in [wa, 2 wa) (head slots of head_stride columns; N >= 2 wa, e.g. the fused QKV
+ * product with N = 3 wa): the forward map is applied to those sections of the bf16-ROUNDED product in the epilogue - the stored matrix is bitwise what
+ * smbv_gemm_nt followed by smbv_rope3d(out, ld, wa, ...) leaves.  epi: bias and out_bf16 only (SMBV_ERR_ARG otherwise); wa and head_stride multiples of 8.
+ * Products the register-epilogue kernel does not take run as exactly those two launches. */
+int smbv_gemm_nt_rope(const smbv_bf16* A, int lda, const smbv_bf16* B, int ldb, int M, int N, int K, const smbv_gemm_epi* epi, const smbv_rope3d_cfg* rope,
+                      int wa, smbv_stream stream);
 /* apply_masks (:542-556): dst[r,:] = src[batch(r)*src_batch_rows + idx[r], :]; scatter is the inverse placement; fill writes `vec`. */
 int smbv_gather_rows_idx_f32(const float* src, float* dst, const int32_t* idx, long nidx, int per_batch, long src_batch_rows, int D, smbv_stream stream);
 int smbv_scatter_rows_idx_f32(const float* src, float* dst, const int32_t* idx, long nidx, int per_batch, long dst_batch_rows, int D, smbv_stream stream);

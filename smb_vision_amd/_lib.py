@@ -10,7 +10,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsmbv.so")
 MAX_LAYERS = 48
-ABI_MAJOR, ABI_MINOR_NEEDED = 3, 2  # include/smbv.h SMBV_ABI_MAJOR; the newest entry point these bindings call
+ABI_MAJOR, ABI_MINOR_NEEDED = 3, 4  # include/smbv.h SMBV_ABI_MAJOR; the newest entry point these bindings call
 
 c_f = C.c_void_p  # all device pointers travel as void*
 
@@ -30,6 +30,10 @@ class GemmEpi(C.Structure):
 class TnJob(C.Structure):
     _fields_ = [("X", c_f), ("Y", c_f), ("out", c_f), ("sum_dst", c_f * 3), ("ldx", C.c_int), ("ldy", C.c_int), ("M", C.c_int), ("N1", C.c_int),
                 ("N2", C.c_int), ("seg", C.c_int), ("reserved", C.c_int)]
+
+
+class Rope3dCfg(C.Structure):
+    _fields_ = [("table", c_f), ("pos", c_f), ("S", C.c_int), ("grid", C.c_int), ("Dh", C.c_int), ("head_stride", C.c_int)]
 
 
 class _Cfg(C.Structure):
@@ -118,7 +122,10 @@ _SIGS = {
     "smbv_gemm_tn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "smbv_gemm_nt_splitk": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GemmEpi), c_f, C.c_size_t, c_f]),
     "smbv_gemm_nt_splitk_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "smbv_gemm_nt_rope": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GemmEpi), C.POINTER(Rope3dCfg), C.c_int, c_f]),
     "smbv_gemm_tn_grouped": (C.c_int, [C.POINTER(TnJob), C.c_int, c_f]),
+    "smbv_gemm_tn_grouped_split_workspace_bytes": (C.c_size_t, [C.POINTER(TnJob), C.c_int]),
+    "smbv_gemm_tn_grouped_split": (C.c_int, [C.POINTER(TnJob), C.c_int, c_f, C.c_size_t, c_f]),
     "smbv_gemm_tn_bias": (C.c_int, [c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f, c_f, C.c_size_t, c_f]),
     "smbv_layernorm_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_float, C.c_long, C.c_long, C.c_long, c_f]),
     "smbv_layernorm_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, c_f, C.c_size_t, c_f]),
@@ -130,6 +137,8 @@ _SIGS = {
     "smbv_attention_bwd_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "smbv_attention_bwd_split": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                            C.c_int, C.c_int, c_f, C.c_size_t, c_f, C.c_size_t, c_f]),
+    "smbv_attention_bwd_rope": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                          C.c_int, C.c_int, c_f, C.c_size_t, c_f, C.c_size_t, C.POINTER(Rope3dCfg), c_f]),
     "smbv_attention_bwd_fp8_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "smbv_attention_bwd_fp8": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                          C.c_int, C.c_int, c_f, C.c_size_t, c_f]),

@@ -22,6 +22,7 @@
 
 namespace smbv {
 extern int g_variant;
+extern int g_ab;   // SMBV_DEBUG_AB (capi.hip): bit 8 = the rotary map of dQ / dK as a launch of its own
 
 
 // 128-byte-row LDS image usable for ds_read_b128 row reads (16 rows x same chunk) AND ds_read_b64_tr_b16 blocks
@@ -127,13 +128,13 @@ template <int QT, int DH>
 struct DkvLds { static constexpr int BUF = 2 * QT * 2 * DH + 2 * QT * 4, BYTES = 2 * BUF; };
 
 // one key-owner block: keys 128 tile_x .. + 127 of (batch b, head); smem: DkvLds<QT, DH>::BYTES, 16-byte aligned
-template <int QT, int DH>
+template <int QT, int DH, bool ROPE = false>   // ROPE: dK leaves through the transposed rotary map (V-JEPA; RopeStore, smbv_common.h)
 __device__ __forceinline__ void attn_dkv2_block(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                 const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO,
                                                 int ldo, const float* __restrict__ LSE, const float* __restrict__ delta,
                                                 bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int ldd, int S, int Sq, int qoff,
                                                 int H, float scale, const int tile_x, const int head, const int b, unsigned char* smem,
-                                                const SweepPart sp = SweepPart()) {
+                                                const SweepPart sp = SweepPart(), const RopeStore rs = RopeStore()) {
   static_assert(QT == 128, "the mid-iteration hand-over is written for 4 sub-tiles");
   static_assert(DH == 64 || DH == 32, "head widths with a native build");
   constexpr int NS = QT / 32;
@@ -365,12 +366,17 @@ __device__ __forceinline__ void attn_dkv2_block(const bf16_t* __restrict__ Q, co
   if (key < S) {
     bf16_t* kp = dK + (row0 + key) * ldd + hoff;
     bf16_t* vp = dV + (row0 + key) * ldd + hoff;
+    RopeTok tk = {};
+    if constexpr (ROPE) tk = rope_tok(rs.pos ? rs.pos[row0 + key] : key, rs.grid, rs.seg);
 #pragma unroll
     for (int dt = 0; dt < DT; dt++)
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
         const int d0 = 32 * dt + 8 * rg + 4 * h2;
-        u32x2 pk = {pack_bf16(dkt[dt][4 * rg] * scale, dkt[dt][4 * rg + 1] * scale), pack_bf16(dkt[dt][4 * rg + 2] * scale, dkt[dt][4 * rg + 3] * scale)};
+        f32x4 kk = {dkt[dt][4 * rg] * scale, dkt[dt][4 * rg + 1] * scale, dkt[dt][4 * rg + 2] * scale, dkt[dt][4 * rg + 3] * scale};
+        // (the gradient of the ROTATED key, rounded to bf16 as the stand-alone launch read it, through the transposed map)
+        if constexpr (ROPE) rope_round_apply4(kk, rope_lane(d0, rs.seg, true), tk, rs.seg, rs.table, true);
+        u32x2 pk = {pack_bf16(kk[0], kk[1]), pack_bf16(kk[2], kk[3])};
         *(u32x2*)(kp + d0) = pk;
         u32x2 pv = {pack_bf16(dvt[dt][4 * rg], dvt[dt][4 * rg + 1]), pack_bf16(dvt[dt][4 * rg + 2], dvt[dt][4 * rg + 3])};
         *(u32x2*)(vp + d0) = pv;
@@ -600,12 +606,13 @@ __device__ __forceinline__ void attn_dq2_block(const bf16_t* __restrict__ Q, con
 // step, where the attention launches follow low-power kernels and cycles count for more than in a back-to-back loop: -0.1 ms MIM, -0.9 ms V-JEPA
 // for this block; the key-owner block re-tiled the same way was 4 % faster back to back on random operands and 0.15-0.3 ms SLOWER in the step, and
 // stays on 32x32x16 (profiles/r03_mfma_shape.txt).
-template <int KT, int DH>
+template <int KT, int DH, bool ROPE = false>   // ROPE: dQ leaves through the transposed rotary map
 __device__ __forceinline__ void attn_dq3_block(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                const bf16_t* __restrict__ V, int ld, const bf16_t* __restrict__ dO, int ldo,
                                                const float* __restrict__ LSE, const float* __restrict__ delta,
                                                bf16_t* __restrict__ dQ, int ldd, int S, int Sq, int qoff, int H, float scale,
-                                               const int tile_x, const int head, const int b, unsigned char* smem, const SweepPart sp = SweepPart()) {
+                                               const int tile_x, const int head, const int b, unsigned char* smem, const SweepPart sp = SweepPart(),
+                                               const RopeStore rs = RopeStore()) {
   static_assert(KT == 128, "bodies are unrolled for 4 sub-tiles per tile");
   static_assert(DH == 64 || DH == 32, "head widths with a native build");
   constexpr int KK = DH / 32, DTN = DH / 16, RB = 2 * DH;
@@ -814,10 +821,14 @@ __device__ __forceinline__ void attn_dq3_block(const bf16_t* __restrict__ Q, con
     const int q = tile_x * 128 + w * 32 + 16 * qi + n;
     if (q < Sq) {
       bf16_t* qp = dQ + (row0 + qoff + q) * ldd + hoff;
+      RopeTok tk = {};
+      if constexpr (ROPE) tk = rope_tok(rs.pos ? rs.pos[row0 + qoff + q] : qoff + q, rs.grid, rs.seg);
 #pragma unroll
       for (int dt = 0; dt < DTN; dt++) {
         const int d0 = 16 * dt + 4 * g;
-        u32x2 pk = {pack_bf16(dqt[dt][qi][0] * scale, dqt[dt][qi][1] * scale), pack_bf16(dqt[dt][qi][2] * scale, dqt[dt][qi][3] * scale)};
+        f32x4 qq = dqt[dt][qi] * scale;
+        if constexpr (ROPE) rope_round_apply4(qq, rope_lane(d0, rs.seg, true), tk, rs.seg, rs.table, true);
+        u32x2 pk = {pack_bf16(qq[0], qq[1]), pack_bf16(qq[2], qq[3])};
         *(u32x2*)(qp + d0) = pk;
       }
     }
@@ -1043,12 +1054,14 @@ __device__ __forceinline__ void pair_fault(unsigned* status, unsigned code) {
   if (status) __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <int DH, int QKIND>   // query-owner block: 0 = 32x32x16 bf16, 1 = 16x16x32 bf16 (shipped), 2 = S / dP recomputation on the fp8 MFMA (head_dim 64)
+// ROPE (QKIND 1 only): dQ and dK are the gradients of the rotated q / k and leave through the transposed rotary map
+template <int DH, int QKIND, bool ROPE = false>   // query-owner block: 0 = 32x32x16 bf16, 1 = 16x16x32 bf16 (shipped), 2 = S / dP recomputation on the fp8 MFMA (head_dim 64)
 __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, int ld,
                                                                const bf16_t* __restrict__ dO, int ldo, const float* __restrict__ LSE,
                                                                const float* __restrict__ delta, bf16_t* __restrict__ dQ, bf16_t* __restrict__ dK,
                                                                bf16_t* __restrict__ dV, int ldd, int B, int S, int Sq, int qoff, int H, float scale, int slot,
-                                                               unsigned epoch, unsigned* __restrict__ status, Fp8BwdOps f8, int xk, int xq, f32x4* __restrict__ split_ws) {
+                                                               unsigned epoch, unsigned* __restrict__ status, Fp8BwdOps f8, int xk, int xq, f32x4* __restrict__ split_ws,
+                                                               RopeStore rs) {
   constexpr int LDS = DkvLds<128, DH>::BYTES > DqLds<128, DH>::BYTES ? DkvLds<128, DH>::BYTES : DqLds<128, DH>::BYTES;
   static_assert(DqF8Lds::BYTES <= DkvLds<128, 64>::BYTES, "the fp8 query-owner block's ring fits the key-owner block's LDS");
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS];
@@ -1105,11 +1118,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __r
   }
   if (role == 0) {
     const int nt = (S + 127) / 128;
-    attn_dkv2_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem, sp);
+    attn_dkv2_block<128, DH, ROPE>(Q, K, V, ld, dO, ldo, LSE, delta, dK, dV, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem, sp, rs);
   } else if (role == 1) {
     const int nt = (Sq + 127) / 128;
     if constexpr (QKIND == 2 && DH == 64) attn_dq_fp8_block(f8, K, ld, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem, sp);
-    else if constexpr (QKIND == 1) attn_dq3_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem, sp);
+    else if constexpr (QKIND == 1) attn_dq3_block<128, DH, ROPE>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem, sp, rs);
     else attn_dq2_block<128, DH>(Q, K, V, ld, dO, ldo, LSE, delta, dQ, ldd, S, Sq, qoff, H, scale, tile % nt, (tile / nt) % H, tile / (nt * H), smem);
   }
   // the block that ends last (every other block has claimed its tile long ago) hands the slot over stamped with the NEXT epoch: no memset node in front of
@@ -1228,9 +1241,32 @@ size_t attention_bwd_split_workspace_max(int B, int S, int H, int Dh) {
   return attention_bwd_split_workspace_bytes(Dh, xk, xq);
 }
 
+static int attention_bwd_impl(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
+                              float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st,
+                              const bf16_t* O_lo, void* f8ws, size_t f8ws_bytes, void* split_ws, size_t split_ws_bytes, const RopeStore* rope, bool* rope_done);
+
+// rope: dQ / dK are gradients of the ROTATED q / k (V-JEPA, modeling_vjepa.py:311-326) and are to leave through the transposed rotary map - in the stores of the
+// one mixed-role launch (bf16 blocks on the 16x16x32 MFMA: what the steps run), bitwise what a rope3d launch over the stored matrix computes; on every other
+// path (fp8 blocks, two launches, debug forms) that launch runs behind the kernels: dQ, dK must then be the q | k sections of one [B * S, ldd] matrix
 int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
                   float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st,
-                  const bf16_t* O_lo, void* f8ws, size_t f8ws_bytes, void* split_ws, size_t split_ws_bytes) {
+                  const bf16_t* O_lo, void* f8ws, size_t f8ws_bytes, void* split_ws, size_t split_ws_bytes, const RopeBwd* rope) {
+  RopeStore rs;
+  if (rope) {
+    rs.table = rope->table; rs.pos = rope->pos; rs.grid = rope->grid; rs.seg = 2 * ((rope->Dh / 3) / 2);
+    if (!rope->table || rope->grid <= 0 || rope->Dh <= 0 || rope->Dh > Dh || (parts & 6) != 6) { set_error("attention_bwd: rotary map needs a table, a grid, head_dim <= the slot and both gradient products"); return SMBV_ERR_ARG; }
+    if (rs.seg <= 0) rope = nullptr;   // head_dim < 6: nothing is rotated
+  }
+  bool done = false;
+  const int rc = attention_bwd_impl(Q, K, V, ld, O, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, H, Dh, scale, parts, Sq, qoff, st, O_lo, f8ws, f8ws_bytes, split_ws,
+                                    split_ws_bytes, rope ? &rs : nullptr, &done);
+  if (rc != SMBV_OK || !rope || done) return rc;
+  return rope3d(dQ, ldd, (int)(dK - dQ), (long)B * S, S, H, Dh, rope->Dh, rope->grid, rope->pos, rope->table, 1, st);
+}
+
+static int attention_bwd_impl(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
+                              float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st,
+                              const bf16_t* O_lo, void* f8ws, size_t f8ws_bytes, void* split_ws, size_t split_ws_bytes, const RopeStore* rope, bool* rope_done) {
   if (Sq <= 0) { Sq = S; qoff = 0; }
   if (qoff < 0 || qoff + Sq > S) { set_error("attention_bwd: query range outside the sequence"); return SMBV_ERR_SHAPE; }
   if (Dh != 64 && Dh != 32) { set_error("attention_bwd: head_dim %d not supported (64 or 32; other widths run zero-padded in 64-wide slots, block.h)", Dh); return SMBV_ERR_SHAPE; }
@@ -1269,8 +1305,12 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
     const bool fp8q = f8ws != nullptr && Dh == 64 && !(g_variant & 8);   // (debug bit 8: bf16 query-owner blocks although fp8 operands were offered)
     if (fp8q) RC(attention_bwd_fp8_prepare(Q, K, V, ld, dO, ldo, B, S, H, scale, f8ws, f8ws_bytes, st, &f8));
     const unsigned epoch = pair_epoch_take(dev, slot);
-#define SMBV_PAIR_LAUNCH(DHV, KIND) hipLaunchKernelGGL((attn_bwd_pair_kernel<DHV, KIND>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot, epoch, status, f8, xk, xq, (f32x4*)split_ws)
-    if (fp8q) SMBV_PAIR_LAUNCH(64, 2);
+    const bool roped = rope && !fp8q && q16 && !(g_ab & 8);   // (A/B word bit 8: the rotary map as launches of its own)
+    const RopeStore rs = roped ? *rope : RopeStore();
+#define SMBV_PAIR_LAUNCH(DHV, KIND, ...) hipLaunchKernelGGL((attn_bwd_pair_kernel<DHV, KIND, ##__VA_ARGS__>), dim3(blocks), dim3(256), 0, st, Q, K, V, ld, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, Sq, qoff, H, scale, slot, epoch, status, f8, xk, xq, (f32x4*)split_ws, rs)
+    if (roped && Dh == 64) SMBV_PAIR_LAUNCH(64, 1, true);
+    else if (roped) SMBV_PAIR_LAUNCH(32, 1, true);
+    else if (fp8q) SMBV_PAIR_LAUNCH(64, 2);
     else if (Dh == 64 && q16) SMBV_PAIR_LAUNCH(64, 1);
     else if (Dh == 64) SMBV_PAIR_LAUNCH(64, 0);
     else if (q16) SMBV_PAIR_LAUNCH(32, 1);
@@ -1278,6 +1318,7 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
 #undef SMBV_PAIR_LAUNCH
     rc = check_launch("attn_bwd_pair");
     if (rc) pair_epoch_untake(dev, slot, epoch);   // nothing was enqueued: the device slot still carries this epoch
+    else if (roped) *rope_done = true;
     return rc;
   }
   // dK/dV and dQ are independent (disjoint outputs, shared read-only inputs).  Their grids rarely fill a whole number of

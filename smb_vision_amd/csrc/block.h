@@ -149,6 +149,7 @@ void carve_bwd_scratch(Carver& cv, BwdScratch& sc, const BwdNeeds& n);  // every
 struct WgradPipe {
   ForkJoin* fj = nullptr;        // null until begin(); stays null when the side stream is unavailable or switched off (variant bit 16384): all inline
   bool allow_defer = true;       // false: every block inline
+  bool last_block = false;       // the step sets it around the LAST block of its backward: its grouped launch has nothing to run beside and is split (gemm.hip)
   int k = 0;                     // blocks issued through this pipe
   int waited = -1;               // the caller's stream has waited for deferred launches <= waited
   bool deferred[4] = {false, false, false, false};  // launch (k & 3) was deferred and its wdone event recorded

@@ -81,6 +81,10 @@ void bwd_scratch_requirements(const BlockDims& d, BwdNeeds& n) {
   n.delta = std::max(n.delta, (size_t)d.B * d.H * d.S);
   auto tn = [&](size_t M, size_t n1, size_t n2) { n.wscratch = std::max(n.wscratch, gemm_tn_workspace_bytes((int)M, (int)n1, (int)n2)); };
   tn(rows, w, ff); tn(rows, ff, w); tn(rows, w, wa); tn(rows, 3 * wa, w); tn(rows, w, w);
+  if (!(w % 256) && !(ff % 256) && !(wa % 256)) {   // the last block's grouped launch as two token halves per tile (gemm_tn_grouped): the first half's tiles pass through here
+    const size_t tiles = (2 * w * ff + 3 * wa * w + wa * w) / (256 * 256);
+    if (tiles <= 128) n.wscratch = std::max(n.wscratch, gemm_tn_grouped_split_bytes((int)tiles));
+  }
   n.scratch = std::max(n.scratch, layernorm_bwd_workspace_bytes((int)rows, (int)w));
   n.attn_split = std::max(n.attn_split, attention_bwd_split_workspace_max(d.B, d.S, d.H, d.slot()));
   if (d.attn_fp8) n.f8 = std::max(n.f8, attention_fp8_workspace_bytes(d.B, d.S, d.H));
@@ -110,9 +114,10 @@ int layer_fwd(const BlockPtrs& p, LayerWs& L, const BlockDims& d, BwdScratch& sc
   RC(layernorm_fwd(x_in, p.ln1_w, p.ln1_b, L.ln1, L.mean1, L.rstd1, M, w, d.eps, 0, 0, 0, st));
   {
     GemmEpi e; e.bias = L.bqkv; e.out_bf16 = L.qkv; e.ld_ob = 3 * wa;
+    // V-JEPA: the rotary embedding of q and k rides in the product's epilogue (gemm_nt: the ring kernel's EPI 3, else a rope3d launch behind the product)
+    if (d.rope_grid > 0) { e.rope_table = d.rope_table; e.rope_pos = d.pos; e.rope_S = S; e.rope_grid = d.rope_grid; e.rope_Dh = d.Dh; e.rope_hs = d.slot(); e.rope_wa = wa; }
     RC(gemm_nt(L.ln1, w, L.wqkv, w, M, 3 * wa, w, e, st));
   }
-  if (d.rope_grid > 0) RC(rope3d(L.qkv, 3 * wa, wa, M, S, H, d.slot(), d.Dh, d.rope_grid, d.pos, d.rope_table, 0, st));
   if (d.attn_fp8 && d.slot() != 64) { set_error("layer_fwd: the fp8 attention forward is built for 64-wide head slots (head_dim %d)", d.Dh); return SMBV_ERR_SHAPE; }
   if (d.attn_fp8) RC(attention_fwd_fp8(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, wa, L.lse, B, S, H, 64, d.scale(), Sq, qoff, sc.f8ws, sc.f8ws_bytes, st));
   else RC(attention_fwd(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, wa, L.lse, B, S, H, d.slot(), d.scale(), Sq, qoff, st, L.attn_o_lo));
@@ -294,10 +299,12 @@ int layer_bwd_core(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const Bl
     RC(gemm_nt(g2c, w, L.proj_t, w, Mq, wa, w, e, st));
   }
   // ---- attention (dQ exists only for the ranged queries; dK/dV for every token) ----
+  RopeBwd rope;
+  rope.table = d.rope_table; rope.pos = d.pos; rope.grid = d.rope_grid; rope.Dh = d.Dh;
   if (ranged) HIPRC(hipMemsetAsync(bf.d_qkv, 0, (size_t)M * 3 * wa * sizeof(bf16_t), st));
   RC(attention_bwd(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, sc.d_o, wa, L.lse, sc.delta, bf.d_qkv, bf.d_qkv + wa, bf.d_qkv + 2 * wa, 3 * wa, B,
-                   S, H, d.slot(), d.scale(), delta_fused ? 6 : 7, Sq, qoff, st, L.attn_o_lo, (d.attn_fp8 & 2) && d.slot() == 64 ? sc.f8ws : nullptr, sc.f8ws_bytes, sc.attn_split, sc.attn_split_bytes));
-  if (d.rope_grid > 0) RC(rope3d(bf.d_qkv, 3 * wa, wa, M, S, H, d.slot(), d.Dh, d.rope_grid, d.pos, d.rope_table, 1, st));
+                   S, H, d.slot(), d.scale(), delta_fused ? 6 : 7, Sq, qoff, st, L.attn_o_lo, (d.attn_fp8 & 2) && d.slot() == 64 ? sc.f8ws : nullptr, sc.f8ws_bytes, sc.attn_split, sc.attn_split_bytes,
+                   d.rope_grid > 0 ? &rope : nullptr));   // V-JEPA: dQ / dK leave through the transposed rotary map in the kernel's stores
   // ---- QKV ----
   if (!defer) {
     // (round 3 joined the three products forked above here.  Since round 4 every buffer they read - gb_in, gb_mid, d_act, d_qkv, the saved activations -
@@ -346,7 +353,9 @@ int layer_bwd_core(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const Bl
     RC(stream_edge(fj, fj->wfork, st, fj->wside));
     RC(layernorm_bwd_reduce(bf.ln2_part, Mq, w, gr.ln2_w, gr.ln2_b, fj->wside));
     RC(layernorm_bwd_reduce(bf.ln1_part, M, w, gr.ln1_w, gr.ln1_b, fj->wside));
-    RC(gemm_tn_grouped(jobs, nj, fj->wside));
+    // (the LAST block's launch - nothing runs beside it, the optimizer waits for it - runs every tile's token range as two halves on twice the CUs: the side
+    // stream's slab scratch is free, nothing else of this backward uses it any more)
+    RC(gemm_tn_grouped(jobs, nj, fj->wside, defer->last_block ? sc.wscratch : nullptr, sc.wscratch_bytes));
     RC(event_record_locked(fj, fj->wdone[launch_no & 3], fj->wside));
     if (dp_event) HIPRC(hipEventRecord(dp_event, fj->wside));
     return SMBV_OK;

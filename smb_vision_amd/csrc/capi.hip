@@ -43,7 +43,8 @@ static GemmEpi to_epi(const smbv_gemm_epi* s) {
 
 int g_variant = 0;  // smbv_debug_set_variant (include/smbv.h): kernel selection for A/B tools and equivalence tests; 0 on the product path
 // second A/B word (the first one's 31 bits are taken): environment SMBV_DEBUG_AB, read once at load; 0 / unset on the product path.  Bits: 1 the inline
-// block backward keeps round 3's join in front of its QKV products; 2 adamw_kernel walks its chunk table front to back (tools/step_ab2.sh)
+// block backward keeps round 3's join in front of its QKV products; 2 adamw_kernel walks its chunk table front to back; 4 the last grouped weight-gradient
+// launch of a backward runs whole; 8 V-JEPA's rotary embedding as launches of its own (tools/step_ab2.sh)
 int g_ab = [] { const char* e = getenv("SMBV_DEBUG_AB"); return e ? atoi(e) : 0; }();
 
 }  // namespace smbv
@@ -52,7 +53,7 @@ using namespace smbv;
 
 extern "C" {
 
-int smbv_version(void) { return 3002; }  // 3000: O_lo in smbv_attention_fwd / _bwd, attn_o_resid in the *_cfg structs; see include/smbv.h
+int smbv_version(void) { return 3004; }  // 3000: O_lo in smbv_attention_fwd / _bwd, attn_o_resid in the *_cfg structs; see include/smbv.h
 void smbv_debug_set_variant(int bits) { smbv::g_variant = bits; }
 int smbv_device_status(int clear) { return smbv::device_status(clear != 0); }
 int smbv_debug_pair_state(int op, smbv_stream stream) { return smbv::pair_state_debug(op, (hipStream_t)stream); }
@@ -87,6 +88,13 @@ int smbv_gemm_nt_splitk(const smbv_bf16* A, int lda, const smbv_bf16* B, int ldb
   return gemm_nt(A, lda, B, ldb, M, N, K, e, (hipStream_t)stream);
 }
 size_t smbv_gemm_nt_splitk_workspace_bytes(int M, int N) { return gemm_nt_splitk_workspace_bytes(M, N); }
+int smbv_gemm_nt_rope(const smbv_bf16* A, int lda, const smbv_bf16* B, int ldb, int M, int N, int K, const smbv_gemm_epi* epi, const smbv_rope3d_cfg* rope, int wa,
+                      smbv_stream stream) {
+  if (!A || !B || !epi || !epi->out_bf16 || !rope || !rope->table) { set_error("smbv_gemm_nt_rope: null operand / no bf16 output / no table"); return SMBV_ERR_ARG; }
+  GemmEpi e = to_epi(epi);
+  e.rope_table = rope->table; e.rope_pos = rope->pos; e.rope_S = rope->S; e.rope_grid = rope->grid; e.rope_Dh = rope->Dh; e.rope_hs = rope->head_stride; e.rope_wa = wa;
+  return gemm_nt(A, lda, B, ldb, M, N, K, e, (hipStream_t)stream);
+}
 int smbv_gemm_tn(const smbv_bf16* X, int ldx, const smbv_bf16* Y, int ldy, int M, int N1, int N2, float* out, void* ws, size_t ws_bytes, smbv_stream stream) {
   if (!X || !Y || !out) { set_error("smbv_gemm_tn: null operand"); return SMBV_ERR_ARG; }
   return gemm_tn(X, ldx, Y, ldy, M, N1, N2, out, ws, ws_bytes, (hipStream_t)stream);
@@ -107,6 +115,28 @@ int smbv_gemm_tn_grouped(const smbv_tn_job* jobs, int njobs, smbv_stream stream)
   TnJob j[TN_GROUP_MAX];
   memcpy(j, jobs, sizeof(TnJob) * njobs);
   return gemm_tn_grouped(j, njobs, (hipStream_t)stream);
+}
+static int tn_group_tiles_256(const smbv_tn_job* jobs, int njobs) {  // 0: not a launch the split form takes
+  int tiles = 0;
+  for (int i = 0; i < njobs; i++) {
+    if ((jobs[i].N1 & 255) || (jobs[i].N2 & 255) || jobs[i].M < 256) return 0;
+    tiles += (jobs[i].N1 / 256) * (jobs[i].N2 / 256);
+  }
+  return tiles <= 128 ? tiles : 0;
+}
+size_t smbv_gemm_tn_grouped_split_workspace_bytes(const smbv_tn_job* jobs, int njobs) {
+  if (!jobs || njobs <= 0 || njobs > TN_GROUP_MAX) return 0;
+  const int tiles = tn_group_tiles_256(jobs, njobs);
+  return tiles ? gemm_tn_grouped_split_bytes(tiles) : 0;
+}
+int smbv_gemm_tn_grouped_split(const smbv_tn_job* jobs, int njobs, void* ws, size_t ws_bytes, smbv_stream stream) {
+  if (!jobs || njobs <= 0 || njobs > TN_GROUP_MAX) { set_error("smbv_gemm_tn_grouped_split: 1..%d jobs", TN_GROUP_MAX); return SMBV_ERR_ARG; }
+  const size_t need = smbv_gemm_tn_grouped_split_workspace_bytes(jobs, njobs);
+  if (!need) { set_error("smbv_gemm_tn_grouped_split: every N1, N2 a multiple of 256, every M >= 256, at most 128 tiles"); return SMBV_ERR_SHAPE; }
+  if (!ws || ws_bytes < need || ((uintptr_t)ws & 255)) { set_error("smbv_gemm_tn_grouped_split: workspace too small or not 256-byte aligned (%zu < %zu)", ws_bytes, need); return SMBV_ERR_WORKSPACE; }
+  TnJob j[TN_GROUP_MAX];
+  memcpy(j, jobs, sizeof(TnJob) * njobs);
+  return gemm_tn_grouped(j, njobs, (hipStream_t)stream, ws, ws_bytes);
 }
 
 int smbv_layernorm_fwd(const float* x, const float* gamma, const float* beta, smbv_bf16* y, float* mean, float* rstd, int rows, int D, float eps,
@@ -153,6 +183,25 @@ int smbv_attention_bwd_split(const smbv_bf16* Q, const smbv_bf16* K, const smbv_
   }
   SMBV_CHECK_DEVICE_STATE();
   return attention_bwd(Q, K, V, ld, O, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, H, Dh, scale, parts, Sq, q_off, (hipStream_t)stream, O_lo, fp8_ws, fp8_ws_bytes, ws, ws_bytes);
+}
+
+int smbv_attention_bwd_rope(const smbv_bf16* Q, const smbv_bf16* K, const smbv_bf16* V, int ld, const smbv_bf16* O, const smbv_bf16* O_lo, const smbv_bf16* dO, int ldo,
+                            const float* LSE, float* delta, smbv_bf16* dQ, smbv_bf16* dK, smbv_bf16* dV, int ldd, int B, int S, int H, int Dh, float scale,
+                            int parts, int Sq, int q_off, void* ws, size_t ws_bytes, void* fp8_ws, size_t fp8_ws_bytes, const smbv_rope3d_cfg* rope, smbv_stream stream) {
+  if (!Q || !K || !V || !O || !dO || !LSE || !delta || !dQ || !dK || !dV || !rope || !rope->table) { set_error("smbv_attention_bwd_rope: null operand"); return SMBV_ERR_ARG; }
+  if ((parts & 6) != 6 || rope->head_stride != Dh || rope->Dh > Dh || (!rope->pos && rope->S != S) || dK <= dQ || dK - dQ >= ldd) {
+    set_error("smbv_attention_bwd_rope: both gradient parts; head_stride = the attention's head slot; pos == NULL means positions 0..S-1; dQ | dK sections of one matrix");
+    return SMBV_ERR_ARG;
+  }
+  if (fp8_ws && Dh != 64) { set_error("smbv_attention_bwd_rope: the fp8 query-owner blocks need head_dim 64"); return SMBV_ERR_SHAPE; }
+  if (ws && (((uintptr_t)ws & 255) || ws_bytes < smbv_attention_bwd_split_workspace_bytes(B, S, H, Dh))) {
+    set_error("smbv_attention_bwd_rope: workspace short or misaligned (%zu < %zu)", ws_bytes, smbv_attention_bwd_split_workspace_bytes(B, S, H, Dh));
+    return SMBV_ERR_WORKSPACE;
+  }
+  SMBV_CHECK_DEVICE_STATE();
+  RopeBwd rb;
+  rb.table = rope->table; rb.pos = rope->pos; rb.grid = rope->grid; rb.Dh = rope->Dh;
+  return attention_bwd(Q, K, V, ld, O, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, H, Dh, scale, parts, Sq, q_off, (hipStream_t)stream, O_lo, fp8_ws, fp8_ws_bytes, ws, ws_bytes, &rb);
 }
 
 size_t smbv_attention_bwd_fp8_workspace_bytes(int B, int S, int H) { return attention_bwd_fp8_workspace_bytes(B, S, H); }

@@ -15,11 +15,14 @@
 // 741/801-803, 720-722 (the nn.Linear calls) and their autograd.
 #include "smbv_common.h"
 #include "smbv_kernels.h"
+#include <mutex>
 
 namespace smbv {
 
 static constexpr int BM = 128, BN = 128, BK = 64;
 extern int g_variant;  // tuning / A-B hook, see attention_fwd.hip
+extern int g_ab;       // SMBV_DEBUG_AB (capi.hip): bit 4 = no token split of the last grouped launch, bit 8 = rotary embedding as launches of its own
+unsigned* device_status_word_dev();   // streams.hip
 
 __device__ __forceinline__ int swz_nt(int row, int chunk) { return row * 128 + (((chunk) ^ ((row >> 1) & 7)) << 4); }
 
@@ -366,12 +369,28 @@ int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, in
       (e.dgelu_pre && ((e.ld_pre & 3) || ((uintptr_t)e.dgelu_pre & 7))) || (e.aux_pre && ((e.ld_aux & 3) || ((uintptr_t)e.aux_pre & 7)))) {
     set_error("gemm_nt: epilogue operand alignment/stride"); return SMBV_ERR_ALIGN;
   }
+  const bool ring_shape = (K <= 768 && N >= 1024) || (K <= 1024 && N >= 2048);
+  if (e.rope_table) {   // rotary embedding of the q | k sections on the way out: the ring kernel's epilogue, or the product followed by the stand-alone launch
+    const int seg = 2 * ((e.rope_Dh / 3) / 2);
+    if (!e.out_bf16 || e.out_f32 || e.act_gelu || e.dgelu_pre || e.rowadd || e.grp_in > 0 || e.dot_out || e.alpha != 1.0f || e.rope_wa <= 0 || e.rope_hs <= 0 ||
+        (e.rope_wa & 7) || (e.rope_hs & 7) || e.rope_wa % e.rope_hs || 2 * e.rope_wa > N || e.rope_grid <= 0 || (!e.rope_pos && e.rope_S <= 0) || 3 * seg > e.rope_hs) {
+      set_error("gemm_nt: rotary epilogue needs a plain bf16 product with q | k sections of whole head slots (wa=%d hs=%d Dh=%d N=%d)", e.rope_wa, e.rope_hs, e.rope_Dh, N);
+      return SMBV_ERR_ARG;
+    }
+    const bool fused = seg > 0 && ring_shape && gemm_nt_ring_ok(lda, ldb, M, N, K, e) && !(g_variant & (256 | 262144)) && !(g_ab & 8);
+    if (!fused) {
+      GemmEpi plain = e;
+      plain.rope_table = nullptr;
+      const int rc = gemm_nt(A, lda, B, ldb, M, N, K, plain, st);
+      if (rc != SMBV_OK || seg <= 0) return rc;
+      return rope3d(e.out_bf16, e.ld_ob, e.rope_wa, M, e.rope_S, e.rope_wa / e.rope_hs, e.rope_hs, e.rope_Dh, e.rope_grid, e.rope_pos, e.rope_table, 0, st);
+    }
+  }
   // long-K products whose 256 x 128 tiles leave CUs idle: two K halves per tile (gemm_nt_ring.hip, round 5) when the caller handed over split-K scratch
   if (gemm_nt_splitk_wanted(lda, ldb, M, N, K, e) && !(g_variant & (256 | 131072))) return gemm_nt_ring_splitk(A, lda, B, ldb, M, N, K, e, st);
   // Kernel choice, measured per shape on MI355X (tools/gemm_ab.py, profiles/r02_gemm_ab.txt): the ring kernel (256 x 128 tiles, two K slices in
   // flight per block, register epilogue) is 7-19 % ahead where the epilogue is heavy and K short - the GELU / dGELU products, the decoder's
   // K = 384 projections, the head - and 5-13 % behind the 128 x 128 kernel on long-K or narrow outputs, whose smaller tiles fill the chip better.
-  const bool ring_shape = (K <= 768 && N >= 1024) || (K <= 1024 && N >= 2048);
   if (gemm_nt_ring_ok(lda, ldb, M, N, K, e) && !(g_variant & 256) && (ring_shape || (g_variant & 131072)))
     return gemm_nt_ring(A, lda, B, ldb, M, N, K, e, (g_variant & 262144) ? 64 : ((g_variant & 512) ? 4 : 3), st, (g_variant >> 20) & 15);
   if (e.dot_out && (!e.dot_with || (e.dot_dh != 64 && e.dot_dh != 32) || e.dot_rows <= 0 || (((uintptr_t)e.dot_with | (uintptr_t)e.dot_with_lo) & 15) || !gemm_nt_rowdot_ok(lda, ldb, M, N, K, e))) {
@@ -658,9 +677,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
 // through a ring of four LDS slots filled by LDS-DMA hidden from hipcc (smbv_common.h), one counted vmcnt + one barrier per slice, fragments
 // by ds_read_b64_tr_b16 (same 32-byte-column XOR swizzle as the 128 kernel; 512-B rows keep its bank pattern).  The token range is split
 // into slabs so that tiles x slabs fills one round of 256 blocks; slabs are summed by reduce_tn_kernel in slab order.
+template <bool SPLIT = false>   // SPLIT: the tile may be one half of a token range (sp.part >= 0) - a separate build, so that the whole-range kernels keep their registers
 __device__ __forceinline__ void tn256_tile(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Y, int ldy, int N1, int N2, float* __restrict__ o,
                                            int ldo, int a0, int b0, int mbeg, int mend, bool do_sum, float* __restrict__ xsum_flat, const TnSum& ts,
-                                           unsigned char* smem) {
+                                           unsigned char* smem, const SweepPart sp = SweepPart()) {
   constexpr int SLICE = 2 * 32 * 512;  // X image | Y image
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -774,6 +794,39 @@ __device__ __forceinline__ void tn256_tile(const bf16_t* __restrict__ X, int ldx
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 
+  if constexpr (SPLIT) if (sp.part >= 0) {   // half of the token range (gemm_tn_grouped, split launch): the fp32 tile + the column sums travel to / come from the other half (smbv_common.h)
+    // the 128 accumulator registers go out / come in where they are (a copy of them would not fit the register file), the column sums as a second group
+    // (row by row: the array is never addressed as a whole, which would put it into scratch memory)
+    f32x4 sums[4] = {accb[0], accb[1], (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    f32x4* bias_base = sp.scratch + 32 * 512;
+    f32x4* tp = sp.scratch + (size_t)w * (32 * 64) + l;   // piece 4 i + j of wave w at [(32 w + 4 i + j) * 64 + lane]
+    __syncthreads();   // (both wave groups have left the ring: its first word carries the consumer's verdict)
+    if (sp.part == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        sweep_store16_sc1<0>(tp + i * 256, acc[i][0]);
+        sweep_store16_sc1<1024>(tp + i * 256, acc[i][1]);
+        sweep_store16_sc1<2048>(tp + i * 256, acc[i][2]);
+        sweep_store16_sc1<3072>(tp + i * 256, acc[i][3]);
+      }
+      sweep_store<4>(bias_base, sums, w, l);
+      sweep_signal(sp, t);
+      return;
+    }
+    if (!sweep_wait(sp, t, (int*)smem)) return;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      f32x4 a[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) a[j] = tp[i * 256 + j * 64];
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] += a[j];
+      asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3])::"memory");
+    }
+    sweep_load<4>(bias_base, sums, w, l);
+    sweep_release(sp, t);
+    accb[0] = sums[0]; accb[1] = sums[1];
+  }
   if (do_sum && l < 16) {
 #pragma unroll
     for (int k = 0; k < 2; k++) tn_store_sum(ts, xsum_flat, a0 + w1 * 128 + (2 * w2 + k) * 16 + l, accb[k][0]);
@@ -804,20 +857,33 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_256_kernel(const bf16_t* __res
 // ---- grouped launch: several weight-gradient products (one transformer block's four) as ONE grid, every tile reduced over its product's WHOLE token
 // range: no slabs, no finishing launch, the bias gradients (column sums of X) written straight to their tensors.  block.hip defers a block's products
 // to the end of its backward and runs this launch on the side stream beside the NEXT block's backward.
-template <int TILE>
+template <int TILE, bool SPLIT = false>
 __global__ __launch_bounds__(TILE == 256 ? 512 : 256, TILE == 256 ? 1 : 2) void gemm_tn_grouped_kernel(TnGroup g) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[TILE == 256 ? 4 * 2 * 32 * 512 : 2 * 2 * BK * 128 * 2];
+  // split launch (g.tiles > 0: twice as many blocks as tiles): block b < tiles reduces the FIRST half of tile b's token range and hands its fp32 tile to block
+  // tiles + b, which reduces the second half, adds and stores (the LAST grouped launch of a backward: nothing runs beside it, the optimizer waits for it)
+  int unit = (int)blockIdx.x;
+  SweepPart sp;
+  if (SPLIT && g.tiles > 0) {
+    sp.part = unit >= g.tiles ? 1 : 0;
+    unit -= sp.part * g.tiles;
+    sp.scratch = g.scratch + (size_t)unit * (36 * 512);
+    sp.flag = g.flags + unit;
+    sp.status = g.status;
+  }
   int j = 0;
 #pragma unroll
   for (int i = 1; i < TN_GROUP_MAX; i++)
-    if (i < g.njobs && (int)blockIdx.x >= g.job[i].tile0) j = i;
+    if (i < g.njobs && unit >= g.job[i].tile0) j = i;
   const TnJob& J = g.job[j];
-  const int tile = (int)blockIdx.x - J.tile0;
+  const int tile = unit - J.tile0;
   const int tiles_1 = J.N1 / TILE;
   const int tile_1 = tile % tiles_1, tile_2 = tile / tiles_1;
   const TnSum ts = {J.sum_dst[0], J.sum_dst[1], J.sum_dst[2], J.seg};
   const bool do_sum = J.seg > 0 && tile_2 == 0;
-  if constexpr (TILE == 256) tn256_tile(J.X, J.ldx, J.Y, J.ldy, J.N1, J.N2, J.out, J.N2, tile_1 * 256, tile_2 * 256, 0, J.M, do_sum, nullptr, ts, smem);
+  const int mh = (J.M / 2) & ~31;   // (slices are 32 tokens)
+  if constexpr (TILE == 256) tn256_tile<SPLIT>(J.X, J.ldx, J.Y, J.ldy, J.N1, J.N2, J.out, J.N2, tile_1 * 256, tile_2 * 256, sp.part == 1 ? mh : 0, sp.part == 0 ? mh : J.M,
+                                               do_sum, nullptr, ts, smem, sp);
   else tn128_tile(J.X, J.ldx, J.Y, J.ldy, J.N1, J.N2, J.out, J.N2, tile_1 * 128, tile_2 * 128, 0, J.M, do_sum, nullptr, ts, smem);
 }
 
@@ -910,7 +976,23 @@ static int tn_group_tile(const TnJob* jobs, int njobs) {  // 256, 128, or 0 = no
 }
 bool gemm_tn_grouped_ok(const TnJob* jobs, int njobs) { return tn_group_tile(jobs, njobs) != 0; }
 
-int gemm_tn_grouped(const TnJob* jobs, int njobs, hipStream_t st) {
+__device__ unsigned g_tn_split_flags[256];   // hand-off flags of the split grouped launch: zero at module load, cleared again by every consumer
+static unsigned* tn_split_flags_dev() {
+  static unsigned* base[64];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!base[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tn_split_flags)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    base[dev] = (unsigned*)p;
+  }
+  return base[dev];
+}
+size_t gemm_tn_grouped_split_bytes(int tiles) { return (size_t)tiles * 36 * 512 * sizeof(f32x4); }
+
+int gemm_tn_grouped(const TnJob* jobs, int njobs, hipStream_t st, void* split_ws, size_t split_ws_bytes) {
   const int tile = tn_group_tile(jobs, njobs);
   if (!tile) { set_error("gemm_tn_grouped: products not groupable (1..%d jobs, widths multiples of 128, 16-byte aligned operands)", TN_GROUP_MAX); return SMBV_ERR_SHAPE; }
   TnGroup g;
@@ -922,8 +1004,18 @@ int gemm_tn_grouped(const TnJob* jobs, int njobs, hipStream_t st) {
     tiles += (jobs[i].N1 / tile) * (jobs[i].N2 / tile);
   }
   for (int i = njobs; i < TN_GROUP_MAX; i++) { g.job[i] = g.job[0]; g.job[i].tile0 = 0x7fffffff; }
-  if (tile == 256) hipLaunchKernelGGL(gemm_tn_grouped_kernel<256>, dim3(tiles), dim3(512), 0, st, g);
-  else hipLaunchKernelGGL(gemm_tn_grouped_kernel<128>, dim3(tiles), dim3(256), 0, st, g);
+  g.tiles = 0; g.scratch = nullptr; g.flags = nullptr; g.status = nullptr;
+  // split launch: every tile's token range as two halves by two workgroups (256 x 256 tiles only; every product with at least 128 tokens per half; one launch in
+  // flight per device at a time: the flags are the library's - the caller is block.hip on the library's side stream)
+  if (tile == 256 && split_ws && !((uintptr_t)split_ws & 255) && tiles <= 128 && split_ws_bytes >= gemm_tn_grouped_split_bytes(tiles) && !(g_ab & 4)) {
+    bool ok = true;
+    for (int i = 0; i < njobs; i++) ok = ok && jobs[i].M >= 256;
+    unsigned* fl = ok ? tn_split_flags_dev() : nullptr;
+    if (fl) { g.tiles = tiles; g.scratch = (f32x4*)split_ws; g.flags = fl; g.status = device_status_word_dev(); }
+  }
+  if (tile == 256 && g.tiles > 0) hipLaunchKernelGGL((gemm_tn_grouped_kernel<256, true>), dim3(2 * tiles), dim3(512), 0, st, g);
+  else if (tile == 256) hipLaunchKernelGGL((gemm_tn_grouped_kernel<256, false>), dim3(tiles), dim3(512), 0, st, g);
+  else hipLaunchKernelGGL((gemm_tn_grouped_kernel<128, false>), dim3(tiles), dim3(256), 0, st, g);
   return check_launch("gemm_tn_grouped");
 }
 

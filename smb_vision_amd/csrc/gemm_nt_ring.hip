@@ -29,7 +29,8 @@ static constexpr int RSLOT = (RBM + RBN) * RBK * 2;  // 24 KiB
 
 // Four output rows (one register index r each) of one lane: v[r] are columns n .. n+3 of row m[r].  Loads of all four rows are issued
 // before the first use so that they are in flight together; rows past M are clamped for the loads and masked for the stores.
-// EPI: 0 plain (bias / row addend / outputs), 1 + GELU (saving the pre-activation), 2 + dGELU multiplier - compiled separately to bound registers
+// EPI: 0 plain (bias / row addend / outputs), 1 + GELU (saving the pre-activation), 2 + dGELU multiplier, 3 + rotary embedding of the q | k sections -
+// compiled separately to bound registers
 template <int EPI>
 __device__ __forceinline__ void epi_rows4(const GemmEpi& e, const int (&m)[4], const int M, const int n, f32x4 (&v)[4], const f32x4 bias) {
   int mc[4];
@@ -84,6 +85,18 @@ __device__ __forceinline__ void epi_rows4(const GemmEpi& e, const int (&m)[4], c
       v[r][0] = gelu_erf(v[r][0]); v[r][1] = gelu_erf(v[r][1]); v[r][2] = gelu_erf(v[r][2]); v[r][3] = gelu_erf(v[r][3]);
     }
   }
+  if constexpr (EPI == 3) {   // rotary embedding of the q | k sections (GemmEpi::rope_*): on the bf16-rounded product, as the stand-alone kernel read it
+    const int seg = 2 * ((e.rope_Dh / 3) / 2);
+    const bool in_section = n < 2 * e.rope_wa;
+    const RopeLane rl = rope_lane((n % e.rope_wa) % e.rope_hs, seg, in_section);
+    if (rl.on[0] | rl.on[1]) {
+      int p[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) p[r] = e.rope_pos ? e.rope_pos[mc[r]] : mc[r] % e.rope_S;
+#pragma unroll
+      for (int r = 0; r < 4; r++) rope_round_apply4(v[r], rl, rope_tok(p[r], e.rope_grid, seg), seg, e.rope_table, false);
+    }
+  }
   if (e.out_f32) {
 #pragma unroll
     for (int r = 0; r < 4; r++)
@@ -119,7 +132,7 @@ __device__ __forceinline__ void ring_epilogue(const f32x4 (&acc)[4][4], const Ge
 
 // one 16-byte store that writes through to the memory side (sc1): a partial tile another workgroup will read must not sit dirty in this XCD's L2
 template <int OFF>   // (the byte offset travels as the instruction's immediate: one address register pair serves four stores)
-__device__ __forceinline__ void store16_sc1(f32x4* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1" ::"v"(p), "v"(v), "i"(OFF) : "memory"); }
+__device__ __forceinline__ void store16_sc1(f32x4* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1\n\ts_nop 1" ::"v"(p), "v"(v), "i"(OFF) : "memory"); }  // s_nop: see sweep_store16_sc1 (smbv_common.h)
 __device__ void splitk_fault(unsigned* status) {
   if (status) __hip_atomic_store(status, 0x6001u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -368,7 +381,8 @@ static void launch_ring(const bf16_t* A, int lda, const bf16_t* B, int ldb, int 
   const int tm = cdiv(M, RBM), tn = N / RBN;
   const dim3 grid(tm * tn), block(512);
   unsigned* nostatus = nullptr;
-  if (e.act_gelu) hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 1, 1>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg, nostatus);
+  if (e.rope_table) hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 3, 1>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg, nostatus);
+  else if (e.act_gelu) hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 1, 1>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg, nostatus);
   else if (e.dgelu_pre) hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 2, 1>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg, nostatus);
   else hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 0, 1>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg, nostatus);
 }

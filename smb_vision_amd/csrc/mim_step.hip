@@ -234,7 +234,10 @@ static int mim_backward(const smbv_mim_cfg& c, const smbv_mim_tensors& p, const 
   for (int l = c.layers - 1; l >= 0; l--) {
     // recompute: the decoder ran after the encoder and does not touch the encoder's shared set, so the last encoder block's activations survive
     if (c.recompute && l != c.layers - 1) { RC(pipe.wait_for(pipe.k - 2, st)); RC(layer_fwd(to_block(p.enc[l]), W.enc[l], de, W.sc, W.x[l], W.x[l + 1], nullptr, 0, 0, st)); }
-    RC(layer_bwd(to_block(p.enc[l]), to_block(gr.enc[l]), W.enc[l], de, W.sc, W.x[l], W.g1, W.g0, pipe, 0, 0, next_event(), st));
+    pipe.last_block = l == 0;
+    const int rcl = layer_bwd(to_block(p.enc[l]), to_block(gr.enc[l]), W.enc[l], de, W.sc, W.x[l], W.g1, W.g0, pipe, 0, 0, next_event(), st);
+    pipe.last_block = false;
+    RC(rcl);
   }
   // patch embedding (the volume needs no gradient)
   {

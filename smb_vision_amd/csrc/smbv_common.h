@@ -39,6 +39,66 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
+// One pair of the reference's 3-axis rotary map (modeling_vjepa.py:204-228; vjepa_ops.hip rope3d_kernel) or of its transpose, with the contraction spelled
+// out: the map is applied by the stand-alone kernel, by the QKV product's epilogue and by the attention backward's stores, and all three must round alike
+__device__ __forceinline__ void rope_pair(float x0, float x1, float c0, float s0, float c1, float s1, bool transpose, float& y0, float& y1) {
+  if (!transpose) { y0 = __builtin_fmaf(x0, c0, -(x1 * s0)); y1 = __builtin_fmaf(x1, c1, x0 * s1); }   // out = x*cos + rot(x)*sin, rot = (-x1, x0)
+  else { y0 = __builtin_fmaf(x0, c0, x1 * s1); y1 = __builtin_fmaf(x1, c1, -(x0 * s0)); }              // transposed map for the gradient
+}
+// what a lane needs of the map for ITS columns (4 consecutive elements e0 .. e0 + 3 of a head, e0 a multiple of 4: two pairs) - token-independent.
+// No integer division: e < 3 seg, and an element t of a segment uses angle t % (seg / 2) with t < seg (the reference TILES cos / sin)
+struct RopeLane {
+  int on[2];        // pair j is rotated (inside the rotated width 3 * seg)
+  int axis[2];      // 0 frame, 1 height, 2 width
+  int i0[2], i1[2]; // table columns of the pair's two angles
+};
+__device__ __forceinline__ RopeLane rope_lane(int e0, int seg, bool in_section) {
+  RopeLane r;
+  const int half = seg >> 1;
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int e = e0 + 2 * j;
+    r.on[j] = in_section && e < 3 * seg;
+    const int ax = (e >= seg ? 1 : 0) + (e >= 2 * seg ? 1 : 0);
+    const int t0 = e - ax * seg, t1 = t0 + 1;   // (seg is even and e is even: t1 < seg)
+    r.axis[j] = ax;
+    r.i0[j] = t0 >= half ? t0 - half : t0;
+    r.i1[j] = t1 >= half ? t1 - half : t1;
+  }
+  return r;
+}
+// a token's three position ids -> its three table rows (element offsets into the table)
+struct RopeTok { int row[3]; };
+__device__ __forceinline__ RopeTok rope_tok(int p, int grid, int seg) {
+  const int tpf = grid * grid;
+  const int frame = p / tpf, rem = p - tpf * frame, height = rem / grid, width = rem - grid * height;
+  return RopeTok{{frame * seg, height * seg, width * seg}};
+}
+// the map (or its transpose) on 4 consecutive elements of one token, already rounded to bf16 where the stand-alone kernel would have read bf16
+__device__ __forceinline__ void rope_apply4(f32x4& v, const RopeLane& rl, const RopeTok& tk, int seg, const float* __restrict__ table, bool transpose) {
+  const int half = seg >> 1;
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    if (!rl.on[j]) continue;
+    const float* tb = table + (rl.axis[j] == 0 ? tk.row[0] : (rl.axis[j] == 1 ? tk.row[1] : tk.row[2]));
+    float y0, y1;
+    rope_pair(v[2 * j], v[2 * j + 1], tb[rl.i0[j]], tb[half + rl.i0[j]], tb[rl.i1[j]], tb[half + rl.i1[j]], transpose, y0, y1);
+    v[2 * j] = y0; v[2 * j + 1] = y1;
+  }
+}
+// round to bf16, apply, ready for the final pack (what "rope3d on the stored bf16 matrix" computes)
+__device__ __forceinline__ void rope_round_apply4(f32x4& v, const RopeLane& rl, const RopeTok& tk, int seg, const float* __restrict__ table, bool transpose) {
+  const unsigned b0 = pack_bf16(v[0], v[1]), b1 = pack_bf16(v[2], v[3]);
+  v = (f32x4){bf_lo(b0), bf_hi(b0), bf_lo(b1), bf_hi(b1)};
+  rope_apply4(v, rl, tk, seg, table, transpose);
+}
+// the map as the attention backward's stores take it (attention_bwd.hip, ROPE builds): dQ / dK leave through the TRANSPOSED map
+struct RopeStore {
+  const float* table = nullptr;
+  const int* pos = nullptr;   // token position ids by row of the [B * S] token matrix (null: the token's index inside its sequence)
+  int grid = 0, seg = 0;
+};
+
 // transposed LDS read (verified by tools/probe/hw_probe.hip): per 16-lane group a 4x16 block of 16-bit
 // elements; lane 4q+p supplies &block[q][4p]; lane i receives {block[0][i], block[1][i], block[2][i], block[3][i]}.
 __device__ __forceinline__ s16x4 lds_read_tr16(const void* lds_addr) {
@@ -149,13 +209,18 @@ struct SweepPart {
   unsigned* flag = nullptr;      // 0 -> 1 by the producer, back to 0 by the consumer
   unsigned* status = nullptr;    // the device's sticky fault word (a consumer that gives up waiting)
 };
+// (the s_nop: a store of more than 8 bytes reads its data registers for two more wait states on gfx940+, and the compiler, which does not look inside the asm,
+// is free to put a VALU write of those registers right behind it - it did, in gemm.hip's hand-off: address arithmetic landed in the last piece's first two words)
 template <int OFF>
-__device__ __forceinline__ void sweep_store16_sc1(f32x4* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1" ::"v"(p), "v"(v), "i"(OFF) : "memory"); }
-// NV 16-byte pieces per lane: piece i of wave w at scratch[(w * NV + i) * 64 + lane]
+__device__ __forceinline__ void sweep_store16_sc1(f32x4* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1\n\ts_nop 1" ::"v"(p), "v"(v), "i"(OFF) : "memory");
+}
+// The hand-off in its parts (a kernel whose accumulators fill the register file stores them where they are, in several groups: gemm.hip), and as the two calls the
+// attention blocks use.  NV 16-byte pieces per lane and group: piece i of wave w at base[(w * NV + i) * 64 + lane]; a wave's pieces sit 1 KiB apart.
 template <int NV>
-__device__ __forceinline__ void sweep_publish(const SweepPart& sp, const f32x4 (&v)[NV], int t, int w, int l) {
+__device__ __forceinline__ void sweep_store(f32x4* base, const f32x4 (&v)[NV], int w, int l) {
   static_assert(NV % 4 == 0, "pieces go out four to an address register pair");
-  f32x4* p = sp.scratch + (size_t)w * (NV * 64) + l;
+  f32x4* p = base + (size_t)w * (NV * 64) + l;
 #pragma unroll
   for (int i = 0; i < NV; i += 4) {
     sweep_store16_sc1<0>(p + i * 64, v[i]);
@@ -163,14 +228,15 @@ __device__ __forceinline__ void sweep_publish(const SweepPart& sp, const f32x4 (
     sweep_store16_sc1<2048>(p + i * 64, v[i + 2]);
     sweep_store16_sc1<3072>(p + i * 64, v[i + 3]);
   }
+}
+// every storing wave drains its own stores, the workgroup meets, ONE lane raises the flag that speaks for all of them
+__device__ __forceinline__ void sweep_signal(const SweepPart& sp, int t) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (t == 0) __hip_atomic_store(sp.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// returns false (after raising the fault word) if the producer's flag never came; `ok` lives in LDS the block no longer uses.  ADD = true: v += the partial
-// (the backward's sums); ADD = false: v = the partial (the forward combines its halves through their row maxima).  `clear`: false leaves the flag to the caller
-template <int NV, bool ADD = true>
-__device__ __forceinline__ bool sweep_collect(const SweepPart& sp, f32x4 (&v)[NV], int t, int w, int l, int* ok) {
+// one lane polls, takes the agent-scope acquire; false (after raising the fault word) if the producer's flag never came.  `ok` lives in LDS the block no longer uses
+__device__ __forceinline__ bool sweep_wait(const SweepPart& sp, int t, int* ok) {
   if (t == 0) {
     int spins = 0;
     while (__hip_atomic_load(sp.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(8); spins++; }
@@ -183,7 +249,12 @@ __device__ __forceinline__ bool sweep_collect(const SweepPart& sp, f32x4 (&v)[NV
     if (t == 0 && sp.status) __hip_atomic_store(sp.status, 0x5004u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return false;
   }
-  const f32x4* p = sp.scratch + (size_t)w * (NV * 64) + l;
+  return true;
+}
+// v += the partial (ADD) or v = the partial, four loads in flight at a time
+template <int NV, bool ADD = true>
+__device__ __forceinline__ void sweep_load(const f32x4* base, f32x4 (&v)[NV], int w, int l) {
+  const f32x4* p = base + (size_t)w * (NV * 64) + l;
 #pragma unroll
   for (int i = 0; i < NV; i += 4) {
     f32x4 a[4];
@@ -193,11 +264,24 @@ __device__ __forceinline__ bool sweep_collect(const SweepPart& sp, f32x4 (&v)[NV
     for (int j = 0; j < 4; j++) { if constexpr (ADD) v[i + j] += a[j]; else v[i + j] = a[j]; }
     asm volatile("" : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3])::"memory");
   }
-  __syncthreads();   // every wave holds its addends before the flag goes back to 0 for the next launch
+}
+// every wave holds its addends: the flag goes back to 0 for the next launch
+__device__ __forceinline__ void sweep_release(const SweepPart& sp, int t) {
+  __syncthreads();
   if (t == 0) __hip_atomic_store(sp.flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int NV>
+__device__ __forceinline__ void sweep_publish(const SweepPart& sp, const f32x4 (&v)[NV], int t, int w, int l) {
+  sweep_store<NV>(sp.scratch, v, w, l);
+  sweep_signal(sp, t);
+}
+template <int NV, bool ADD = true>
+__device__ __forceinline__ bool sweep_collect(const SweepPart& sp, f32x4 (&v)[NV], int t, int w, int l, int* ok) {
+  if (!sweep_wait(sp, t, ok)) return false;
+  sweep_load<NV, ADD>(sp.scratch, v, w, l);
+  sweep_release(sp, t);
   return true;
 }
-
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -40,6 +40,13 @@ struct GemmEpi {
   // form measured SLOWER than the mixed-tile 128 x 128 launch (profiles/r05_splitk_ab.txt) and is not selected
   void* splitk_ws = nullptr;
   size_t splitk_ws_bytes = 0;
+  // 3-axis rotary embedding of the q | k column sections on the way out (V-JEPA's fused QKV product, round 5): columns [0, 2 * rope_wa) in head slots of
+  // rope_hs columns get rope3d's map - applied to the bf16-ROUNDED product, exactly what the rope3d launch behind the product computed before (bitwise the
+  // same matrix) - in the ring kernel's epilogue (EPI 3); a product that kernel does not take runs plain and gemm_nt launches rope3d behind it.
+  // Needs: out_bf16 only (no fp32 output, no activation), rope_wa and rope_hs multiples of 4
+  const float* rope_table = nullptr;   // fp32 [P][2][seg / 2] cos | sin
+  const int* rope_pos = nullptr;       // token position ids [M] (null: m % rope_S)
+  int rope_S = 0, rope_grid = 0, rope_Dh = 0, rope_hs = 0, rope_wa = 0;
 };
 // split-K form of the ring kernel: is it the selection for this product, and what it needs
 bool gemm_nt_splitk_wanted(int lda, int ldb, int M, int N, int K, const GemmEpi& e);
@@ -71,9 +78,15 @@ struct TnJob {
   int ldx, ldy, M, N1, N2, seg;
   int tile0;  // (filled in by gemm_tn_grouped) first block of this job
 };
-struct TnGroup { TnJob job[TN_GROUP_MAX]; int njobs; };
+struct TnGroup {
+  TnJob job[TN_GROUP_MAX]; int njobs;
+  int tiles;                    // > 0: split launch - 2 x tiles blocks, each tile's token range as two halves (gemm.hip)
+  f32x4* scratch; unsigned* flags; unsigned* status;
+};
 bool gemm_tn_grouped_ok(const TnJob* jobs, int njobs);
-int gemm_tn_grouped(const TnJob* jobs, int njobs, hipStream_t st);
+// split_ws (256-byte aligned, gemm_tn_grouped_split_bytes(tiles)): the launch runs every 256 x 256 tile's token range as two halves by two workgroups
+int gemm_tn_grouped(const TnJob* jobs, int njobs, hipStream_t st, void* split_ws = nullptr, size_t split_ws_bytes = 0);
+size_t gemm_tn_grouped_split_bytes(int tiles);
 
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd, int rows, int D, float eps,
                   long grp_in, long grp_out, long row_off, hipStream_t st, float* y32 = nullptr);
@@ -87,9 +100,16 @@ size_t layernorm_bwd_workspace_bytes(int rows, int D);
 // the stored bf16 output otherwise enters delta at 2^-9 relative, which a near-uniform softmax over many keys does not average out
 int attention_fwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, bf16_t* O, int ldo, float* LSE, int B, int S, int H, int Dh,
                   float scale, int Sq, int qoff, hipStream_t st, bf16_t* O_lo = nullptr);
+// the rotary map the q / k of this attention went through (attention_bwd: dQ / dK leave through its transpose; Dh = the REAL head_dim, <= the slot width)
+struct RopeBwd {
+  const float* table = nullptr;
+  const int* pos = nullptr;   // position ids by row of the [B * S] token matrix; null: the token's index in its sequence
+  int grid = 0, Dh = 0;
+};
 int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
                   float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st,
-                  const bf16_t* O_lo = nullptr, void* f8ws = nullptr, size_t f8ws_bytes = 0, void* split_ws = nullptr, size_t split_ws_bytes = 0);
+                  const bf16_t* O_lo = nullptr, void* f8ws = nullptr, size_t f8ws_bytes = 0, void* split_ws = nullptr, size_t split_ws_bytes = 0,
+                  const RopeBwd* rope = nullptr);
 // split_ws (256-byte aligned, attention_bwd_split_workspace_max bytes): the pair launch runs the last tiles of each role as two half sweeps (attention_bwd.hip SweepPart)
 size_t attention_bwd_split_workspace_bytes(int Dh, int xk, int xq);
 size_t attention_bwd_split_workspace_max(int B, int S, int H, int Dh);

@@ -46,8 +46,7 @@ __global__ __launch_bounds__(256) void rope3d_kernel(bf16_t* __restrict__ qkv, i
       const unsigned u = sec ? k[j] : q[j];
       const float x0 = bf_lo(u), x1 = bf_hi(u);
       float y0, y1;
-      if (!transpose) { y0 = x0 * c0 - x1 * s0; y1 = x1 * c1 + x0 * s1; }   // out = x*cos + rot(x)*sin, rot = (-x1, x0)
-      else { y0 = x0 * c0 + x1 * s1; y1 = x1 * c1 - x0 * s0; }              // transposed map for the gradient
+      rope_pair(x0, x1, c0, s0, c1, s1, transpose != 0, y0, y1);
       if (sec) k[j] = pack_bf16(y0, y1); else q[j] = pack_bf16(y0, y1);
     }
   }

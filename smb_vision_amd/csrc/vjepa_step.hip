@@ -287,7 +287,10 @@ static int vjepa_backward(const smbv_vjepa_cfg& c, const smbv_vjepa_tensors& p, 
                         W.sc.scratch, W.sc.scratch_bytes, st));
   RC(mark());  // [players+2] encoder.layernorm
   for (int l = c.layers - 1; l >= 0; l--) {
-    RC(layer_bwd(vblock(p.enc[l]), vblock(gr.enc[l]), W.enc[l], de, W.sc, W.x[l], W.g0, W.g1, pipe, l == c.layers - 1 ? need : 0, 0, next_event(), st));   // [players+3 ..] encoder layers, last first
+    pipe.last_block = l == 0;   // its weight-gradient launch is the tail of the backward: token halves on twice the CUs (gemm_tn_grouped)
+    const int rcl = layer_bwd(vblock(p.enc[l]), vblock(gr.enc[l]), W.enc[l], de, W.sc, W.x[l], W.g0, W.g1, pipe, l == c.layers - 1 ? need : 0, 0, next_event(), st);   // [players+3 ..] encoder layers, last first
+    pipe.last_block = false;
+    RC(rcl);
   }
   // patch embedding
   {

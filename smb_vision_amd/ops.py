@@ -30,10 +30,11 @@ def _ws(nbytes, dev):
 
 
 def gemm_nt(A, B, *, bias=None, rowadd=None, rowidx=None, gelu=False, save_pre=False, dgelu_pre=None, out_bf16=True, out_f32=False,
-            alpha=1.0, grp=None, out_rows=None, reuse=None, splitk=False):
+            alpha=1.0, grp=None, out_rows=None, reuse=None, splitk=False, rope=None):
     """C = epi(A[M,K] @ B[N,K]^T).  Returns dict with 'bf16', 'f32', 'pre' entries as requested.  reuse: a dict returned by an earlier call of the
     same shape - its tensors are written again instead of allocating (and zero-filling) new ones (timing loops).  splitk: smbv_gemm_nt_splitk (two K
-    halves per 256 x 128 tile; raises ValueError for a product that form does not take)."""
+    halves per 256 x 128 tile; raises ValueError for a product that form does not take).  rope: dict(table, pos (or None), S, grid, Dh, head_stride, wa) -
+    smbv_gemm_nt_rope, the 3-axis rotary embedding of the q | k sections applied in the epilogue."""
     _need_gpu(A, B)
     lib = _lib.load()
     M, K = A.shape
@@ -64,8 +65,27 @@ def gemm_nt(A, B, *, bias=None, rowadd=None, rowidx=None, gelu=False, save_pre=F
         res["splitk_ws"] = ws
         check(lib.smbv_gemm_nt_splitk(_p(A), A.stride(0), _p(B), B.stride(0), M, N, K, C.byref(e), _p(ws), ws.numel(), _stream()), "smbv_gemm_nt_splitk")
         return res
+    if rope is not None:
+        rc = rope_cfg(**{k: v for k, v in rope.items() if k != "wa"})
+        check(lib.smbv_gemm_nt_rope(_p(A), A.stride(0), _p(B), B.stride(0), M, N, K, C.byref(e), C.byref(rc), rope["wa"], _stream()), "smbv_gemm_nt_rope")
+        return res
     check(lib.smbv_gemm_nt(_p(A), A.stride(0), _p(B), B.stride(0), M, N, K, C.byref(e), _stream()), "smbv_gemm_nt")
     return res
+
+
+def rope_cfg(table, pos, S, grid, Dh, head_stride):
+    """smbv_rope3d_cfg over live tensors (the caller keeps them alive for the call)."""
+    rc = _lib.Rope3dCfg()
+    rc.table, rc.pos, rc.S, rc.grid, rc.Dh, rc.head_stride = table.data_ptr(), (pos.data_ptr() if pos is not None else None), S, grid, Dh, head_stride
+    return rc
+
+
+def rope3d_(qkv, wa, H, rope, transpose=False):
+    """smbv_rope3d in place on the q | k sections of qkv [rows, ld] (rope: the dict gemm_nt takes, wa ignored)."""
+    lib = _lib.load()
+    check(lib.smbv_rope3d(_p(qkv), qkv.stride(0), wa, qkv.shape[0], rope["S"], H, rope["head_stride"], rope["Dh"], rope["grid"],
+                          (rope["pos"].data_ptr() if rope["pos"] is not None else None), rope["table"].data_ptr(), int(transpose), _stream()), "smbv_rope3d")
+    return qkv
 
 
 def gemm_tn(X, Y):
@@ -93,9 +113,10 @@ def gemm_tn_bias(X, Y):
     return out, xs
 
 
-def gemm_tn_grouped(pairs, sums=None, out=None):
+def gemm_tn_grouped(pairs, sums=None, out=None, split=False):
     """pairs: list of (X [M,N1], Y [M,N2]) bf16; returns the list of X^T @ Y (fp32) from ONE launch (smbv_gemm_tn_grouped).  sums: per job None or a
-    segment count (1..3): also returns that job's column sums of X as a list of `segments` tensors."""
+    segment count (1..3): also returns that job's column sums of X as a list of `segments` tensors.  split: every tile's token range as two halves by two
+    workgroups (smbv_gemm_tn_grouped_split)."""
     lib = _lib.load()
     n = len(pairs)
     jobs = (_lib.TnJob * n)()
@@ -118,7 +139,11 @@ def gemm_tn_grouped(pairs, sums=None, out=None):
         else:
             j.seg = 0
             xs.append(None)
-    check(lib.smbv_gemm_tn_grouped(jobs, n, _stream()), "smbv_gemm_tn_grouped")
+    if split:
+        ws = _ws(max(256, lib.smbv_gemm_tn_grouped_split_workspace_bytes(jobs, n)), pairs[0][0].device)
+        check(lib.smbv_gemm_tn_grouped_split(jobs, n, _p(ws), ws.numel(), _stream()), "smbv_gemm_tn_grouped_split")
+    else:
+        check(lib.smbv_gemm_tn_grouped(jobs, n, _stream()), "smbv_gemm_tn_grouped")
     return (outs, xs) if sums else outs
 
 
@@ -179,8 +204,9 @@ def attention_fwd_fp8(qkv, B, S, H, scale=None, Sq=0, q_off=0):
     return O, lse
 
 
-def attention_bwd(qkv, O, dO, lse, B, S, H, scale=None, parts=7, out=None, Sq=0, q_off=0, Dh=64, O_lo=None, fp8=False, fp8_ws_short=0, split=None):
-    """fp8: the query-owner blocks recompute S and dP on the block-scaled fp8 MFMA (smbv_attention_bwd_fp8; head_dim 64).  fp8_ws_short: declare the
+def attention_bwd(qkv, O, dO, lse, B, S, H, scale=None, parts=7, out=None, Sq=0, q_off=0, Dh=64, O_lo=None, fp8=False, fp8_ws_short=0, split=None, rope=None):
+    """rope: dict(table, pos (or None), S, grid, Dh (the real head_dim), head_stride) - smbv_attention_bwd_rope: dQ / dK leave through the transposed rotary map
+    (split: None / False = no half sweeps).  fp8: the query-owner blocks recompute S and dP on the block-scaled fp8 MFMA (smbv_attention_bwd_fp8; head_dim 64).  fp8_ws_short: declare the
     workspace that many bytes smaller than it is (the error-path test).  split: True (a fresh scratch) or a uint8 scratch tensor - smbv_attention_bwd_split, the
     form the steps run (the last tiles of each role as two half sweeps)."""
     _need_gpu(qkv, O, dO, lse)
@@ -189,6 +215,15 @@ def attention_bwd(qkv, O, dO, lse, B, S, H, scale=None, parts=7, out=None, Sq=0,
     scale = scale if scale is not None else Dh ** -0.5
     dqkv, delta = out if out is not None else (torch.zeros_like(qkv), torch.empty(B, H, Sq if Sq > 0 else S, dtype=torch.float32, device=qkv.device))
     base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+    if rope is not None:
+        use_split = split is not None and split is not False
+        ws = (split if torch.is_tensor(split) else _ws(max(256, lib.smbv_attention_bwd_split_workspace_bytes(B, S, H, Dh)), qkv.device)) if use_split else None
+        f8 = _ws(lib.smbv_attention_bwd_fp8_workspace_bytes(B, S, H), qkv.device) if fp8 else None
+        rc = rope_cfg(**{k: v for k, v in rope.items() if k != "wa"})
+        check(lib.smbv_attention_bwd_rope(base, base + 2 * w, base + 4 * w, qkv.stride(0), _p(O), _p(O_lo), _p(dO), w, _p(lse), _p(delta), dbase, dbase + 2 * w,
+                                          dbase + 4 * w, dqkv.stride(0), B, S, H, Dh, scale, parts, Sq, q_off, _p(ws), ws.numel() if use_split else 0, _p(f8),
+                                          f8.numel() if fp8 else 0, C.byref(rc), _stream()), "smbv_attention_bwd_rope")
+        return dqkv, delta
     if fp8 and (split is None or split is False):
         ws = _ws(lib.smbv_attention_bwd_fp8_workspace_bytes(B, S, H), qkv.device)
         check(lib.smbv_attention_bwd_fp8(base, base + 2 * w, base + 4 * w, qkv.stride(0), _p(O), _p(O_lo), _p(dO), w, _p(lse), _p(delta), dbase, dbase + 2 * w,

@@ -139,6 +139,35 @@ def test_gemm_tn_grouped_is_the_products_one_by_one(ops, shapes):
         ops.gemm_tn_grouped([(rnd(64, 136, seed=1).bfloat16(), rnd(64, 128, seed=2).bfloat16())])
 
 
+@pytest.mark.parametrize("shapes", [
+    [(1000, 256, 512), (1000, 512, 256), (777, 256, 256), (1000, 768, 256)],       # ragged token counts: the halves are [0, (M / 2) & ~31) and the rest
+    [(7168, 768, 3072), (7168, 3072, 768), (7168, 768, 768), (7168, 2304, 768)],   # the ViT-base encoder block's launch: 108 tiles, 216 workgroups
+    [(256, 256, 256)],
+])
+def test_gemm_tn_grouped_split_hands_the_first_half_over_exactly(ops, shapes):
+    """smbv_gemm_tn_grouped_split (ABI 3003): every tile's token range as two halves by two workgroups, the first handing its fp32 tile and column sums to the
+    second through scratch.  Same products as the whole-range launch up to the order of two fp32 additions, identical run to run, flags left clear (the
+    second and third call would otherwise read a stale hand-off or trip the bounded wait), device status word untouched."""
+    pairs = [(rnd(M, N1, seed=10 + i).bfloat16(), rnd(M, N2, seed=20 + i).bfloat16()) for i, (M, N1, N2) in enumerate(shapes)]
+    nseg = [3 if N1 % 3 == 0 and (N1 // 3) % 256 == 0 else 1 for (_, N1, _) in shapes]
+    whole, xw = ops.gemm_tn_grouped(pairs, sums=nseg)
+    runs = [ops.gemm_tn_grouped(pairs, sums=nseg, split=True) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert ops.device_status() == 0
+    outs, xs = runs[0]
+    for i, ((X, Y), o, w, x, xw_i, (M, N1, N2)) in enumerate(zip(pairs, outs, whole, xs, xw, shapes)):
+        ref = X.float().t() @ Y.float()
+        assert rel_err(o, ref) < 1e-5 * math.sqrt(M) + 1e-6
+        assert rel_err(o, w) < 2e-6
+        assert rel_err(torch.cat(x), torch.cat(xw_i)) < 2e-6
+        for other, xo in runs[1:]:
+            assert torch.equal(o, other[i]) and torch.equal(torch.cat(x), torch.cat(xo[i]))
+    with pytest.raises(ValueError):   # a launch the split form does not take is refused, not run whole behind the caller's back
+        ops.gemm_tn_grouped([(rnd(512, 384, seed=1).bfloat16(), rnd(512, 256, seed=2).bfloat16())], split=True)
+    with pytest.raises(ValueError):
+        ops.gemm_tn_grouped([(rnd(100, 256, seed=1).bfloat16(), rnd(100, 256, seed=2).bfloat16())], split=True)
+
+
 @pytest.mark.parametrize("rows,D", [(5, 64), (1000, 768), (333, 384), (64, 128), (17, 1024)])
 def test_layernorm(ops, rows, D):
     x = rnd(rows, D, seed=1) * 2 + 0.5
@@ -682,6 +711,49 @@ def test_attention_backward_split_sweeps_hand_off_exactly(ops, B, S, H, Dh, Sq, 
         assert torch.equal(f8_split, again) and torch.equal(f8_split[:, w:], firsts[1][:, w:])
         dq = f8_split[:, :w].float() - f8_whole[:, :w].float()
         assert float(dq.norm()) <= 2e-3 * float(f8_whole[:, :w].float().norm())
+
+
+@pytest.mark.parametrize("B,S,H,Dh,real,Sq,qoff,with_pos", [
+    (1, 7168, 12, 64, 64, 0, 0, False),       # large enough for half sweeps: the consumer halves store through the map too
+    (2, 1000, 3, 64, 64, 0, 0, True),         # batch 2, ragged tiles, shuffled position ids
+    (1, 2048, 6, 32, 32, 0, 0, True),         # head_dim 32: seg = 10, a 4-column group straddles two axes
+    (1, 1536, 4, 64, 40, 0, 0, True),         # head_dim 40 in a 64-wide slot (seg = 12: columns 36.. pass through)
+    (1, 4096, 4, 64, 64, 1024, 3072, True),   # ranged queries: dQ rows outside the range stay as they were
+])
+def test_attention_backward_stores_through_the_transposed_rotary_map_bitwise(ops, B, S, H, Dh, real, Sq, qoff, with_pos):
+    """smbv_attention_bwd_rope (ABI 3004; modeling_vjepa.py:311-326's rotation in the backward): dQ and dK of the rotated q / k leave through the transposed
+    3-axis map inside the kernel's stores - bitwise the matrix that smbv_attention_bwd(_split) followed by smbv_rope3d(transpose) leaves, which
+    tests/test_vjepa_gpu.py::test_rope3d_matches_oracle pins against autograd of the oracle's map.  Also with the fp8 query-owner blocks, which keep the launch
+    behind the kernels, and run to run."""
+    from smb_vision_amd import _lib
+    from smb_vision_amd.modeling_vjepa import rope_table
+    lib = _lib.load()
+    grid = 8
+    w = H * Dh
+    qkv, O, lse, dO = _bwd_case(ops, B, S, H, Dh, Sq, qoff, seed=83)
+    g = torch.Generator().manual_seed(5)
+    pos = torch.randint(0, grid * grid * 8, (B * S,), generator=g).to(torch.int32).cuda() if with_pos else None
+    rope = dict(table=rope_table(real, 128 if not with_pos else 16, "cuda"), pos=pos, S=S, grid=grid, Dh=real, head_stride=Dh)
+    need = lib.smbv_attention_bwd_split_workspace_bytes(B, S, H, Dh)
+    for split in ([False, True] if need > 0 else [False]):
+        ws = torch.empty(max(need, 256), dtype=torch.uint8, device="cuda") if split else None
+        two, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh, split=ws)
+        plain = two.clone()
+        ops.rope3d_(two, w, H, rope, transpose=True)
+        fused, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh, split=ws, rope=rope)
+        again, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh, split=ws, rope=rope)
+        torch.cuda.synchronize()
+        assert ops.device_status() == 0, _lib.last_error()
+        assert torch.equal(fused, two) and torch.equal(fused, again)
+        assert not torch.equal(fused[:, :2 * w], plain[:, :2 * w]) and torch.equal(fused[:, 2 * w:], plain[:, 2 * w:])   # dQ | dK mapped, dV untouched
+    if Dh == 64 and real == 64:
+        two, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh, fp8=True)
+        ops.rope3d_(two, w, H, rope, transpose=True)
+        fused, _ = ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh, fp8=True, rope=rope)
+        torch.cuda.synchronize()
+        assert torch.equal(fused, two)
+    with pytest.raises(_lib.SmbvError, match="rc=-3"):   # dK / dV only: the map needs both gradient products of the launch
+        ops.attention_bwd(qkv, O, dO, lse, B, S, H, Sq=Sq, q_off=qoff, Dh=Dh, parts=3, rope=rope)
 
 
 def test_attention_backward_argument_error_does_not_poison_the_stream(ops):

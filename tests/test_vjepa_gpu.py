@@ -63,6 +63,38 @@ def test_rope3d_matches_oracle(Dh, hs):
     assert rel(got, src.grad) < 1.5e-2
 
 
+@pytest.mark.parametrize("M,w,H,Dh,hs,S,with_pos", [
+    (2048, 768, 12, 64, 64, 1024, True),     # the encoder's product: N = 2304, K = 768 - the ring kernel's rotary epilogue
+    (1000, 384, 12, 32, 32, 500, False),     # the predictor's: head_dim 32 (a 4-column group straddles two axes: seg = 10), positions = row % S, ragged M
+    (1536, 384, 6, 64, 64, 512, True),       # N = 1152, K = 384
+    (300, 256, 3, 40, 64, 100, True),        # padded head slots; N = 576: not a ring shape - the product runs plain with the rope3d launch behind it
+])
+def test_qkv_product_with_rotary_epilogue_is_the_two_launches_bitwise(M, w, H, Dh, hs, S, with_pos):
+    """smbv_gemm_nt_rope (ABI 3004): the fused QKV product whose epilogue applies the 3-axis rotary map to the q | k sections of the bf16-rounded product
+    (modeling_vjepa.py:204-228, :311-326) leaves bitwise the matrix that smbv_gemm_nt followed by smbv_rope3d leaves - which test_rope3d_matches_oracle
+    pins against the oracle."""
+    from smb_vision_amd import ops
+    from smb_vision_amd.modeling_vjepa import rope_table
+    grid = 8
+    wa = H * hs
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(M, w, generator=g).bfloat16().cuda()
+    Wt = (torch.randn(3 * wa, w, generator=g) / w ** 0.5).bfloat16().cuda()
+    bias = (0.1 * torch.randn(3 * wa, generator=g)).cuda()
+    pos = torch.randint(0, grid * grid * 6, (M,), generator=g).to(torch.int32).cuda() if with_pos else None
+    rope = dict(table=rope_table(Dh, 16, "cuda"), pos=pos, S=S, grid=grid, Dh=Dh, head_stride=hs, wa=wa)   # frame / height / width ids < 16
+    fused = ops.gemm_nt(A, Wt, bias=bias, rope=rope)["bf16"]
+    two = ops.gemm_nt(A, Wt, bias=bias)["bf16"]
+    plain = two.clone()
+    ops.rope3d_(two, wa, H, rope)
+    torch.cuda.synchronize()
+    assert torch.equal(fused, two)
+    assert not torch.equal(fused[:, :2 * wa], plain[:, :2 * wa]) and torch.equal(fused[:, 2 * wa:], plain[:, 2 * wa:])   # q | k rotated, v untouched
+    from smb_vision_amd._lib import SmbvError
+    with pytest.raises(SmbvError):   # an epilogue the rotary form does not combine with
+        ops.gemm_nt(A, Wt, bias=bias, rope=rope, out_f32=True)
+
+
 def test_l1_and_ema_kernels():
     from smb_vision_amd.modeling_vjepa import MomentumEncoder, l1_loss
     torch.manual_seed(7)
