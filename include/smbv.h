@@ -364,6 +364,9 @@ typedef struct smbv_rope3d_cfg {
   const float* table;              /* as smbv_rope3d */
   const int32_t* pos;              /* int32 [rows] or NULL (= row % S) */
   int S, grid, Dh, head_stride;
+  int table_rows;                  /* P: the table covers frame / height / width ids 0 .. P-1 and every id of the call is below it (the fused forms stage the
+                                      table into LDS and decode positions without integer division: P * seg * 4 <= 32 KiB and P * grid^4 < 2^32; otherwise, or with 0 =
+                                      unknown, the map runs as the smbv_rope3d launch) */
 } smbv_rope3d_cfg;
 /* smbv_gemm_nt whose bf16 output [M, N] holds q in columns [0, wa) and k in [wa, 2 wa) (head slots of head_stride columns; N >= 2 wa, e.g. the fused QKV
  * product with N = 3 wa): the forward map is applied to those sections of the bf16-ROUNDED product in the epilogue - the stored matrix is bitwise what
@@ -434,7 +437,8 @@ typedef struct smbv_vjepa_io {
   const int32_t* pred_pos;         /* int32 [P,Nctx+Ntgt] position ids of the predictor sequence, sorted (modeling_vjepa.py:718-719) */
   const int32_t* ctx_slot;         /* int32 [P,Nctx] row of each context token in the sorted predictor sequence */
   const int32_t* tgt_slot;         /* int32 [P,Ntgt] row of each target token in the sorted predictor sequence */
-  const float* rope_enc;           /* fp32 [P][2][seg/2] cos|sin table for the encoder head_dim (see smbv_rope3d) */
+  const float* rope_enc;           /* fp32 [P][2][seg/2] cos|sin table for the encoder head_dim (see smbv_rope3d); P >= max(T / ts, H / ps, W / ps): the steps
+                                      stage that many rows into LDS for the rotary map they apply inside the QKV product and the attention backward */
   const float* rope_pred;          /* same for the predictor head_dim */
   float* enc_out;                  /* out: fp32 [B*N, d] last_hidden_state (after encoder.layernorm) */
   float* pred_out;                 /* out: fp32 [P*Ntgt, d] predictor_output.last_hidden_state (NULL: encoder only = skip_predictor) */

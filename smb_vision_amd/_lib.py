@@ -33,7 +33,7 @@ class TnJob(C.Structure):
 
 
 class Rope3dCfg(C.Structure):
-    _fields_ = [("table", c_f), ("pos", c_f), ("S", C.c_int), ("grid", C.c_int), ("Dh", C.c_int), ("head_stride", C.c_int)]
+    _fields_ = [("table", c_f), ("pos", c_f), ("S", C.c_int), ("grid", C.c_int), ("Dh", C.c_int), ("head_stride", C.c_int), ("table_rows", C.c_int)]
 
 
 class _Cfg(C.Structure):

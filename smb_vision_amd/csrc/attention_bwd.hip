@@ -363,19 +363,25 @@ __device__ __forceinline__ void attn_dkv2_block(const bf16_t* __restrict__ Q, co
 #pragma unroll
         for (int e = 0; e < 4; e++) { dkt[dt][4 * rg + e] = pv[4 * dt + rg][e]; dvt[dt][4 * rg + e] = pv[4 * DT + 4 * dt + rg][e]; }
   }
+  if constexpr (ROPE) {   // the cos | sin table into the tile loop's (dead) LDS, behind the word the hand-off's verdict travels through
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no LDS-DMA piece of the loop is still on its way into this memory)
+    __syncthreads();
+    rope_stage_table((float*)(smem + 16), rs.table, rs.geo, t, 256);
+    __syncthreads();
+  }
   if (key < S) {
     bf16_t* kp = dK + (row0 + key) * ldd + hoff;
     bf16_t* vp = dV + (row0 + key) * ldd + hoff;
     RopeTok tk = {};
-    if constexpr (ROPE) tk = rope_tok(rs.pos ? rs.pos[row0 + key] : key, rs.grid, rs.seg);
+    if constexpr (ROPE) tk = rope_tok(rs.pos ? rs.pos[row0 + key] : key, rs.geo);
 #pragma unroll
     for (int dt = 0; dt < DT; dt++)
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
         const int d0 = 32 * dt + 8 * rg + 4 * h2;
         f32x4 kk = {dkt[dt][4 * rg] * scale, dkt[dt][4 * rg + 1] * scale, dkt[dt][4 * rg + 2] * scale, dkt[dt][4 * rg + 3] * scale};
-        // (the gradient of the ROTATED key, rounded to bf16 as the stand-alone launch read it, through the transposed map)
-        if constexpr (ROPE) rope_round_apply4(kk, rope_lane(d0, rs.seg, true), tk, rs.seg, rs.table, true);
+        // (the gradient of the ROTATED key, rounded to bf16 as the stand-alone launch read it, through the transposed map; table in LDS)
+        if constexpr (ROPE) rope_round_apply4(kk, rope_lane(d0, rs.geo.seg, true), tk, rs.geo.seg, (const float*)(smem + 16), true);
         u32x2 pk = {pack_bf16(kk[0], kk[1]), pack_bf16(kk[2], kk[3])};
         *(u32x2*)(kp + d0) = pk;
         u32x2 pv = {pack_bf16(dvt[dt][4 * rg], dvt[dt][4 * rg + 1]), pack_bf16(dvt[dt][4 * rg + 2], dvt[dt][4 * rg + 3])};
@@ -816,18 +822,24 @@ __device__ __forceinline__ void attn_dq3_block(const bf16_t* __restrict__ Q, con
       for (int qi = 0; qi < 2; qi++) dqt[dt][qi] = pv[2 * dt + qi];
   }
 
+  if constexpr (ROPE) {   // the cos | sin table into the tile loop's (dead) LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no LDS-DMA piece of the loop is still on its way into this memory)
+    __syncthreads();
+    rope_stage_table((float*)(smem + 16), rs.table, rs.geo, t, 256);
+    __syncthreads();
+  }
 #pragma unroll
   for (int qi = 0; qi < 2; qi++) {
     const int q = tile_x * 128 + w * 32 + 16 * qi + n;
     if (q < Sq) {
       bf16_t* qp = dQ + (row0 + qoff + q) * ldd + hoff;
       RopeTok tk = {};
-      if constexpr (ROPE) tk = rope_tok(rs.pos ? rs.pos[row0 + qoff + q] : qoff + q, rs.grid, rs.seg);
+      if constexpr (ROPE) tk = rope_tok(rs.pos ? rs.pos[row0 + qoff + q] : qoff + q, rs.geo);
 #pragma unroll
       for (int dt = 0; dt < DTN; dt++) {
         const int d0 = 16 * dt + 4 * g;
         f32x4 qq = dqt[dt][qi] * scale;
-        if constexpr (ROPE) rope_round_apply4(qq, rope_lane(d0, rs.seg, true), tk, rs.seg, rs.table, true);
+        if constexpr (ROPE) rope_round_apply4(qq, rope_lane(d0, rs.geo.seg, true), tk, rs.geo.seg, (const float*)(smem + 16), true);
         u32x2 pk = {pack_bf16(qq[0], qq[1]), pack_bf16(qq[2], qq[3])};
         *(u32x2*)(qp + d0) = pk;
       }
@@ -1253,13 +1265,15 @@ int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, con
                   const bf16_t* O_lo, void* f8ws, size_t f8ws_bytes, void* split_ws, size_t split_ws_bytes, const RopeBwd* rope) {
   RopeStore rs;
   if (rope) {
-    rs.table = rope->table; rs.pos = rope->pos; rs.grid = rope->grid; rs.seg = 2 * ((rope->Dh / 3) / 2);
+    rs.table = rope->table; rs.pos = rope->pos;
     if (!rope->table || rope->grid <= 0 || rope->Dh <= 0 || rope->Dh > Dh || (parts & 6) != 6) { set_error("attention_bwd: rotary map needs a table, a grid, head_dim <= the slot and both gradient products"); return SMBV_ERR_ARG; }
-    if (rs.seg <= 0) rope = nullptr;   // head_dim < 6: nothing is rotated
+    if (2 * ((rope->Dh / 3) / 2) <= 0) rope = nullptr;   // head_dim < 6: nothing is rotated
   }
+  // in the stores only with a table whose extent is known (it is staged into LDS) and positions the division-free decode is exact for
+  const bool storable = rope && rope_geo(rs.geo, rope->grid, rope->Dh, rope->rows);
   bool done = false;
   const int rc = attention_bwd_impl(Q, K, V, ld, O, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, H, Dh, scale, parts, Sq, qoff, st, O_lo, f8ws, f8ws_bytes, split_ws,
-                                    split_ws_bytes, rope ? &rs : nullptr, &done);
+                                    split_ws_bytes, storable ? &rs : nullptr, &done);
   if (rc != SMBV_OK || !rope || done) return rc;
   return rope3d(dQ, ldd, (int)(dK - dQ), (long)B * S, S, H, Dh, rope->Dh, rope->grid, rope->pos, rope->table, 1, st);
 }

@@ -24,6 +24,7 @@ struct BlockDims {
   int rope_grid = 0;              // > 0: 3-axis RoPE on q and k with this grid size (tokens per row; tokens per frame = grid^2)
   const int* pos = nullptr;       // token position ids for RoPE (null = index within the sequence)
   const float* rope_table = nullptr;
+  int rope_rows = 0;              // positions per axis the table covers (frames, rows and columns of the token grid all stay below it)
   int attn_fp8 = 0;               // bit 0: attention forward on the block-scaled fp8 MFMA (attention_fp8.hip); bit 1: also the backward's recomputed
                                   // S / dP products (query-owner blocks, attention_bwd.hip attn_dq_fp8_block); the accumulating products stay bf16
   int o_resid = 0;                // 1: the attention forward also saves the bf16 residual of its fp32 output (LayerWs::attn_o_lo) and the backward's

@@ -115,7 +115,7 @@ int layer_fwd(const BlockPtrs& p, LayerWs& L, const BlockDims& d, BwdScratch& sc
   {
     GemmEpi e; e.bias = L.bqkv; e.out_bf16 = L.qkv; e.ld_ob = 3 * wa;
     // V-JEPA: the rotary embedding of q and k rides in the product's epilogue (gemm_nt: the ring kernel's EPI 3, else a rope3d launch behind the product)
-    if (d.rope_grid > 0) { e.rope_table = d.rope_table; e.rope_pos = d.pos; e.rope_S = S; e.rope_grid = d.rope_grid; e.rope_Dh = d.Dh; e.rope_hs = d.slot(); e.rope_wa = wa; }
+    if (d.rope_grid > 0) { e.rope_table = d.rope_table; e.rope_pos = d.pos; e.rope_S = S; e.rope_grid = d.rope_grid; e.rope_Dh = d.Dh; e.rope_hs = d.slot(); e.rope_wa = wa; e.rope_rows = d.rope_rows; }
     RC(gemm_nt(L.ln1, w, L.wqkv, w, M, 3 * wa, w, e, st));
   }
   if (d.attn_fp8 && d.slot() != 64) { set_error("layer_fwd: the fp8 attention forward is built for 64-wide head slots (head_dim %d)", d.Dh); return SMBV_ERR_SHAPE; }
@@ -300,7 +300,7 @@ int layer_bwd_core(const BlockPtrs& p, const BlockPtrs& gr, LayerWs& L, const Bl
   }
   // ---- attention (dQ exists only for the ranged queries; dK/dV for every token) ----
   RopeBwd rope;
-  rope.table = d.rope_table; rope.pos = d.pos; rope.grid = d.rope_grid; rope.Dh = d.Dh;
+  rope.table = d.rope_table; rope.pos = d.pos; rope.grid = d.rope_grid; rope.Dh = d.Dh; rope.rows = d.rope_rows;
   if (ranged) HIPRC(hipMemsetAsync(bf.d_qkv, 0, (size_t)M * 3 * wa * sizeof(bf16_t), st));
   RC(attention_bwd(L.qkv, L.qkv + wa, L.qkv + 2 * wa, 3 * wa, L.attn_o, sc.d_o, wa, L.lse, sc.delta, bf.d_qkv, bf.d_qkv + wa, bf.d_qkv + 2 * wa, 3 * wa, B,
                    S, H, d.slot(), d.scale(), delta_fused ? 6 : 7, Sq, qoff, st, L.attn_o_lo, (d.attn_fp8 & 2) && d.slot() == 64 ? sc.f8ws : nullptr, sc.f8ws_bytes, sc.attn_split, sc.attn_split_bytes,

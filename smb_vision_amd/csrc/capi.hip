@@ -92,7 +92,7 @@ int smbv_gemm_nt_rope(const smbv_bf16* A, int lda, const smbv_bf16* B, int ldb, 
                       smbv_stream stream) {
   if (!A || !B || !epi || !epi->out_bf16 || !rope || !rope->table) { set_error("smbv_gemm_nt_rope: null operand / no bf16 output / no table"); return SMBV_ERR_ARG; }
   GemmEpi e = to_epi(epi);
-  e.rope_table = rope->table; e.rope_pos = rope->pos; e.rope_S = rope->S; e.rope_grid = rope->grid; e.rope_Dh = rope->Dh; e.rope_hs = rope->head_stride; e.rope_wa = wa;
+  e.rope_table = rope->table; e.rope_pos = rope->pos; e.rope_S = rope->S; e.rope_grid = rope->grid; e.rope_Dh = rope->Dh; e.rope_hs = rope->head_stride; e.rope_wa = wa; e.rope_rows = rope->table_rows;
   return gemm_nt(A, lda, B, ldb, M, N, K, e, (hipStream_t)stream);
 }
 int smbv_gemm_tn(const smbv_bf16* X, int ldx, const smbv_bf16* Y, int ldy, int M, int N1, int N2, float* out, void* ws, size_t ws_bytes, smbv_stream stream) {
@@ -200,7 +200,7 @@ int smbv_attention_bwd_rope(const smbv_bf16* Q, const smbv_bf16* K, const smbv_b
   }
   SMBV_CHECK_DEVICE_STATE();
   RopeBwd rb;
-  rb.table = rope->table; rb.pos = rope->pos; rb.grid = rope->grid; rb.Dh = rope->Dh;
+  rb.table = rope->table; rb.pos = rope->pos; rb.grid = rope->grid; rb.Dh = rope->Dh; rb.rows = rope->table_rows;
   return attention_bwd(Q, K, V, ld, O, dO, ldo, LSE, delta, dQ, dK, dV, ldd, B, S, H, Dh, scale, parts, Sq, q_off, (hipStream_t)stream, O_lo, fp8_ws, fp8_ws_bytes, ws, ws_bytes, &rb);
 }
 

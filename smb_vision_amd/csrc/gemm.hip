@@ -377,7 +377,15 @@ int gemm_nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, in
       set_error("gemm_nt: rotary epilogue needs a plain bf16 product with q | k sections of whole head slots (wa=%d hs=%d Dh=%d N=%d)", e.rope_wa, e.rope_hs, e.rope_Dh, N);
       return SMBV_ERR_ARG;
     }
-    const bool fused = seg > 0 && ring_shape && gemm_nt_ring_ok(lda, ldb, M, N, K, e) && !(g_variant & (256 | 262144)) && !(g_ab & 8);
+    RopeGeo geo;
+    const bool fused = seg > 0 && rope_geo(geo, e.rope_grid, e.rope_Dh, e.rope_rows) && e.rope_rows * seg <= 1024 /* two table floats per thread */ &&
+                       (e.rope_pos || rope_geo_rows(geo, M, e.rope_S)) && ring_shape && gemm_nt_ring_ok(lda, ldb, M, N, K, e) &&
+                       !(g_variant & (256 | 262144 | 512)) && !(g_ab & 8);
+    if (fused) {
+      GemmEpi ee = e;
+      ee.rope_geo = geo;
+      return gemm_nt_ring(A, lda, B, ldb, M, N, K, ee, 3, st, (g_variant >> 20) & 15);
+    }
     if (!fused) {
       GemmEpi plain = e;
       plain.rope_table = nullptr;

@@ -26,13 +26,17 @@ unsigned* device_status_word_dev();
 
 static constexpr int RBM = 256, RBN = 128, RBK = 32;
 static constexpr int RSLOT = (RBM + RBN) * RBK * 2;  // 24 KiB
+static constexpr int ROPE_LDS_TABLE_FLOATS = 1024;  // EPI 3: the cos | sin table (two floats per thread) in front of the tile's decoded token rows, in the idle ring
+// what a thread of an EPI 3 block fetches BEFORE the main loop and parks in registers (the loads' latency is the main loop's): its two floats of the table, and -
+// threads 0..255 - one token of the tile decoded into its three table rows.  After the loop they go to LDS between two barriers, no memory access in between
+struct RopeRegs { float t0 = 0.f, t1 = 0.f; int p = 0; };   // (p: the token's position id, decoded after the loop - nothing in front of the loop waits for a load)
 
 // Four output rows (one register index r each) of one lane: v[r] are columns n .. n+3 of row m[r].  Loads of all four rows are issued
 // before the first use so that they are in flight together; rows past M are clamped for the loads and masked for the stores.
 // EPI: 0 plain (bias / row addend / outputs), 1 + GELU (saving the pre-activation), 2 + dGELU multiplier, 3 + rotary embedding of the q | k sections -
 // compiled separately to bound registers
 template <int EPI>
-__device__ __forceinline__ void epi_rows4(const GemmEpi& e, const int (&m)[4], const int M, const int n, f32x4 (&v)[4], const f32x4 bias) {
+__device__ __forceinline__ void epi_rows4(const GemmEpi& e, const int (&m)[4], const int M, const int n, f32x4 (&v)[4], const f32x4 bias, const float* rope_lds = nullptr) {
   int mc[4];
   unsigned orow[4];  // 32-bit element offsets throughout (gemm_nt_ring_ok bounds every operand below 2^30 elements): base pointer in SGPRs + one VGPR
 #pragma unroll
@@ -41,11 +45,11 @@ __device__ __forceinline__ void epi_rows4(const GemmEpi& e, const int (&m)[4], c
     orow[r] = (unsigned)mc[r];
     v[r] = v[r] * e.alpha + bias;
   }
-  if (e.grp_in > 0) {
+  if constexpr (EPI != 3) if (e.grp_in > 0) {   // (EPI 3 is a plain bias + bf16 product: gemm_nt refuses the rest)
 #pragma unroll
     for (int r = 0; r < 4; r++) orow[r] = (unsigned)((mc[r] / e.grp_in) * e.grp_out + (mc[r] % e.grp_in));
   }
-  if (e.rowadd) {
+  if constexpr (EPI != 3) if (e.rowadd) {
     unsigned rr[4];
     if (e.rowidx) {
 #pragma unroll
@@ -86,18 +90,28 @@ __device__ __forceinline__ void epi_rows4(const GemmEpi& e, const int (&m)[4], c
     }
   }
   if constexpr (EPI == 3) {   // rotary embedding of the q | k sections (GemmEpi::rope_*): on the bf16-rounded product, as the stand-alone kernel read it
-    const int seg = 2 * ((e.rope_Dh / 3) / 2);
+    const int seg = e.rope_geo.seg;
     const bool in_section = n < 2 * e.rope_wa;
-    const RopeLane rl = rope_lane((n % e.rope_wa) % e.rope_hs, seg, in_section);
+    const RopeLane rl = rope_lane((n % e.rope_wa) % e.rope_hs, seg, in_section);   // (per lane, once per tile)
     if (rl.on[0] | rl.on[1]) {
-      int p[4];
+      // the tile's 256 tokens were decoded once, by 256 threads, into table-row offsets [3 axes][256 rows] behind the table (ring_epilogue): a lane reads the
+      // two axes its pairs turn on - no position load, no decode, in the per-row chain
+      const int* trow = (const int*)(rope_lds + ROPE_LDS_TABLE_FLOATS);
+      RopeLane rq = rl;
+      rq.axis[0] = 0; rq.axis[1] = 1;     // (rope_apply4 selects row[axis]: slots 0 / 1 are filled with what this lane's two pairs need)
+      RopeTok tk[4];
 #pragma unroll
-      for (int r = 0; r < 4; r++) p[r] = e.rope_pos ? e.rope_pos[mc[r]] : mc[r] % e.rope_S;
+      for (int r = 0; r < 4; r++) {
+        const int lr = m[r] & (RBM - 1);   // row inside the tile (tiles start at multiples of RBM)
+        tk[r].row[0] = trow[rl.axis[0] * RBM + lr];
+        tk[r].row[1] = trow[rl.axis[1] * RBM + lr];
+        tk[r].row[2] = 0;
+      }
 #pragma unroll
-      for (int r = 0; r < 4; r++) rope_round_apply4(v[r], rl, rope_tok(p[r], e.rope_grid, seg), seg, e.rope_table, false);
+      for (int r = 0; r < 4; r++) rope_round_apply4(v[r], rq, tk[r], seg, rope_lds, false);
     }
   }
-  if (e.out_f32) {
+  if constexpr (EPI != 3) if (e.out_f32) {
 #pragma unroll
     for (int r = 0; r < 4; r++)
       if (m[r] < M) *(f32x4*)(e.out_f32 + (orow[r] * (unsigned)e.ld_of + (unsigned)n)) = v[r];
@@ -113,8 +127,20 @@ __device__ __forceinline__ void epi_rows4(const GemmEpi& e, const int (&m)[4], c
 
 // epilogue shared by the ring kernels: register r of acc[i][j] is row 64 wm + 16 i + 4 (l >> 4) + r, column 64 wn + 4 (l & 15) + j
 template <int EPI>
-__device__ __forceinline__ void ring_epilogue(const f32x4 (&acc)[4][4], const GemmEpi& e_in, int m0, int n0, int wm, int wn, int l, int M) {
+__device__ __forceinline__ void ring_epilogue(const f32x4 (&acc)[4][4], const GemmEpi& e_in, int m0, int n0, int wm, int wn, int l, int M, unsigned char* smem = nullptr,
+                                              const RopeRegs rr = RopeRegs()) {
   const GemmEpi e = e_in;
+  if constexpr (EPI == 3) {   // the cos | sin table goes into the (now idle) ring: 16 tokens x 8 angles per lane come out of LDS instead of as L1 gathers
+    __syncthreads();          // every wave is past its last slice and has drained its run-off copies
+    float* ts = (float*)smem;
+    ts[threadIdx.x] = rr.t0; ts[512 + threadIdx.x] = rr.t1;
+    if (threadIdx.x < RBM) {  // one thread per token of the tile
+      int* trow = (int*)smem + ROPE_LDS_TABLE_FLOATS;
+      const RopeTok tk = rope_tok(rr.p, e.rope_geo);
+      trow[threadIdx.x] = tk.row[0]; trow[RBM + threadIdx.x] = tk.row[1]; trow[2 * RBM + threadIdx.x] = tk.row[2];
+    }
+    __syncthreads();
+  }
   const int n = n0 + 64 * wn + 4 * (l & 15);
   const int mb = m0 + 64 * wm + 4 * (l >> 4);
   f32x4 bias = {0.f, 0.f, 0.f, 0.f};
@@ -125,7 +151,7 @@ __device__ __forceinline__ void ring_epilogue(const f32x4 (&acc)[4][4], const Ge
     f32x4 v[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) v[r] = (f32x4){acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
-    epi_rows4<EPI>(e, m, M, n, v, bias);
+    epi_rows4<EPI>(e, m, M, n, v, bias, (const float*)smem);
     __builtin_amdgcn_sched_barrier(0);  // keep the next row group's loads from being hoisted up here (register budget of the 2-blocks-per-CU build)
   }
 }
@@ -197,6 +223,17 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_nt_ring_kernel(cons
   const int a_off = (64 * wm + fr) * 64 + pch;
   const int b_off = RBM * RBK * 2 + (64 * wn + fr) * 64 + pch;
 
+  RopeRegs rr;
+  if constexpr (EPI == 3) {   // (issued in front of the first copies: older than every piece the counted waits below count)
+    const int nf = e_in.rope_geo.rows * e_in.rope_geo.seg;   // <= 1024 (gemm_nt)
+    if (t < nf) rr.t0 = e_in.rope_table[t];
+    if (t + 512 < nf) rr.t1 = e_in.rope_table[t + 512];
+    if (t < RBM) {
+      const int m = min(m0 + t, M - 1);
+      rr.p = e_in.rope_geo.S > 0 ? rope_row_pos(m, e_in.rope_geo) : 0;   // (computed first: a register a pending load may still write would have to be waited for)
+      if (e_in.rope_pos) rr.p = e_in.rope_pos[m];
+    }
+  }
 #pragma unroll
   for (int s = 0; s < NS - 1; s++) stage(s);
   for (int s = 0; s < nks; s++) {
@@ -279,7 +316,7 @@ __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_nt_ring_kernel(cons
     __syncthreads();   // every wave holds its addends (the loads above were waited for by their uses) before the flag goes back to 0 for the next launch
     if (t == 0) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  ring_epilogue<EPI>(acc, e_in, m0, n0, wm, wn, l, M);
+  ring_epilogue<EPI>(acc, e_in, m0, n0, wm, wn, l, M, smem, rr);
 }
 
 // The same tile with 64-deep K slices: rows of 128 B, so every copy request is a whole cache line (the 32-deep slices above ask L2 for 64-B

@@ -60,7 +60,7 @@ __device__ __forceinline__ RopeLane rope_lane(int e0, int seg, bool in_section) 
     const int e = e0 + 2 * j;
     r.on[j] = in_section && e < 3 * seg;
     const int ax = (e >= seg ? 1 : 0) + (e >= 2 * seg ? 1 : 0);
-    const int t0 = e - ax * seg, t1 = t0 + 1;   // (seg is even and e is even: t1 < seg)
+    const int t0 = r.on[j] ? e - ax * seg : 0, t1 = t0 + 1;   // (seg is even and e is even: t1 < seg; a pair outside the width gets valid indices it will not use)
     r.axis[j] = ax;
     r.i0[j] = t0 >= half ? t0 - half : t0;
     r.i1[j] = t1 >= half ? t1 - half : t1;
@@ -74,16 +74,54 @@ __device__ __forceinline__ RopeTok rope_tok(int p, int grid, int seg) {
   const int frame = p / tpf, rem = p - tpf * frame, height = rem / grid, width = rem - grid * height;
   return RopeTok{{frame * seg, height * seg, width * seg}};
 }
+// the same without integer division, for the fused forms (16 tokens per lane in a GEMM epilogue: two divisions per token were a third of that epilogue):
+// m = ceil(2^32 / d), q = umulhi(p, m) is exact while p * d < 2^32 (rope_geo checks it on the host against the table's row count)
+struct RopeGeo {
+  int grid = 0, seg = 0, rows = 0;        // rows: positions the table covers per axis (the table is staged into LDS: rows * seg floats)
+  unsigned m_tpf = 0, m_grid = 0;
+  int S = 0; unsigned m_S = 0;            // row -> position inside its sequence, for callers without position ids (rope_geo_rows)
+};
+__device__ __forceinline__ int rope_row_pos(int m, const RopeGeo& g) { return g.S == 1 ? 0 : m - (int)__umulhi((unsigned)m, g.m_S) * g.S; }
+__device__ __forceinline__ RopeTok rope_tok(int p, const RopeGeo& g) {
+  const unsigned up = (unsigned)p, tpf = (unsigned)(g.grid * g.grid);
+  const unsigned frame = g.grid == 1 ? up : __umulhi(up, g.m_tpf), rem = up - frame * tpf;
+  const unsigned height = g.grid == 1 ? rem : __umulhi(rem, g.m_grid), width = rem - height * (unsigned)g.grid;
+  return RopeTok{{(int)frame * g.seg, (int)height * g.seg, (int)width * g.seg}};
+}
+static inline bool rope_geo(RopeGeo& g, int grid, int Dh, int table_rows) {   // false: the fused forms cannot take this map (the stand-alone launch can)
+  g.grid = grid; g.seg = 2 * ((Dh / 3) / 2); g.rows = table_rows;
+  const unsigned long long tpf = (unsigned long long)grid * grid;
+  if (grid <= 0 || g.seg <= 0 || table_rows <= 0 || (size_t)table_rows * g.seg * sizeof(float) > 32768 || tpf * tpf * (unsigned long long)table_rows >= (1ull << 32)) return false;
+  g.m_tpf = tpf > 1 ? (unsigned)(((1ull << 32) + tpf - 1) / tpf) : 0;
+  g.m_grid = grid > 1 ? (unsigned)(((1ull << 32) + grid - 1) / grid) : 0;
+  return true;
+}
+static inline bool rope_geo_rows(RopeGeo& g, long rows, int S) {   // row % S by multiplication: exact while rows * S < 2^32
+  if (S <= 0 || (unsigned long long)rows * (unsigned long long)S >= (1ull << 32)) return false;
+  g.S = S; g.m_S = S > 1 ? (unsigned)(((1ull << 32) + S - 1) / S) : 0;
+  return true;
+}
+// block-cooperative copy of the table into LDS (the caller brackets it with barriers)
+__device__ __forceinline__ void rope_stage_table(float* lds, const float* __restrict__ table, const RopeGeo& g, int tid, int nthreads) {
+  const int nf = g.rows * g.seg;
+  for (int i = tid; i < nf; i += nthreads) lds[i] = table[i];
+}
 // the map (or its transpose) on 4 consecutive elements of one token, already rounded to bf16 where the stand-alone kernel would have read bf16
 __device__ __forceinline__ void rope_apply4(f32x4& v, const RopeLane& rl, const RopeTok& tk, int seg, const float* __restrict__ table, bool transpose) {
+  // branch-free (a pair outside the rotated width reads valid angles - rope_lane clamps - and keeps its values): the reads of all pairs and of the caller's
+  // other tokens issue back to back instead of one exec-masked block with its own wait per pair
   const int half = seg >> 1;
+  float c0[2], s0[2], c1[2], s1[2];
 #pragma unroll
   for (int j = 0; j < 2; j++) {
-    if (!rl.on[j]) continue;
     const float* tb = table + (rl.axis[j] == 0 ? tk.row[0] : (rl.axis[j] == 1 ? tk.row[1] : tk.row[2]));
+    c0[j] = tb[rl.i0[j]]; s0[j] = tb[half + rl.i0[j]]; c1[j] = tb[rl.i1[j]]; s1[j] = tb[half + rl.i1[j]];
+  }
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
     float y0, y1;
-    rope_pair(v[2 * j], v[2 * j + 1], tb[rl.i0[j]], tb[half + rl.i0[j]], tb[rl.i1[j]], tb[half + rl.i1[j]], transpose, y0, y1);
-    v[2 * j] = y0; v[2 * j + 1] = y1;
+    rope_pair(v[2 * j], v[2 * j + 1], c0[j], s0[j], c1[j], s1[j], transpose, y0, y1);
+    v[2 * j] = rl.on[j] ? y0 : v[2 * j]; v[2 * j + 1] = rl.on[j] ? y1 : v[2 * j + 1];
   }
 }
 // round to bf16, apply, ready for the final pack (what "rope3d on the stored bf16 matrix" computes)
@@ -96,7 +134,7 @@ __device__ __forceinline__ void rope_round_apply4(f32x4& v, const RopeLane& rl, 
 struct RopeStore {
   const float* table = nullptr;
   const int* pos = nullptr;   // token position ids by row of the [B * S] token matrix (null: the token's index inside its sequence)
-  int grid = 0, seg = 0;
+  RopeGeo geo;
 };
 
 // transposed LDS read (verified by tools/probe/hw_probe.hip): per 16-lane group a 4x16 block of 16-bit

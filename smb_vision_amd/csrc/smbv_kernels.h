@@ -47,6 +47,8 @@ struct GemmEpi {
   const float* rope_table = nullptr;   // fp32 [P][2][seg / 2] cos | sin
   const int* rope_pos = nullptr;       // token position ids [M] (null: m % rope_S)
   int rope_S = 0, rope_grid = 0, rope_Dh = 0, rope_hs = 0, rope_wa = 0;
+  int rope_rows = 0;                   // positions per axis the table covers (0: unknown - the map then runs as the launch behind the product)
+  RopeGeo rope_geo;                    // (filled in by gemm_nt)
 };
 // split-K form of the ring kernel: is it the selection for this product, and what it needs
 bool gemm_nt_splitk_wanted(int lda, int ldb, int M, int N, int K, const GemmEpi& e);
@@ -105,6 +107,7 @@ struct RopeBwd {
   const float* table = nullptr;
   const int* pos = nullptr;   // position ids by row of the [B * S] token matrix; null: the token's index in its sequence
   int grid = 0, Dh = 0;
+  int rows = 0;               // positions per axis the table covers (0: unknown - the map then runs as a launch behind the kernels)
 };
 int attention_bwd(const bf16_t* Q, const bf16_t* K, const bf16_t* V, int ld, const bf16_t* O, const bf16_t* dO, int ldo, const float* LSE,
                   float* delta, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int ldd, int B, int S, int H, int Dh, float scale, int parts, int Sq, int qoff, hipStream_t st,

@@ -31,6 +31,7 @@ struct VjepaWs {
 static BlockDims venc_dims(const smbv_vjepa_cfg& c, const smbv_vjepa_io* io) {
   BlockDims d; d.rows = (size_t)c.B * c.N; d.w = c.d; d.ff = c.ff; d.B = c.B; d.S = c.N; d.H = c.heads; d.Dh = c.d / c.heads; d.eps = c.ln_eps;
   d.o_resid = c.attn_o_resid; d.rope_grid = c.W / c.ps; d.pos = io ? io->enc_pos : nullptr; d.rope_table = io ? io->rope_enc : nullptr;
+  d.rope_rows = std::max(c.T / c.ts, std::max(c.H / c.ps, c.W / c.ps));   // every frame / height / width id is below it (include/smbv.h: the table covers them)
   return d;
 }
 static inline int vmasks(const smbv_vjepa_cfg& c) { return c.n_masks > 1 ? c.n_masks : 1; }
@@ -43,6 +44,7 @@ static BlockDims vpred_dims(const smbv_vjepa_cfg& c, const smbv_vjepa_io* io) {
   const int Sp = c.Nctx + c.Ntgt;
   BlockDims d; d.rows = (size_t)vpb(c) * Sp; d.w = c.pd; d.ff = c.pff; d.B = vpb(c); d.S = Sp; d.H = c.pheads; d.Dh = c.pd / c.pheads; d.eps = c.ln_eps;
   d.o_resid = c.attn_o_resid; d.rope_grid = c.W / c.ps; d.pos = io ? io->pred_pos : nullptr; d.rope_table = io ? io->rope_pred : nullptr;
+  d.rope_rows = std::max(c.T / c.ts, std::max(c.H / c.ps, c.W / c.ps));
   return d;
 }
 static BlockPtrs vblock(const smbv_block_ptrs& p) {

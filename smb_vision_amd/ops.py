@@ -73,15 +73,17 @@ def gemm_nt(A, B, *, bias=None, rowadd=None, rowidx=None, gelu=False, save_pre=F
     return res
 
 
-def rope_cfg(table, pos, S, grid, Dh, head_stride):
-    """smbv_rope3d_cfg over live tensors (the caller keeps them alive for the call)."""
+def rope_cfg(table, pos, S, grid, Dh, head_stride, table_rows=None):
+    """smbv_rope3d_cfg over live tensors (the caller keeps them alive for the call).  table_rows: default the table's extent; 0 = "unknown" (the map then
+    runs as the stand-alone launch)."""
     rc = _lib.Rope3dCfg()
     rc.table, rc.pos, rc.S, rc.grid, rc.Dh, rc.head_stride = table.data_ptr(), (pos.data_ptr() if pos is not None else None), S, grid, Dh, head_stride
+    rc.table_rows = table.shape[0] if table_rows is None else table_rows
     return rc
 
 
 def rope3d_(qkv, wa, H, rope, transpose=False):
-    """smbv_rope3d in place on the q | k sections of qkv [rows, ld] (rope: the dict gemm_nt takes, wa ignored)."""
+    """smbv_rope3d in place on the q | k sections of qkv [rows, ld] (rope: the dict gemm_nt takes, wa / table_rows ignored)."""
     lib = _lib.load()
     check(lib.smbv_rope3d(_p(qkv), qkv.stride(0), wa, qkv.shape[0], rope["S"], H, rope["head_stride"], rope["Dh"], rope["grid"],
                           (rope["pos"].data_ptr() if rope["pos"] is not None else None), rope["table"].data_ptr(), int(transpose), _stream()), "smbv_rope3d")

@@ -89,6 +89,8 @@ def test_qkv_product_with_rotary_epilogue_is_the_two_launches_bitwise(M, w, H, D
     ops.rope3d_(two, wa, H, rope)
     torch.cuda.synchronize()
     assert torch.equal(fused, two)
+    unknown = ops.gemm_nt(A, Wt, bias=bias, rope=dict(rope, table_rows=0))["bf16"]   # a table of unknown extent is not staged into LDS: the two launches
+    assert torch.equal(unknown, two)
     assert not torch.equal(fused[:, :2 * wa], plain[:, :2 * wa]) and torch.equal(fused[:, 2 * wa:], plain[:, 2 * wa:])   # q | k rotated, v untouched
     from smb_vision_amd._lib import SmbvError
     with pytest.raises(SmbvError):   # an epilogue the rotary form does not combine with

@@ -1,8 +1,8 @@
 #!/bin/bash
-# round-5 A/B of the token split of the last grouped weight-gradient launch (SMBV_DEBUG_AB bit 4 = off): MIM step and V-JEPA step, interleaved, two passes
+# scratch: V-JEPA rotary fold - tests, A/B, fused profile
 set -e
-STEPS=30 tools/step_ab2.sh 0:0 4:0 | tee gpurun_out/r05v_ab.txt
-for PASS in 1 2; do for AB in 0 4; do
-  SMBV_DEBUG_AB=$AB python3 bench.py --vjepa --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-roofline --no-feed --no-trainer --no-extra-configs 2>/dev/null |
-    python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('pass $PASS vjepa ab $AB ms_per_step %.3f' % d['ms_per_step'])"
-done; done | tee -a gpurun_out/r05v_ab.txt
+timeout -k 10 600 python3 -m pytest tests/test_vjepa_gpu.py -m gpu -x -q > gpurun_out/r05z_tests.log 2>&1 || { tail -30 gpurun_out/r05z_tests.log; exit 1; }
+tail -1 gpurun_out/r05z_tests.log
+STEPS=16 tools/vjepa_ab2.sh 0 8 | tee gpurun_out/r05z_ab.txt
+tools/profile_vjepa.sh r05z_fused > gpurun_out/r05z_fused.log 2>&1
+grep -h "gemm_nt_ring_kernel<3, [03]\|rope3d" gpurun_out/r05z_fused_vjepa_kernel_by_shape.txt | head -12
