@@ -107,6 +107,7 @@ struct Carver {
 };
 
 extern int g_variant;  // debug hook, capi.hip (smbv_debug_set_variant)
+extern int g_ab;       // second A/B word: environment SMBV_DEBUG_AB (capi.hip)
 struct PrepList {
   std::vector<PrepJob> jobs;
   int tiles = 0;

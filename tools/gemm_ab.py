@@ -19,6 +19,10 @@ if len(sys.argv) > 2 and sys.argv[2] == "large":   # BASELINE config 5's model: 
     shapes = [(7168, 3072, 1024, {}), (7168, 1024, 1024, {}), (7168, 4096, 1024, dict(gelu=True, save_pre=True)), (7168, 1024, 4096, {}), (7168, 4096, 1024, dict(dgelu=True)),
               (7168, 1024, 3072, {}), (20480, 1536, 512, {}), (20480, 512, 512, {}), (20480, 2048, 512, dict(gelu=True, save_pre=True)), (20480, 512, 2048, {}),
               (20480, 2048, 512, dict(dgelu=True)), (20480, 512, 1536, {}), (13312, 4096, 512, {}), (13312, 512, 4096, {}), (7168, 512, 1024, {})]
+if len(sys.argv) > 2 and sys.argv[2] == "vjepa":   # BASELINE config 4: ViT-base encoder over all 20,480 tokens, predictor 384 / 1536 over 20,480 rows
+    shapes = [(20480, 2304, 768, {}), (20480, 768, 768, {}), (20480, 3072, 768, dict(gelu=True, save_pre=True)), (20480, 768, 3072, {}), (20480, 3072, 768, dict(dgelu=True)),
+              (20480, 768, 2304, {}), (20480, 1152, 384, {}), (20480, 384, 384, {}), (20480, 1536, 384, dict(gelu=True, save_pre=True)), (20480, 384, 1536, {}),
+              (20480, 1536, 384, dict(dgelu=True)), (20480, 384, 1152, {}), (20480, 384, 768, {}), (12222, 768, 384, {})]
 g = torch.Generator(device="cuda").manual_seed(0)
 for M, N, K, kw in shapes:
     A = torch.randn(M, K, generator=g, device="cuda").bfloat16()
