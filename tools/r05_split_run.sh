@@ -1,8 +1,6 @@
 #!/bin/bash
-# scratch: V-JEPA rotary fold - tests, A/B, fused profile
+# scratch: head / encoder_to_decoder weight gradients on the side stream - step + DP tests, then the A/B (SMBV_DEBUG_AB bit 16 = on the caller's stream)
 set -e
-timeout -k 10 600 python3 -m pytest tests/test_vjepa_gpu.py -m gpu -x -q > gpurun_out/r05z_tests.log 2>&1 || { tail -30 gpurun_out/r05z_tests.log; exit 1; }
-tail -1 gpurun_out/r05z_tests.log
-STEPS=16 tools/vjepa_ab2.sh 0 8 | tee gpurun_out/r05z_ab.txt
-tools/profile_vjepa.sh r05z_fused > gpurun_out/r05z_fused.log 2>&1
-grep -h "gemm_nt_ring_kernel<3, [03]\|rope3d" gpurun_out/r05z_fused_vjepa_kernel_by_shape.txt | head -12
+timeout -k 10 800 python3 -m pytest tests/test_mim_step_gpu.py tests/test_accum_dp_gpu.py tests/test_step_sweep_gpu.py -m gpu -x -q > gpurun_out/r05aa_tests.log 2>&1 || { tail -30 gpurun_out/r05aa_tests.log; exit 1; }
+tail -1 gpurun_out/r05aa_tests.log
+STEPS=30 tools/step_ab2.sh 0:0 16:0 | tee gpurun_out/r05aa_ab.txt
