@@ -925,9 +925,10 @@ __device__ __forceinline__ void attn_dq_fp8_block(const Fp8BwdOps f8, const bf16
   // One 64-key tile out of ring slot `slot` (a literal: the loop below is unrolled over the ring, so every LDS read is a per-lane base hoisted out of the
   // loop plus an immediate - with the slot computed from kt the loop carried ~45 address adds per tile next to its 80 exponentials / multiplies / converts,
   // in a block that is vector-issue bound)
-  auto tile = [&](int kt, auto slotc) __attribute__((always_inline)) {
-    constexpr int slot = decltype(slotc)::value;
-    const unsigned char* sb = smem + slot * SLOT;
+  // `tail`: a literal at every call site.  Only the sequence's LAST tile can hold keys past its end, and only when S is not a multiple of 64: that tile runs
+  // as a copy of its own behind the loop.  (Round 5: the test `kt == nt - 1 && (S & 63)` inside the one body had been if-converted - 32 compares and 32
+  // selects per tile, a quarter of the vector instructions of a block that is vector-issue bound, for a mask that 319 of 320 tiles cannot need.)
+  auto tile_at = [&](int kt, const unsigned char* sb, const bool tail) __attribute__((always_inline)) {
     const unsigned char* scb = sb + 8192;
     const unsigned char* kimg = sb + 8448;
     // both sub-tiles' fp8 products first: the exponentials / multiplies / converts of sub-tile 0 then run under sub-tile 1's MFMAs, and sub-tile 0's dQ
@@ -951,7 +952,7 @@ __device__ __forceinline__ void attn_dq_fp8_block(const Fp8BwdOps f8, const bf16
     for (int tt = 0; tt < 2; tt++) {
 #pragma unroll
       for (int i = 0; i < 16; i++) dp[tt][i] *= fast_exp2(sx[tt][i]);
-      if (kt == nt - 1 && (S & 63)) {  // keys past the end of the sequence: their e4m3 rows are whatever follows in the workspace
+      if (tail) {  // keys past the end of the sequence: their e4m3 rows are whatever follows in the workspace
 #pragma unroll
         for (int i = 0; i < 16; i++) {
           const int key = kt * 64 + 32 * tt + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -978,26 +979,33 @@ __device__ __forceinline__ void attn_dq_fp8_block(const Fp8BwdOps f8, const bf16
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile kt have returned before it can reach the next barrier
   };
+  auto tile = [&](int kt, auto slotc) __attribute__((always_inline)) { tile_at(kt, smem + decltype(slotc)::value * SLOT, false); };
   // this wave's five copies of tile kt have landed (tile kt + 1's may still fly); the barrier publishes the tile and retires everybody's reads of tile
   // kt - 1, whose slot tile kt + 2 now takes (past the end the K8 / V8 / scale copies read unused bytes of the workspace, the bf16 copies zeros: never used)
   auto landed = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
+  const bool masked_last = (S & 63) && kt_end == nt;          // this block's range ends with the sequence's ragged last tile
+  const int kt_stop = masked_last ? kt_end - 1 : kt_end;      // tiles [kt_first, kt_stop): every key inside the sequence
   stage(kt_first, 0);
   stage(kt_first + 1, 1);
-  for (int kt = kt_first; kt < kt_end; kt += 3) {
+  for (int kt = kt_first; kt < kt_stop; kt += 3) {
     landed();
     stage(kt + 2, 2);
     tile(kt, std::integral_constant<int, 0>{});
-    if (kt + 1 >= kt_end) break;
+    if (kt + 1 >= kt_stop) break;
     landed();
     stage(kt + 3, 0);
     tile(kt + 1, std::integral_constant<int, 1>{});
-    if (kt + 2 >= kt_end) break;
+    if (kt + 2 >= kt_stop) break;
     landed();
     stage(kt + 4, 1);
     tile(kt + 2, std::integral_constant<int, 2>{});
+  }
+  if (masked_last) {   // (its copies and tile kt_stop + 1's were issued by the iterations above or the prologue: the same "five may still fly" count)
+    landed();
+    tile_at(kt_stop, smem + ((kt_stop - kt_first) % 3) * SLOT, true);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
   if (sp.part >= 0) {   // half a sweep: dQ^T as 8 pieces of 16 bytes per lane (the layout of the 16x16x32 block's hand-off: same scratch size)
