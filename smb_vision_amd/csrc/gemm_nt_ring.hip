@@ -173,9 +173,12 @@ __device__ void splitk_fault(unsigned* status) {
 // fix - run-to-run identical.  A consumer waits only for a producer and producers wait for nothing: no cycle; the producers are the LOWER block ids,
 // dispatched first.  The flag is cleared by its consumer; the step zeroes the flag words once per forward (a zero-fill job of the weight-preparation
 // launch), a spin that outlasts ~1 s raises the device status word (smbv_device_status 0x6001) and ends.
-template <int NS, int EPI, int KS>
+// ABL: the ablation hooks of tools/gemm_ablate.py (dbg bits: 1 no epilogue traffic, 2 no copies, 4 no MFMAs, 8 no LDS reads) - a build of their own: as tests of
+// a run-time argument they sat in the K loop of the product kernel as five taken branches per slice
+template <int NS, int EPI, int KS, bool ABL = false>
 __global__ __launch_bounds__(512, NS == 3 ? 4 : 2) void gemm_nt_ring_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
-                                                                          int M, int N, int K, int tiles_m, int tiles_n, GemmEpi e_in, int dbg, unsigned* status) {
+                                                                          int M, int N, int K, int tiles_m, int tiles_n, GemmEpi e_in, int dbg_arg, unsigned* status) {
+  const int dbg = ABL ? dbg_arg : 0;
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * RSLOT];
   const int t = threadIdx.x, l = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -418,6 +421,12 @@ static void launch_ring(const bf16_t* A, int lda, const bf16_t* B, int ldb, int 
   const int tm = cdiv(M, RBM), tn = N / RBN;
   const dim3 grid(tm * tn), block(512);
   unsigned* nostatus = nullptr;
+  if (dbg && NS == 3 && !e.rope_table) {   // tools/gemm_ablate.py
+    if (e.act_gelu) hipLaunchKernelGGL((gemm_nt_ring_kernel<3, 1, 1, true>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg, nostatus);
+    else if (e.dgelu_pre) hipLaunchKernelGGL((gemm_nt_ring_kernel<3, 2, 1, true>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg, nostatus);
+    else hipLaunchKernelGGL((gemm_nt_ring_kernel<3, 0, 1, true>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg, nostatus);
+    return;
+  }
   if (e.rope_table) hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 3, 1>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg, nostatus);
   else if (e.act_gelu) hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 1, 1>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg, nostatus);
   else if (e.dgelu_pre) hipLaunchKernelGGL((gemm_nt_ring_kernel<NS, 2, 1>), grid, block, 0, st, A, lda, B, ldb, M, N, K, tm, tn, e, dbg, nostatus);
