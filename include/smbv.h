@@ -69,14 +69,20 @@ int smbv_last_error(char* buf, size_t len);               /* copies the thread's
 void smbv_debug_set_variant(int bits);
 /* (A second A/B word, for tools only, is read ONCE from the environment variable SMBV_DEBUG_AB when the library is loaded - csrc/capi.hip lists its bits; unset
  * / 0 on the product path.) */
-/* The device's sticky status (ABI 3000).  A kernel that detects a fault it cannot return - today: the attention backward's block scheduler finding a
- * scheduling word of another launch (0x5001 / 0x5003) or both of its tile queues exhausted (0x5002: a tile was skipped) - stores a code into 4 bytes of
- * host-mapped memory; every smbv_*_forward / _backward / smbv_attention_bwd call on that device then returns SMBV_ERR_STATE instead of enqueueing more
- * work on top of incomplete gradients.  This function reads it without synchronising (a fault shows once its kernel has run): 0, or SMBV_ERR_STATE with
- * the code in smbv_last_error(); clear != 0 resets it.  Never set on a healthy run. */
+/* The device's sticky status (ABI 3000).  A kernel that detects a fault it cannot return - the attention backward's block scheduler finding a
+ * scheduling word of another launch (0x5001 / 0x5003) or both of its tile queues exhausted (0x5002: a tile was skipped), a consumer half of a split
+ * launch that outwaited its producer (0x5004: attention split sweeps, split grouped weight gradients, split-K product), a block of the split
+ * weight-gradient launch that drew a ticket outside its launch's run (0x5005) - stores a code into 4 bytes of host-mapped memory; every
+ * smbv_*_forward / _backward / smbv_attention_bwd call on that device then returns SMBV_ERR_STATE instead of enqueueing more work on top of incomplete
+ * gradients.  This function reads it without synchronising (a fault shows once its kernel has run): 0, or SMBV_ERR_STATE with the code in
+ * smbv_last_error(); clear != 0 resets the WORD.  The scheduling state a faulted launch left behind (tile queues, tickets, hand-off flags) is put back
+ * by smbv_debug_pair_state(0, stream) - recover with both, in that order, after the stream has drained.  Hand-off flags are stamped with their launch's
+ * epoch / sequence number, so even without the reset a word of a faulted launch is never taken for a later launch's.  Never set on a healthy run. */
 int smbv_device_status(int clear);
-/* Test hook for the above (NOT the product path): op 1 dirties the attention backward's scheduling slots on `stream` the way a second launch sharing a
- * slot would, op 0 restores them (and the host's launch epochs) to their load-time state. */
+/* Test / recovery hook for the above: op 0 restores every scheduling slot of the current device - attention backward tile queues, per-CU tickets and
+ * split-sweep flags, the split weight-gradient launch's tickets and flags - and the host's launch epochs to their load-time state (enqueued on `stream`; the
+ * device must be idle otherwise).  NOT the product path: op 1 dirties the slots the way a second launch sharing a slot would (attention key-owner queue
+ * + 3, weight-gradient ticket + 3); op 2 + 4 e leaves every hand-off flag raised as an unfinished launch of epoch / sequence number e + 1 would. */
 int smbv_debug_pair_state(int op, smbv_stream stream);
 
 /* ---- per-op entry points (also what the parity tests call) ------------------------------------------------------ */

@@ -1063,7 +1063,9 @@ struct PairState {            // one slot of the library's device-side schedulin
   unsigned done;              // blocks of the running launch that have ended                      } a launch only accepts words stamped with ITS epoch
   unsigned pad[13];
   unsigned cu_ticket[2048];   // arrival counter per CU, indexed by (XCC id, SE id, SH id, CU id): 3 + 3 + 1 + 4 bits (parity only: roles, never results)
-  unsigned split_flag[2][PAIR_SPLIT_MAX];   // hand-off flags of the split sweeps (SweepPart): zero at module load, cleared again by every consumer
+  unsigned split_flag[2][PAIR_SPLIT_MAX];   // hand-off flags of the split sweeps (SweepPart): zero at module load, raised to (launch epoch + 1) by a producer, cleared again
+                                            // by its consumer.  A launch that faulted or ran short (0x5001 / 0x5002 blocks run no tile, a 0x5004 consumer gives up) leaves
+                                            // words behind: they carry THAT launch's epoch, and a later consumer only accepts its own
 };
 __device__ PairState g_pair_state[8];
 static constexpr unsigned PAIR_COUNT_MASK = 0xfffffu;
@@ -1133,6 +1135,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __r
       constexpr int KV_F4 = 8 * (DH / 32) * 256, Q_F4 = (DH / 8) * 256;
       sp.scratch = split_ws + (role ? (size_t)xk * KV_F4 + (size_t)js * Q_F4 : (size_t)js * KV_F4);
       sp.flag = &ps.split_flag[role][js];
+      sp.want = epoch + 1u;   // 1 .. 0x1000: never the idle 0, never another epoch's word
       sp.status = status;
     }
   }
@@ -1162,13 +1165,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair_kernel(const bf16_t* __r
 }
 
 // debug hooks (smbv_debug_pair_state, include/smbv.h): op 1 = dirty every slot's key-owner queue (what an overlapping second launch would do),
-// op 0 = every slot back to its module-load state
-__global__ void pair_state_debug_kernel(int op) {
+// op 2 = raise every hand-off flag of every slot the way producers of an unfinished launch of epoch `arg` would have left them,
+// op 0 = every slot back to its module-load state (hand-off flags included)
+__global__ void pair_state_debug_kernel(int op, unsigned arg) {
   const int slot = blockIdx.x;
   PairState& ps = g_pair_state[slot];
   if (op == 1) { if (threadIdx.x == 0) atomicAdd(&ps.head[0], 3u); return; }
+  if (op == 2) { for (int i = threadIdx.x; i < 2 * PAIR_SPLIT_MAX; i += 256) ps.split_flag[0][i] = (arg & 0xfffu) + 1u; return; }
   if (threadIdx.x == 0) { ps.head[0] = 0; ps.head[1] = 0; ps.done = 0; }
   for (int i = threadIdx.x; i < 2048; i += 256) ps.cu_ticket[i] = 0;
+  for (int i = threadIdx.x; i < 2 * PAIR_SPLIT_MAX; i += 256) ps.split_flag[0][i] = 0;
 }
 
 // Host side of the slots: per device, a slot belongs to the first stream that used it (at most 8 streams per device run the pair launch; further
@@ -1217,11 +1223,17 @@ static void pair_epoch_untake(int dev, int slot, unsigned e) {
   if (h.epoch[slot] == ((e + 1u) & 0xfffu)) h.epoch[slot] = e;
 }
 
+int tn_split_state_debug(int op, unsigned arg, hipStream_t st);   // gemm.hip: the split grouped weight-gradient launch keeps the same kind of state
+
 int pair_state_debug(int op, hipStream_t st) {
-  if (op != 0 && op != 1) { set_error("smbv_debug_pair_state: op %d (0 = reset, 1 = dirty)", op); return SMBV_ERR_ARG; }
-  hipLaunchKernelGGL(pair_state_debug_kernel, dim3(8), dim3(256), 0, st, op);
-  if (op == 0) pair_slot_for(nullptr, nullptr, true);   // the host's epochs restart with the slots
-  return check_launch("pair_state_debug");
+  // op 2 + 4 e (e = 0 .. 0xfff): stale hand-off flags of epoch e
+  const int base = op & 3;
+  if (op < 0 || base == 3 || (base != 2 && op != base)) { set_error("smbv_debug_pair_state: op %d (0 = reset, 1 = dirty the tile queues, 2 + 4 e = stale hand-off flags of epoch e)", op); return SMBV_ERR_ARG; }
+  hipLaunchKernelGGL(pair_state_debug_kernel, dim3(8), dim3(256), 0, st, base, (unsigned)(op >> 2));
+  if (base == 0) pair_slot_for(nullptr, nullptr, true);   // the host's epochs restart with the slots
+  const int rc = check_launch("pair_state_debug");
+  if (rc) return rc;
+  return tn_split_state_debug(base, (unsigned)(op >> 2), st);
 }
 
 // how many tiles of each role the pair launch runs as two half sweeps: 192 of each (in-box A/B at the step's shapes, profiles/r05_pair_split_ab.txt: 0 / 128 / 192 /

@@ -868,15 +868,27 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_256_kernel(const bf16_t* __res
 template <int TILE, bool SPLIT = false>
 __global__ __launch_bounds__(TILE == 256 ? 512 : 256, TILE == 256 ? 1 : 2) void gemm_tn_grouped_kernel(TnGroup g) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[TILE == 256 ? 4 * 2 * 32 * 512 : 2 * 2 * BK * 128 * 2];
-  // split launch (g.tiles > 0: twice as many blocks as tiles): block b < tiles reduces the FIRST half of tile b's token range and hands its fp32 tile to block
-  // tiles + b, which reduces the second half, adds and stores (the LAST grouped launch of a backward: nothing runs beside it, the optimizer waits for it)
+  // split launch (g.tiles > 0: twice as many blocks as tiles): unit u < tiles reduces the FIRST half of tile u's token range and hands its fp32 tile to unit
+  // tiles + u, which reduces the second half, adds and stores (the LAST grouped launch of a backward: nothing runs beside it, the optimizer waits for it).
+  // Units are claimed from a ticket, not read off blockIdx: a consumer unit is then only ever held by a block that started after every producer
+  // unit had been claimed by a RUNNING block - forward progress no longer rests on the order in which the dispatcher places workgroups.
   int unit = (int)blockIdx.x;
   SweepPart sp;
   if (SPLIT && g.tiles > 0) {
+    int* bc = (int*)smem;
+    if (threadIdx.x == 0) bc[0] = (int)(atomicAdd(g.ticket, 1u) - g.ticket0);
+    __syncthreads();
+    unit = bc[0];
+    __syncthreads();   // (read by every wave before the ring overwrites it)
+    if ((unsigned)unit >= 2u * (unsigned)g.tiles) {   // a counter another launch moved (two launches sharing a slot, a slot left dirty): no tile is run on a guess
+      if (threadIdx.x == 0 && g.status) __hip_atomic_store(g.status, 0x5005u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
     sp.part = unit >= g.tiles ? 1 : 0;
     unit -= sp.part * g.tiles;
     sp.scratch = g.scratch + (size_t)unit * (36 * 512);
     sp.flag = g.flags + unit;
+    sp.want = g.want;
     sp.status = g.status;
   }
   int j = 0;
@@ -984,19 +996,70 @@ static int tn_group_tile(const TnJob* jobs, int njobs) {  // 256, 128, or 0 = no
 }
 bool gemm_tn_grouped_ok(const TnJob* jobs, int njobs) { return tn_group_tile(jobs, njobs) != 0; }
 
-__device__ unsigned g_tn_split_flags[256];   // hand-off flags of the split grouped launch: zero at module load, cleared again by every consumer
-static unsigned* tn_split_flags_dev() {
-  static unsigned* base[64];
-  static std::mutex mu;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> lk(mu);
-  if (!base[dev]) {
-    void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tn_split_flags)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    base[dev] = (unsigned*)p;
+// Device-side state of the split grouped launch: eight slots per device, a slot OWNED by one stream (the first eight streams that run a split launch; a ninth
+// runs its launches whole), as the attention backward's pair launch keeps its queues.  `ticket` only ever counts up - a launch claims the run
+// [ticket0, ticket0 + 2 tiles) the host reserved for it - and a flag is raised to the launch's sequence number, so neither a word left behind by a launch that
+// faulted or gave up waiting (0x5004 / 0x5005) nor a launch of another stream is ever taken for this launch's.  smbv_debug_pair_state(0) restores it.
+static constexpr int TN_SPLIT_TILES_MAX = 128;
+struct TnSplitState { unsigned ticket; unsigned pad[63]; unsigned flag[TN_SPLIT_TILES_MAX]; };
+__device__ TnSplitState g_tn_split[8];
+struct TnSplitHost {
+  hipStream_t streams[8];
+  unsigned seq[8], base[8];
+  TnSplitState* dev = nullptr;
+  int n = 0;
+};
+static TnSplitHost g_tn_host[64];
+static std::mutex g_tn_mu;
+
+__global__ void tn_split_state_debug_kernel(int op, unsigned arg) {
+  TnSplitState& s = g_tn_split[blockIdx.x];
+  if (op == 1) { if (threadIdx.x == 0) atomicAdd(&s.ticket, 3u); return; }                                              // what a second launch sharing the slot would do
+  if (op == 2) { for (int i = threadIdx.x; i < TN_SPLIT_TILES_MAX; i += blockDim.x) s.flag[i] = arg + 1u; return; }     // flags a launch of sequence number arg + 1 never saw consumed
+  if (threadIdx.x == 0) s.ticket = 0;
+  for (int i = threadIdx.x; i < TN_SPLIT_TILES_MAX; i += blockDim.x) s.flag[i] = 0;
+}
+int tn_split_state_debug(int op, unsigned arg, hipStream_t st) {
+  hipLaunchKernelGGL(tn_split_state_debug_kernel, dim3(8), dim3(128), 0, st, op, arg);
+  if (op == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+      std::lock_guard<std::mutex> lk(g_tn_mu);
+      g_tn_host[dev].n = 0;
+    }
   }
-  return base[dev];
+  return check_launch("tn_split_state_debug");
+}
+// reserves the next launch of (current device, st): its slot's state, ticket run and sequence number; false = no slot (all eight belong to other streams)
+struct TnSplitTake { TnSplitState* state; unsigned ticket0, want; int dev, slot; };
+static bool tn_split_take(hipStream_t st, int units, TnSplitTake& t) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  std::lock_guard<std::mutex> lk(g_tn_mu);
+  TnSplitHost& h = g_tn_host[dev];
+  if (!h.dev) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tn_split)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    h.dev = (TnSplitState*)p;
+  }
+  int slot = -1;
+  for (int i = 0; i < h.n; i++) if (h.streams[i] == st) { slot = i; break; }
+  if (slot < 0) {
+    if (h.n >= 8) return false;
+    slot = h.n++;
+    h.streams[slot] = st; h.seq[slot] = 0; h.base[slot] = 0;
+  }
+  t.state = h.dev + slot; t.dev = dev; t.slot = slot;
+  t.ticket0 = h.base[slot];
+  h.base[slot] += (unsigned)units;
+  if (++h.seq[slot] == 0) h.seq[slot] = 1;
+  t.want = h.seq[slot];
+  return true;
+}
+static void tn_split_untake(const TnSplitTake& t, int units) {   // the launch was not enqueued: the device counter never moved
+  std::lock_guard<std::mutex> lk(g_tn_mu);
+  TnSplitHost& h = g_tn_host[t.dev];
+  if (t.slot < h.n && h.base[t.slot] == t.ticket0 + (unsigned)units) { h.base[t.slot] = t.ticket0; h.seq[t.slot] = t.want - 1u; }
 }
 size_t gemm_tn_grouped_split_bytes(int tiles) { return (size_t)tiles * 36 * 512 * sizeof(f32x4); }
 
@@ -1012,19 +1075,26 @@ int gemm_tn_grouped(const TnJob* jobs, int njobs, hipStream_t st, void* split_ws
     tiles += (jobs[i].N1 / tile) * (jobs[i].N2 / tile);
   }
   for (int i = njobs; i < TN_GROUP_MAX; i++) { g.job[i] = g.job[0]; g.job[i].tile0 = 0x7fffffff; }
-  g.tiles = 0; g.scratch = nullptr; g.flags = nullptr; g.status = nullptr;
-  // split launch: every tile's token range as two halves by two workgroups (256 x 256 tiles only; every product with at least 128 tokens per half; one launch in
-  // flight per device at a time: the flags are the library's - the caller is block.hip on the library's side stream)
-  if (tile == 256 && split_ws && !((uintptr_t)split_ws & 255) && tiles <= 128 && split_ws_bytes >= gemm_tn_grouped_split_bytes(tiles) && !(g_ab & 4)) {
+  g.tiles = 0; g.scratch = nullptr; g.flags = nullptr; g.status = nullptr; g.ticket = nullptr; g.ticket0 = 0; g.want = 1u;
+  // split launch: every tile's token range as two halves by two workgroups (256 x 256 tiles only; every product with at least 128 tokens per half).  The
+  // launch's scheduling words live in a slot of the library's that belongs to `st` (above); a ninth stream of one device runs whole launches
+  TnSplitTake take{};
+  bool split = false;
+  if (tile == 256 && split_ws && !((uintptr_t)split_ws & 255) && tiles <= TN_SPLIT_TILES_MAX && split_ws_bytes >= gemm_tn_grouped_split_bytes(tiles) && !(g_ab & 4)) {
     bool ok = true;
     for (int i = 0; i < njobs; i++) ok = ok && jobs[i].M >= 256;
-    unsigned* fl = ok ? tn_split_flags_dev() : nullptr;
-    if (fl) { g.tiles = tiles; g.scratch = (f32x4*)split_ws; g.flags = fl; g.status = device_status_word_dev(); }
+    split = ok && tn_split_take(st, 2 * tiles, take);
+    if (split) {
+      g.tiles = tiles; g.scratch = (f32x4*)split_ws; g.flags = take.state->flag; g.status = device_status_word_dev();
+      g.ticket = &take.state->ticket; g.ticket0 = take.ticket0; g.want = take.want;
+    }
   }
   if (tile == 256 && g.tiles > 0) hipLaunchKernelGGL((gemm_tn_grouped_kernel<256, true>), dim3(2 * tiles), dim3(512), 0, st, g);
   else if (tile == 256) hipLaunchKernelGGL((gemm_tn_grouped_kernel<256, false>), dim3(tiles), dim3(512), 0, st, g);
   else hipLaunchKernelGGL((gemm_tn_grouped_kernel<128, false>), dim3(tiles), dim3(256), 0, st, g);
-  return check_launch("gemm_tn_grouped");
+  const int rc = check_launch("gemm_tn_grouped");
+  if (rc && split) tn_split_untake(take, 2 * tiles);
+  return rc;
 }
 
 int gemm_tn(const bf16_t* X, int ldx, const bf16_t* Y, int ldy, int M, int N1, int N2, float* out, void* ws, size_t ws_bytes, hipStream_t st,

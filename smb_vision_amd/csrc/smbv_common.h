@@ -244,7 +244,9 @@ struct SweepPart {
   int t0 = 0, t1 = 0;            // sub-range of the swept tiles (t1 = 0: the whole sweep)
   int part = -1;                 // -1 whole sweep, 0 producer half, 1 consumer half
   f32x4* scratch = nullptr;      // this tile's partial accumulators
-  unsigned* flag = nullptr;      // 0 -> 1 by the producer, back to 0 by the consumer
+  unsigned* flag = nullptr;      // 0 -> `want` by the producer, back to 0 by the consumer
+  unsigned want = 1u;            // the value that speaks for THIS launch (never 0).  Launches that keep their flags in library-owned device memory stamp it with their
+                                 // launch epoch / sequence number: a word left behind by a launch that faulted or never finished is then not mistaken for this one's
   unsigned* status = nullptr;    // the device's sticky fault word (a consumer that gives up waiting)
 };
 // (the s_nop: a store of more than 8 bytes reads its data registers for two more wait states on gfx940+, and the compiler, which does not look inside the asm,
@@ -271,13 +273,13 @@ __device__ __forceinline__ void sweep_store(f32x4* base, const f32x4 (&v)[NV], i
 __device__ __forceinline__ void sweep_signal(const SweepPart& sp, int t) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (t == 0) __hip_atomic_store(sp.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t == 0) __hip_atomic_store(sp.flag, sp.want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // one lane polls, takes the agent-scope acquire; false (after raising the fault word) if the producer's flag never came.  `ok` lives in LDS the block no longer uses
 __device__ __forceinline__ bool sweep_wait(const SweepPart& sp, int t, int* ok) {
   if (t == 0) {
     int spins = 0;
-    while (__hip_atomic_load(sp.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(8); spins++; }
+    while (__hip_atomic_load(sp.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sp.want && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(8); spins++; }
     *ok = spins < (1 << 22);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -84,6 +84,8 @@ struct TnGroup {
   TnJob job[TN_GROUP_MAX]; int njobs;
   int tiles;                    // > 0: split launch - 2 x tiles blocks, each tile's token range as two halves (gemm.hip)
   f32x4* scratch; unsigned* flags; unsigned* status;
+  unsigned* ticket; unsigned ticket0;   // split launch: units are CLAIMED, in order, from a device counter (this launch's run starts at ticket0)
+  unsigned want;                        // ... and its hand-off flags carry this launch's sequence number (never 0)
 };
 bool gemm_tn_grouped_ok(const TnJob* jobs, int njobs);
 // split_ws (256-byte aligned, gemm_tn_grouped_split_bytes(tiles)): the launch runs every 256 x 256 tile's token range as two halves by two workgroups

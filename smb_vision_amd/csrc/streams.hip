@@ -72,8 +72,10 @@ int device_status(bool clear) {
   const char* what = code == 0x5001u ? "attention backward: a scheduling word of another launch epoch (two launches shared one slot, or the slot was left dirty)"
                      : code == 0x5002u ? "attention backward: a block found both tile queues exhausted (a tile was skipped: gradients of that launch are incomplete)"
                      : code == 0x5003u ? "attention backward: the completion counter carried another launch's epoch"
+                     : code == 0x5004u ? "split launch: a consumer half gave up waiting for its producer half's partial sums (that tile's gradients were not stored)"
+                     : code == 0x5005u ? "split weight-gradient launch: a block drew a ticket outside its launch's run (two launches shared one slot, or the slot was left dirty)"
                                        : "unknown fault";
-  set_error("device fault 0x%x recorded by an earlier kernel - %s; results since then are not to be trusted (smbv_device_status(1) clears it)", code, what);
+  set_error("device fault 0x%x recorded by an earlier kernel - %s; results since then are not to be trusted (smbv_debug_pair_state(0) restores the scheduling state, smbv_device_status(1) clears the word)", code, what);
   return SMBV_ERR_STATE;
 }
 

@@ -104,6 +104,10 @@ class VolumeFeeder:
         # i - nhost = i - prefetch - 2 has been taken off the queue and its upload enqueued (self._h2d_done[k] set); wait for that upload.
         # An item is ONE raw volume or a LIST of them (a batch: the volumes may differ in shape and dtype, the step receives [B, depth, 1, H, W]).
         try:
+            # a new thread's current device is 0: under one process per GPU every rank > 0 would otherwise page-lock its buffers through, and create a
+            # context on, GPU 0
+            if self.device.type == "cuda":
+                torch.cuda.set_device(self.device)
             for i, (raw, extras) in enumerate(self.source):
                 if stop.is_set():
                     return

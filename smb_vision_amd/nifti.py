@@ -85,8 +85,14 @@ def read_nifti(path: str) -> Tuple[np.ndarray, np.ndarray]:
     elif qform_code > 0:
         b, c, d = struct.unpack_from(bo + "3f", raw, 256)
         off = struct.unpack_from(bo + "3f", raw, 268)
+        # the NIfTI-1 standard's quatern -> matrix rule (nifti1.h "QUATERNION REPRESENTATION OF ROTATION MATRIX"): a = sqrt(1 - b^2 - c^2 - d^2); when that
+        # is not positive (a 180-degree rotation stored in single precision lands slightly above 1) (b, c, d) is renormalised and a = 0
         a2 = 1.0 - (b * b + c * c + d * d)
-        a = np.sqrt(a2) if a2 > 0 else 0.0
+        if a2 < 1e-7:
+            n = 1.0 / np.sqrt(b * b + c * c + d * d)
+            b, c, d, a = b * n, c * n, d * n, 0.0
+        else:
+            a = np.sqrt(a2)
         R = np.array([[a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c)],
                       [2 * (b * c + a * d), a * a + c * c - b * b - d * d, 2 * (c * d - a * b)],
                       [2 * (b * d - a * c), 2 * (c * d + a * b), a * a + d * d - b * b - c * c]])

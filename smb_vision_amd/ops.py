@@ -315,6 +315,8 @@ def device_status(clear=False) -> int:
 
 
 def debug_pair_state(op: int):
-    """smbv_debug_pair_state (test hook): 1 = dirty the attention backward's scheduling slots, 0 = restore them."""
+    """smbv_debug_pair_state: 0 = restore the library's device-side scheduling state (attention backward tile queues / tickets / split-sweep flags, the split
+    weight-gradient launch's tickets / flags) and the host's launch epochs; test hooks: 1 = dirty the slots, 2 + 4 e = raise every hand-off flag as an unfinished
+    launch of epoch e would have left it."""
     check(_lib.load().smbv_debug_pair_state(int(op), _stream()), "smbv_debug_pair_state")
 

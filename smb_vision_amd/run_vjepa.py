@@ -104,8 +104,9 @@ class SyntheticVJEPADataset(Dataset):
         item = {"image": torch.rand(self.depth, 1, self.crop, self.crop, generator=g)}
         # a fixed mask per sample (the generator draws from torch's GLOBAL stream, transforms.py:168-170): what the reference's PersistentDataset caches
         # with the image, and what lets a resumed run see the uninterrupted run's batches; the global stream is left as it was found
+        # (default_generator.manual_seed, not torch.manual_seed: the latter also reseeds every CUDA generator, which set_rng_state below would not put back)
         state = torch.random.get_rng_state()
-        torch.manual_seed(self.seed + i)
+        torch.default_generator.manual_seed(self.seed + i)
         try:
             return self.gen(item)
         finally:
@@ -122,7 +123,7 @@ class _SeededMasks:
     def __call__(self, item):
         import zlib
         state = torch.random.get_rng_state()
-        torch.manual_seed(self.seed + zlib.crc32(os.path.basename(item["volume"].path).encode()))
+        torch.default_generator.manual_seed(self.seed + zlib.crc32(os.path.basename(item["volume"].path).encode()))   # CPU stream only, as above
         try:
             return self.gen(item)
         finally:

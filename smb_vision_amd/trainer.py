@@ -211,16 +211,36 @@ class SmbTrainer(Trainer):
             inputs[key] = raw_batch_to_device(inputs.pop(RAW_KEY), next(self.model.parameters()).device, size, depth)
         return super()._prepare_inputs(inputs)
 
+    def _refuse_after_device_fault(self, what: str) -> None:
+        """Nothing of weights a faulted step has touched is written: the library's sticky status word is set by a kernel that detects a fault it
+        cannot return (``smbv_device_status``); it is read here after a device synchronisation, BEFORE anything goes to disk - an auto-resume must never pick up
+        a checkpoint, and ``output_dir`` never a ``model.safetensors``, whose last update consumed incomplete gradients.  Under data parallelism the ranks agree on
+        the verdict first (MAX over the status words): a rank that raised alone would leave the others inside HF's save barrier until the collective timed out."""
+        if not (_is_native(self.model) and next(self.model.parameters()).is_cuda):
+            return
+        from . import _lib, ops
+        torch.cuda.synchronize()
+        status = ops.device_status()
+        mine = _lib.last_error() if status != 0 else ""
+        faulted = status != 0
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            on_gpu = "nccl" in str(dist.get_backend()).lower()
+            flag = torch.tensor([1 if faulted else 0], dtype=torch.int32, device=next(self.model.parameters()).device if on_gpu else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            faulted = bool(int(flag.item()))
+        if faulted:
+            where = mine or "recorded on another rank"
+            raise _lib.SmbvError(f"refusing to write {what}: a kernel of an earlier step recorded a fault on this device ({where})")
+
     def _save_checkpoint(self, *args, **kwargs):
-        """No checkpoint of weights a faulted step has touched: the library's sticky status word is set by a kernel that detects a fault it cannot
-        return (``smbv_device_status``); it is read here after a device synchronisation, BEFORE anything is written - an auto-resume must never pick up a
-        checkpoint whose last update consumed incomplete gradients."""
-        if _is_native(self.model) and next(self.model.parameters()).is_cuda:
-            from . import _lib, ops
-            torch.cuda.synchronize()
-            if ops.device_status() != 0:
-                raise _lib.SmbvError(f"refusing to write a checkpoint: a kernel of an earlier step recorded a fault on this device ({_lib.last_error()})")
+        self._refuse_after_device_fault("a checkpoint")
         return super()._save_checkpoint(*args, **kwargs)
+
+    def save_model(self, *args, **kwargs):
+        """``train_and_evaluate`` (and the reference scripts, ``src/run_mim.py:441``) call this right after ``train()``: a fault recorded by the LAST steps is seen by
+        no later library entry, so it is looked for here as well."""
+        self._refuse_after_device_fault("the model")
+        return super().save_model(*args, **kwargs)
 
     # -- decay grouping -------------------------------------------------------------------------------------------------------------------
     def get_decay_parameter_names(self, model):

@@ -201,6 +201,36 @@ def test_hf_trainer_resumes_from_a_checkpoint_bit_identically_and_evaluates(tmp_
     assert "eval_loss" not in m_a
 
 
+def test_nothing_is_saved_after_a_device_fault(tmp_path):
+    """weights a faulted step has touched never reach the disk - neither as a checkpoint (``_save_checkpoint``) nor as the final
+    ``model.safetensors`` (``save_model``, which ``train_and_evaluate`` calls right after ``train()``: a fault recorded by the last steps is seen by no later
+    library entry).  The fault is a real one: a split weight-gradient launch into a dirtied scheduling slot."""
+    from smb_vision_amd import _lib, ops
+    from smb_vision_amd.run_mim import build_trainer
+    trainer = build_trainer(["--output_dir", str(tmp_path / "o"), "--max_steps", "1", "--save_strategy", "no", *_TINY_RUN])
+    trainer.train()
+    torch.cuda.synchronize()
+    assert ops.device_status() == 0, _lib.last_error()
+    x = torch.randn(512, 256, device="cuda").bfloat16()
+    try:
+        ops.debug_pair_state(1)
+        ops.gemm_tn_grouped([(x, x)], split=True)
+        torch.cuda.synchronize()
+        assert ops.device_status() == -5
+        with pytest.raises(_lib.SmbvError, match="refusing to write the model"):
+            trainer.save_model(str(tmp_path / "final"))
+        with pytest.raises(_lib.SmbvError, match="refusing to write a checkpoint"):
+            trainer._save_checkpoint(trainer.model, None)
+        out_dir = tmp_path / "o"
+        assert not os.path.exists(tmp_path / "final") and not (os.path.isdir(out_dir) and any(n.startswith("checkpoint") for n in os.listdir(out_dir)))
+    finally:
+        ops.debug_pair_state(0)
+        torch.cuda.synchronize()
+        ops.device_status(clear=True)
+    trainer.save_model(str(tmp_path / "final"))
+    assert os.path.exists(tmp_path / "final" / "model.safetensors")
+
+
 def test_gradient_checkpointing_recompute_is_bitwise_identical_and_smaller():
     """config.smbv_recompute = "always" + gradient_checkpointing_enable(): per-layer recompute (reference spec :459-465, torch.utils.checkpoint per
     VideoMAELayer) - the blocks of a stack share one activation set and each block's forward re-runs in front of its backward.  Same kernels on

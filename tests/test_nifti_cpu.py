@@ -93,6 +93,16 @@ def test_reorientation_to_ras_from_sform_qform_and_pixdim(tmp_path):
     write_nifti(p, world[::-1, ::-1, :].copy(), qform=(1.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0), pixdim=(1.5, 1.5, 3.0))
     v, sp = nifti.to_ras(*nifti.read_nifti(p))
     assert np.array_equal(v, world) and np.allclose(sp, [1.5, 1.5, 3.0], atol=1e-5)
+    # (d') the same half turn stored a little long (|(b, c, d)| = 1.0002: single-precision storage of a 180-degree rotation), and a half turn about the
+    # diagonal of x / y (b = c = 0.70712 > 1 / sqrt 2): the standard renormalises (b, c, d) and takes a = 0 instead of giving up the rotation's scale
+    write_nifti(p, world[::-1, ::-1, :].copy(), qform=(1.0, 0.0, 0.0, 1.0002, 0.0, 0.0, 0.0), pixdim=(1.5, 1.5, 3.0))
+    v, sp = nifti.to_ras(*nifti.read_nifti(p))
+    assert np.array_equal(v, world) and np.allclose(sp, [1.5, 1.5, 3.0], atol=1e-5)
+    write_nifti(p, np.transpose(world, (1, 0, 2))[:, :, ::-1].copy(), qform=(1.0, 0.70712, 0.70712, 0.0, 0.0, 0.0, 0.0), pixdim=(1.5, 1.5, 3.0))
+    _, aff = nifti.read_nifti(p)
+    assert np.allclose(aff[:3, :3], np.array([[0, 1.5, 0], [1.5, 0, 0], [0, 0, -3.0]]), atol=1e-4)   # x <-> y swapped, z reversed: an exact rotation again
+    v, sp = nifti.to_ras(nifti.read_nifti(p)[0], aff)
+    assert np.array_equal(v, world) and np.allclose(sp, [1.5, 1.5, 3.0], atol=1e-4)
     # (e) neither form: pixdim alone
     write_nifti(p, world, pixdim=(0.7, 0.7, 5.0))
     v, sp = nifti.to_ras(*nifti.read_nifti(p))

@@ -666,6 +666,70 @@ def test_attention_backward_scheduling_fault_is_an_error_not_wrong_gradients(ops
     assert torch.equal(again, want) and ops.device_status() == 0
 
 
+def test_hand_off_words_of_a_faulted_or_unfinished_split_launch_are_never_taken_for_a_later_launchs(ops):
+    """the split sweeps of the attention backward and the split grouped weight-gradient launch hand fp32 partial sums between workgroups
+    through flags the LIBRARY keeps in device memory.  A launch that faults or runs short leaves flags raised; a later launch's consumer that took such a word for
+    its own producer's would add stale or half-written scratch - silently.  Now a flag carries its launch's epoch (attention) / sequence number (weight gradients),
+    the weight-gradient launch claims its units from a ticket inside a run the host reserved, and smbv_debug_pair_state(0) restores all of it.  Pinned here:
+    (a) flags raised as an EARLIER launch would have left them change nothing - bitwise; (b) a launch into dirtied state is a device fault, not a result;
+    (c) reset + clear, and the next split launches reproduce the first bit for bit; (d) a second stream has a slot of its own."""
+    from smb_vision_amd import _lib
+    lib = _lib.load()
+    B, S, H = 1, 7168, 12
+    qkv, O, lse, dO = _bwd_case(ops, B, S, H, 64, 0, 0, seed=43)
+    aws = torch.empty(lib.smbv_attention_bwd_split_workspace_bytes(B, S, H, 64), dtype=torch.uint8, device="cuda")
+    shapes = [(1024, 768, 512), (1024, 512, 768), (1024, 256, 256)]
+    pairs = [(rnd(M, N1, seed=30 + i).bfloat16(), rnd(M, N2, seed=40 + i).bfloat16()) for i, (M, N1, N2) in enumerate(shapes)]
+    nseg = [3, 1, 1]
+
+    def attn():
+        return ops.attention_bwd(qkv, O, dO, lse, B, S, H, split=aws)[0]
+
+    def tn():
+        outs, xs = ops.gemm_tn_grouped(pairs, sums=nseg, split=True)
+        return torch.cat([o.flatten() for o in outs] + [t for x in xs for t in x])
+
+    torch.cuda.synchronize()
+    assert ops.device_status() == 0, _lib.last_error()
+    try:
+        ops.debug_pair_state(0)                       # epochs / sequence numbers restart: the launches below carry 0, 1, 2 ... and 1, 2, 3 ...
+        a0, t0 = attn(), tn()                         # attention epoch 0 (flags raised to 1), weight gradients sequence number 1
+        a1, t1 = attn(), tn()
+        assert torch.equal(a0, a1) and torch.equal(t0, t1)
+        ops.debug_pair_state(2 + 4 * 0)               # (a) every flag of every slot = 1: what epoch 0 / launch 1 would have left had its consumers never run
+        a2, t2 = attn(), tn()                         # epoch 2 waits for 3, launch 3 for 3: the stale 1 is overwritten by the producer, never consumed
+        torch.cuda.synchronize()
+        assert ops.device_status() == 0, _lib.last_error()
+        assert torch.equal(a2, a0) and torch.equal(t2, t0)
+        ops.debug_pair_state(1)                       # (b) tile queue + 3 / ticket + 3
+        bad_t = tn()                                  # three producer units are never claimed: their consumers give up after the bounded wait (~1 s), three blocks draw tickets past the run
+        torch.cuda.synchronize()
+        assert ops.device_status() == -5
+        assert "0x5004" in _lib.last_error() or "0x5005" in _lib.last_error()
+        assert not torch.equal(bad_t, t0)
+        assert ops.device_status(clear=True) == -5
+        bad_a = attn()                                # its last three consumer halves are never claimed: flags stay raised with this launch's epoch
+        torch.cuda.synchronize()
+        assert ops.device_status() == -5 and ("0x5002" in _lib.last_error() or "0x5001" in _lib.last_error())
+        assert not torch.equal(bad_a, a0)
+    finally:
+        ops.debug_pair_state(0)                       # (c)
+        torch.cuda.synchronize()
+        ops.device_status(clear=True)
+    assert ops.device_status() == 0
+    for _ in range(2):
+        assert torch.equal(attn(), a0) and torch.equal(tn(), t0)
+    side = torch.cuda.Stream()                        # (d)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ts, as_ = tn(), attn()
+    side.synchronize()
+    assert torch.equal(ts, t0) and torch.equal(as_, a0)
+    assert torch.equal(tn(), t0)
+    torch.cuda.synchronize()
+    assert ops.device_status() == 0, _lib.last_error()
+
+
 @pytest.mark.parametrize("B,S,H,Dh,Sq,qoff", [(1, 7168, 12, 64, 0, 0), (1, 20480, 6, 64, 13312, 7168), (2, 4096, 6, 64, 0, 0), (1, 7168, 12, 32, 0, 0), (1, 6100, 8, 64, 0, 0)])
 def test_attention_backward_split_sweeps_hand_off_exactly(ops, B, S, H, Dh, Sq, qoff):
     """Round 5: smbv_attention_bwd_split - the pair launch's last 192 tiles of each role as two half sweeps whose fp32 accumulators are handed from one workgroup to
