@@ -54,7 +54,8 @@ typedef uint16_t smbv_bf16;
  * by the library: a binding compiled against a shorter or longer layout is refused with SMBV_ERR_ARG instead of being read past its end);
  * 1000-1002 (round 1-2) had no such guard and grew smbv_mim_cfg / smbv_vjepa_cfg in place.  3000 (round 4): smbv_attention_fwd / smbv_attention_bwd take
  * the residual output O_lo, the *_cfg structs end with attn_o_resid.  3001 (round 5, additive): smbv_gemm_nt_splitk + its workspace query; 3002 (round 5, additive): smbv_attention_bwd_split + its workspace query;
- * 3003 (round 5, additive): smbv_gemm_tn_grouped_split + its workspace query; 3004 (round 5, additive): smbv_rope3d_cfg, smbv_gemm_nt_rope, smbv_attention_bwd_rope. */
+ * 3003 (round 5, additive): smbv_gemm_tn_grouped_split + its workspace query; 3004 (round 5, additive): smbv_rope3d_cfg, smbv_gemm_nt_rope, smbv_attention_bwd_rope.
+ * 3005 (round 6, additive): smbv_debug_pair_state(0) also restores the hand-off flags / tickets of the split launches and takes op 2 + 4 e; device status codes 0x5004 / 0x5005. */
 #define SMBV_ABI_MAJOR 3
 int smbv_version(void);
 int smbv_last_error(char* buf, size_t len);               /* copies the thread's last error text; returns its length */
@@ -82,7 +83,8 @@ int smbv_device_status(int clear);
 /* Test / recovery hook for the above: op 0 restores every scheduling slot of the current device - attention backward tile queues, per-CU tickets and
  * split-sweep flags, the split weight-gradient launch's tickets and flags - and the host's launch epochs to their load-time state (enqueued on `stream`; the
  * device must be idle otherwise).  NOT the product path: op 1 dirties the slots the way a second launch sharing a slot would (attention key-owner queue
- * + 3, weight-gradient ticket + 3); op 2 + 4 e leaves every hand-off flag raised as an unfinished launch of epoch / sequence number e + 1 would. */
+ * + 3, weight-gradient ticket + 3); op 2 + 4 e leaves every hand-off flag raised to e + 1: what an unfinished attention launch of epoch e / an unfinished
+ * weight-gradient launch of sequence number e + 1 would have left behind. */
 int smbv_debug_pair_state(int op, smbv_stream stream);
 
 /* ---- per-op entry points (also what the parity tests call) ------------------------------------------------------ */
