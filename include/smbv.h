@@ -139,7 +139,11 @@ int smbv_gemm_tn_grouped(const smbv_tn_job* jobs /* host */, int njobs, smbv_str
  * half its CUs - the steps run the LAST block's weight gradients this way, the optimizer waits for nothing else (profiles/r05_tn_split_ab.txt).  The
  * first half's workgroup hands its fp32 tile and column sums through ws (write-through stores, one flag per tile), the second adds its own and writes
  * the result: the same two addends in the same order on every run.  Every N1, N2 a multiple of 256, every M >= 256, at most 128 tiles in all
- * (the workspace query returns 0 otherwise and the call SMBV_ERR_SHAPE); ws 256-byte aligned; one such launch in flight per device. */
+ * (the workspace query returns 0 otherwise and the call SMBV_ERR_SHAPE); ws 256-byte aligned and not shared between launches that may overlap.  The
+ * launch's scheduling words (a unit ticket, one flag per tile) live in a slot of the library's that belongs to `stream` - eight slots per device, a slot taken by
+ * the first launch of a stream; launches of a ninth stream run whole (same products, the two addends of a tile then meet in the matrix pipe instead).  Units are
+ * claimed from the ticket, so a consumer half only ever runs after every producer half has been claimed by a running workgroup; flags carry the launch's
+ * sequence number (ABI 3005: round 5 kept ONE flag array per device and took roles from the workgroup index). */
 size_t smbv_gemm_tn_grouped_split_workspace_bytes(const smbv_tn_job* jobs /* host */, int njobs);
 int smbv_gemm_tn_grouped_split(const smbv_tn_job* jobs /* host */, int njobs, void* ws, size_t ws_bytes, smbv_stream stream);
 
