@@ -219,13 +219,15 @@ class SmbTrainer(Trainer):
         if not (_is_native(self.model) and next(self.model.parameters()).is_cuda):
             return
         from . import _lib, ops
-        torch.cuda.synchronize()
-        status = ops.device_status()
+        dev = next(self.model.parameters()).device
+        with torch.cuda.device(dev):          # the status word is per device: the model's, whatever the process's current device is
+            torch.cuda.synchronize(dev)
+            status = ops.device_status()
         mine = _lib.last_error() if status != 0 else ""
         faulted = status != 0
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             on_gpu = "nccl" in str(dist.get_backend()).lower()
-            flag = torch.tensor([1 if faulted else 0], dtype=torch.int32, device=next(self.model.parameters()).device if on_gpu else "cpu")
+            flag = torch.tensor([1 if faulted else 0], dtype=torch.int32, device=dev if on_gpu else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             faulted = bool(int(flag.item()))
         if faulted:
