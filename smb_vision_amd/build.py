@@ -21,7 +21,11 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result", "-ffp-contract=fast"]
 # The attention bodies place single-issue VALU work between MFMAs; SLP-packing adjacent f32 multiplies into v_pk_* (plus the moves
 # that line the pairs up) costs more issue slots there than it saves.
-FILE_FLAGS = {"attention_bwd.hip": ["-fno-slp-vectorize"], "attention_fwd.hip": ["-fno-slp-vectorize"]}
+# gemm.hip: LLVM's max-ILP machine scheduler for the compiler-scheduled K loops (gemm_nt_dma_kernel: LDS reads issued further ahead of their MFMAs, four
+# instead of seven MFMAs behind the barrier; 104 -> 112 registers, same occupancy): -0.10 ms per MIM step in-box, same results bit for bit
+# (profiles/r06_sched_strategy_ab.txt; the other files measured null or slower with it - the hand-phased attention backward +0.1 ms)
+FILE_FLAGS = {"attention_bwd.hip": ["-fno-slp-vectorize"], "attention_fwd.hip": ["-fno-slp-vectorize"],
+              "gemm.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def _hipcc() -> str:
