@@ -55,7 +55,8 @@ typedef uint16_t smbv_bf16;
  * 1000-1002 (round 1-2) had no such guard and grew smbv_mim_cfg / smbv_vjepa_cfg in place.  3000 (round 4): smbv_attention_fwd / smbv_attention_bwd take
  * the residual output O_lo, the *_cfg structs end with attn_o_resid.  3001 (round 5, additive): smbv_gemm_nt_splitk + its workspace query; 3002 (round 5, additive): smbv_attention_bwd_split + its workspace query;
  * 3003 (round 5, additive): smbv_gemm_tn_grouped_split + its workspace query; 3004 (round 5, additive): smbv_rope3d_cfg, smbv_gemm_nt_rope, smbv_attention_bwd_rope.
- * 3005 (round 6, additive): smbv_debug_pair_state(0) also restores the hand-off flags / tickets of the split launches and takes op 2 + 4 e; device status codes 0x5004 / 0x5005. */
+ * 3005 (round 6, additive): smbv_debug_pair_state(0) also restores the hand-off flags / tickets of the split launches and takes op 2 + 4 e; device status codes 0x5004 / 0x5005.
+ * 3006 (round 6, additive): smbv_encoder_hidden_states / smbv_mim_hidden_states (output_hidden_states=True of the reference's model classes). */
 #define SMBV_ABI_MAJOR 3
 int smbv_version(void);
 int smbv_last_error(char* buf, size_t len);               /* copies the thread's last error text; returns its length */
@@ -300,6 +301,10 @@ int smbv_mim_forward(const smbv_mim_cfg* cfg, const smbv_mim_tensors* params, co
  *   [..+layers] encoder layers (last first), [last] patch embedding  — used to launch RCCL all-reduces on a side stream. */
 int smbv_mim_backward(const smbv_mim_cfg* cfg, const smbv_mim_tensors* params, const smbv_mim_tensors* grads, const smbv_mim_io* io,
                       void* ws, size_t ws_bytes, void** events, int n_events, smbv_stream stream);
+/* output_hidden_states=True of VideoMAEForPreTraining (spec :900-907 hands on the ENCODER's hidden states, visible tokens only): after smbv_mim_forward,
+ * out[l] (l = 0 .. layers; n_out = layers + 1) points at the fp32 [B*Nvis, d] residual stream in front of encoder layer l (out[layers] = the encoder's output;
+ * MIM has no final encoder LayerNorm, spec :517-520).  Kept by every mode (gradient checkpointing keeps exactly these).  Pointers into `ws`, no launch. */
+int smbv_mim_hidden_states(const smbv_mim_cfg* cfg, void* ws, size_t ws_bytes, float** out, int n_out);
 
 /* ---- encoder-only forward: VideoMAEModel.forward (spec :509-655) as src/run_inference.py:78-83 calls it for the
  *      embedding export (all tokens, no mask) and as the classification head (spec :917-989) sits on it. ---- */
@@ -333,6 +338,11 @@ typedef struct smbv_encoder_io {
 size_t smbv_encoder_workspace_bytes(const smbv_encoder_cfg* cfg);
 int smbv_encoder_forward(const smbv_encoder_cfg* cfg, const smbv_encoder_tensors* params, const smbv_encoder_io* io, void* ws, size_t ws_bytes,
                          smbv_stream stream);
+/* output_hidden_states=True (spec :452-457, 478-483: the encoder collects the embedding output and every layer's output, NOT the final LayerNorm's): after a
+ * forward with cfg.train = 1, out[l] (l = 0 .. layers; n_out = layers + 1) points at the fp32 [B*Nsel, d] residual stream the workspace holds in front of layer l
+ * (out[layers] = the last layer's output).  Pointers into `ws`: valid until the workspace is rewritten by the next forward; no launch, no synchronisation.
+ * The inference forward (cfg.train = 0) shares one activation set between its layers and is refused. */
+int smbv_encoder_hidden_states(const smbv_encoder_cfg* cfg, void* ws, size_t ws_bytes, float** out, int n_out);
 /* Fine-tuning (src/run_classification.py): gradients of every tensor in `grads` (overwritten) from d(last_hidden_state) fp32 [B*Nsel, d];
  * same cfg (train = 1), io and workspace as the forward that preceded it. */
 int smbv_encoder_backward(const smbv_encoder_cfg* cfg, const smbv_encoder_tensors* params, const smbv_encoder_tensors* grads, const smbv_encoder_io* io,

@@ -262,9 +262,10 @@ def mim_forward(p: "dict[str, torch.Tensor]", cfg: MIMConfig, pixel_values: torc
     return loss, logits
 
 
-def encoder_forward(p, cfg: MIMConfig, pixel_values, bool_masked_pos=None, prefix="videomae.", final_ln=False, emulate_bf16=False):
+def encoder_forward(p, cfg: MIMConfig, pixel_values, bool_masked_pos=None, prefix="videomae.", final_ln=False, emulate_bf16=False, hidden_states=None):
     """VideoMAEModel.forward (spec :509-655; embeddings :124-139): all tokens when bool_masked_pos is None (the embedding export of
-    src/run_inference.py:78-83), the visible ones otherwise; final ``layernorm`` only when the config has use_mean_pooling=False (:517-520)."""
+    src/run_inference.py:78-83), the visible ones otherwise; final ``layernorm`` only when the config has use_mean_pooling=False (:517-520).
+    ``hidden_states`` (a list) receives what output_hidden_states=True collects (spec :452-457, 478-483): the embedding output and every layer's output."""
     emu = emulate_bf16
     B = pixel_values.shape[0]
     N, d = cfg.num_patches, cfg.hidden_size
@@ -273,8 +274,12 @@ def encoder_forward(p, cfg: MIMConfig, pixel_values, bool_masked_pos=None, prefi
     x = emb + sinusoid_table(N, d)[None]
     if bool_masked_pos is not None:
         x = x[~bool_masked_pos].reshape(B, -1, d)
+    if hidden_states is not None:
+        hidden_states.append(x)
     for i in range(cfg.num_hidden_layers):
         x = layer(x, p, f"{prefix}encoder.layer.{i}.", cfg.num_attention_heads, cfg.layer_norm_eps, emu)
+        if hidden_states is not None:
+            hidden_states.append(x)
     if final_ln:
         x = F.layer_norm(x, (d,), p[prefix + "layernorm.weight"], p[prefix + "layernorm.bias"], cfg.layer_norm_eps)
     return x

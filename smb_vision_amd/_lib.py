@@ -10,7 +10,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsmbv.so")
 MAX_LAYERS = 48
-ABI_MAJOR, ABI_MINOR_NEEDED = 3, 4  # include/smbv.h SMBV_ABI_MAJOR; the newest entry point these bindings call
+ABI_MAJOR, ABI_MINOR_NEEDED = 3, 6  # include/smbv.h SMBV_ABI_MAJOR; the newest entry point these bindings call
 
 c_f = C.c_void_p  # all device pointers travel as void*
 
@@ -167,6 +167,8 @@ _SIGS = {
     "smbv_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderCfg)]),
     "smbv_encoder_forward": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(EncoderTensors), C.POINTER(EncoderIO), c_f, C.c_size_t, c_f]),
     "smbv_encoder_backward": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(EncoderTensors), C.POINTER(EncoderTensors), C.POINTER(EncoderIO), c_f, c_f, C.c_size_t, c_f]),
+    "smbv_encoder_hidden_states": (C.c_int, [C.POINTER(EncoderCfg), c_f, C.c_size_t, C.POINTER(C.c_void_p), C.c_int]),
+    "smbv_mim_hidden_states": (C.c_int, [C.POINTER(MimCfg), c_f, C.c_size_t, C.POINTER(C.c_void_p), C.c_int]),
     "smbv_mim_workspace_bytes": (C.c_size_t, [C.POINTER(MimCfg)]),
     "smbv_mim_forward": (C.c_int, [C.POINTER(MimCfg), C.POINTER(MimTensors), C.POINTER(MimIO), c_f, C.c_size_t, c_f]),
     "smbv_mim_backward": (C.c_int, [C.POINTER(MimCfg), C.POINTER(MimTensors), C.POINTER(MimTensors), C.POINTER(MimIO), c_f, C.c_size_t,

@@ -53,7 +53,7 @@ using namespace smbv;
 
 extern "C" {
 
-int smbv_version(void) { return 3005; }  // 3000: O_lo in smbv_attention_fwd / _bwd, attn_o_resid in the *_cfg structs; see include/smbv.h
+int smbv_version(void) { return 3006; }  // 3000: O_lo in smbv_attention_fwd / _bwd, attn_o_resid in the *_cfg structs; see include/smbv.h
 void smbv_debug_set_variant(int bits) { smbv::g_variant = bits; }
 int smbv_device_status(int clear) { return smbv::device_status(clear != 0); }
 int smbv_debug_pair_state(int op, smbv_stream stream) { return smbv::pair_state_debug(op, (hipStream_t)stream); }

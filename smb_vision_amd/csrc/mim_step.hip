@@ -260,6 +260,17 @@ size_t smbv_mim_workspace_bytes(const smbv_mim_cfg* cfg) {
   return W.total;
 }
 
+int smbv_mim_hidden_states(const smbv_mim_cfg* cfg, void* ws, size_t ws_bytes, float** out, int n_out) {
+  if (!cfg || !out) { smbv::set_error("smbv_mim_hidden_states: null argument"); return SMBV_ERR_ARG; }
+  if (int rc = smbv::check_cfg(*cfg)) return rc;
+  if (n_out != cfg->layers + 1) { smbv::set_error("smbv_mim_hidden_states: n_out = %d, the encoder has %d hidden states (embeddings + one per layer)", n_out, cfg->layers + 1); return SMBV_ERR_ARG; }
+  smbv::MimWs W;
+  smbv::carve(*cfg, ws, W);
+  if (!ws || ws_bytes < W.total || ((uintptr_t)ws & 255)) { smbv::set_error("smbv_mim_hidden_states: workspace too small or misaligned (%zu < %zu)", ws_bytes, W.total); return SMBV_ERR_WORKSPACE; }
+  for (int l = 0; l <= cfg->layers; l++) out[l] = W.x[l];
+  return SMBV_OK;
+}
+
 int smbv_mim_forward(const smbv_mim_cfg* cfg, const smbv_mim_tensors* params, const smbv_mim_io* io, void* ws, size_t ws_bytes, smbv_stream stream) {
   if (!cfg || !params || !io) { smbv::set_error("smbv_mim_forward: null argument"); return SMBV_ERR_ARG; }
   SMBV_CHECK_DEVICE_STATE();

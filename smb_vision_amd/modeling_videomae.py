@@ -106,11 +106,14 @@ class _Slots(nn.Module):
     """Pure parameter container; the hierarchy only exists to reproduce the reference's state-dict names.  The ``videomae`` node of a
     task model is also callable (``model.videomae(image)``, src/run_inference.py:78-83): its owner installs ``_encode``."""
 
-    def forward(self, pixel_values=None, bool_masked_pos=None, **kwargs):
+    def forward(self, pixel_values=None, bool_masked_pos=None, head_mask=None, output_attentions=None, output_hidden_states=None, return_dict=None, **kwargs):
         enc = self.__dict__.get("_encode")
         if enc is None:
             raise TypeError("this container only holds parameters")
-        return enc(pixel_values, bool_masked_pos)
+        if head_mask is not None or output_attentions:
+            raise NotImplementedError("smb_vision_amd: head masks / attention maps are not produced by the fused HIP path")
+        out = enc(pixel_values, bool_masked_pos, output_hidden_states=output_hidden_states)
+        return out.to_tuple() if return_dict is False else out
 
 
 def _register(root: nn.Module, dotted: str, p: nn.Parameter):
@@ -201,9 +204,9 @@ class SmbVideoMAEForPreTraining(PreTrainedModel):
         self.reset_parameters()
         self.post_init()
 
-        def _encode(pixel_values, bool_masked_pos=None, _ref=weakref.ref(self)):
+        def _encode(pixel_values, bool_masked_pos=None, output_hidden_states=None, _ref=weakref.ref(self)):
             from .modeling_videomae_encoder import encode_with
-            return encode_with(_ref(), pixel_values, bool_masked_pos)
+            return encode_with(_ref(), pixel_values, bool_masked_pos, output_hidden_states)
         object.__setattr__(self._modules["videomae"], "_encode", _encode)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -462,8 +465,9 @@ class SmbVideoMAEForPreTraining(PreTrainedModel):
         """``VideoMAEForPreTraining.forward`` (spec :753-908).  ``visible_index`` / ``masked_index`` (optional, int32 [B, N-M] / [B, M], ascending - what
         ``masking.split_mask_indices_host`` builds in the collate function from the mask it just generated) spare the per-step device sort that
         otherwise derives them from ``bool_masked_pos``; they MUST describe the same partition."""
-        if output_attentions or output_hidden_states:
-            raise NotImplementedError("smb_vision_amd: attention maps / hidden states are never materialised by the fused HIP path")
+        if head_mask is not None or output_attentions or (output_attentions is None and getattr(self.config, "output_attentions", False)):
+            raise NotImplementedError("smb_vision_amd: head masks / attention maps ([B, H, N, N]) are never materialised by the fused HIP path")
+        want_hidden = bool(output_hidden_states if output_hidden_states is not None else getattr(self.config, "output_hidden_states", False))  # spec :790-793
         if pixel_values.dim() != 5:
             raise ValueError("pixel_values must be [batch, frames, channels, height, width]")
         B, T, Cc, H, W = pixel_values.shape
@@ -498,9 +502,22 @@ class SmbVideoMAEForPreTraining(PreTrainedModel):
                 loss, logits = _MIMStepFn.apply(weakref.ref(self), pixel_values, vis_idx, mask_idx, *params)
             else:
                 loss, logits, _ = self._run_forward(pixel_values, vis_idx, mask_idx)
+            hidden = self._encoder_hidden_states(B, n_masked) if want_hidden else None
         if return_dict is False:
-            return (loss, logits)
-        return SmbVideoMAEForPreTrainingOutput(loss=loss, logits=logits)
+            return (loss, logits) + ((hidden,) if want_hidden else ())
+        return SmbVideoMAEForPreTrainingOutput(loss=loss, logits=logits, hidden_states=hidden)
+
+    def _encoder_hidden_states(self, B, n_masked):
+        """``hidden_states`` of the reference's output (spec :900-907: the ENCODER's, over the visible tokens - the embedding output and every layer's output),
+        copied out of the step workspace the forward just filled (``smbv_mim_hidden_states``; every mode keeps them).  Detached, fp32."""
+        lib = _lib.load()
+        cfg = self._cfg_struct(B, n_masked)
+        n = cfg.layers + 1
+        ptrs = (C.c_void_p * n)()
+        _lib.check(lib.smbv_mim_hidden_states(C.byref(cfg), self._ws.data_ptr(), self._ws.numel(), ptrs, n), "smbv_mim_hidden_states")
+        base, rows = self._ws.data_ptr(), self.num_patches - n_masked
+        nb = B * rows * cfg.d * 4
+        return tuple(self._ws[int(ptrs[l]) - base:int(ptrs[l]) - base + nb].view(torch.float32).view(B, rows, cfg.d).clone() for l in range(n))
 
 
 _HF5_KEY_MAPPING = {

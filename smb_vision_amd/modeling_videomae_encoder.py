@@ -53,6 +53,7 @@ class _EncoderFn(torch.autograd.Function):
     def forward(ctx, runner, pix, sel, nsel, *params):
         out, st = runner._run(pix, sel, nsel, params, train=True)
         ctx.runner, ctx.st = runner, st
+        runner._last_st = dict(cfg=st["cfg"])   # (what hidden_states() needs; not the tensors)
         return out
 
     @staticmethod
@@ -140,6 +141,21 @@ class _EncoderRunner:
                                             torch.cuda.current_stream().cuda_stream), "smbv_encoder_forward")
         return out, dict(cfg=cfg, io=io, tens=tens, keep=(pix, sel, out), params=list(params))
 
+    def hidden_states(self, st):
+        """``hidden_states`` of the reference's encoder (spec :452-457, 478-483: the embedding output and every layer's output, not the final LayerNorm's)
+        as copies out of the workspace of the train-mode forward ``st`` came from.  Detached: the fused backward differentiates ``last_hidden_state`` only."""
+        lib = _lib.load()
+        cfg = st["cfg"]
+        n = cfg.layers + 1
+        ptrs = (C.c_void_p * n)()
+        _lib.check(lib.smbv_encoder_hidden_states(C.byref(cfg), self._ws.data_ptr(), self._ws.numel(), ptrs, n), "smbv_encoder_hidden_states")
+        base, nb = self._ws.data_ptr(), cfg.B * cfg.Nsel * cfg.d * 4
+        out = []
+        for l in range(n):
+            off = int(ptrs[l]) - base
+            out.append(self._ws[off:off + nb].view(torch.float32).view(cfg.B, cfg.Nsel, cfg.d).clone())
+        return tuple(out)
+
     def _run_backward(self, st, d_out):
         lib = _lib.load()
         dev = d_out.device
@@ -150,7 +166,8 @@ class _EncoderRunner:
                                                  self._ws.numel(), torch.cuda.current_stream().cuda_stream), "smbv_encoder_backward")
         return [v.clone() for v in views]  # autograd accumulates into .grad; the arena is rewritten by the next backward
 
-    def encode(self, pixel_values: torch.Tensor, bool_masked_pos: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def encode(self, pixel_values: torch.Tensor, bool_masked_pos: Optional[torch.Tensor] = None, output_hidden_states: bool = False):
+        """``last_hidden_state``; with ``output_hidden_states`` the pair (last_hidden_state, hidden_states tuple)."""
         c = self.config
         if pixel_values is None:
             raise ValueError("You have to specify pixel_values")
@@ -184,8 +201,14 @@ class _EncoderRunner:
                 nsel = self.N - n_masked
                 sel, _ = split_mask_indices(m, n_masked)
             if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-                return _EncoderFn.apply(self, pix, sel, nsel, *params)  # fine-tuning: activations kept, backward available
-            out, _ = self._run(pix, sel, nsel, params, train=False)
+                out = _EncoderFn.apply(self, pix, sel, nsel, *params)  # fine-tuning: activations kept, backward available
+                if output_hidden_states:
+                    return out, self.hidden_states(self._last_st)
+                return out
+            # (the inference forward shares one activation set between its layers: hidden states need the per-layer form)
+            out, st = self._run(pix, sel, nsel, params, train=bool(output_hidden_states))
+            if output_hidden_states:
+                return out, self.hidden_states(st)
         return out
 
 
@@ -256,10 +279,12 @@ class _EncoderModelBase(PreTrainedModel):
         convert_state_dict_keys(sd, "")
         return super().load_state_dict(sd, strict=strict, assign=assign)
 
-    @staticmethod
-    def _reject(head_mask, output_attentions, output_hidden_states):
-        if head_mask is not None or output_attentions or output_hidden_states:
-            raise NotImplementedError("smb_vision_amd: head masks / attention maps / hidden-state lists are not produced by the fused HIP path")
+    def _reject(self, head_mask, output_attentions, output_hidden_states=None):
+        """Resolves ``output_hidden_states`` against the config as the reference does (spec :596-599); head masks and attention maps ([B, H, N, N]: 10 GB per
+        layer at 20,480 tokens) are never materialised by the fused path."""
+        if head_mask is not None or output_attentions or (output_attentions is None and getattr(self.config, "output_attentions", False)):
+            raise NotImplementedError("smb_vision_amd: head masks / attention maps are not produced by the fused HIP path")
+        return bool(output_hidden_states if output_hidden_states is not None else getattr(self.config, "output_hidden_states", False))
 
 
 class SmbVideoMAEModel(_EncoderModelBase):
@@ -269,11 +294,11 @@ class SmbVideoMAEModel(_EncoderModelBase):
 
     def forward(self, pixel_values: torch.Tensor = None, bool_masked_pos: Optional[torch.Tensor] = None, head_mask=None, output_attentions=None,
                 output_hidden_states=None, return_dict=None, **kwargs):
-        self._reject(head_mask, output_attentions, output_hidden_states)
-        seq = self._runner.encode(pixel_values, bool_masked_pos)
+        want = self._reject(head_mask, output_attentions, output_hidden_states)
+        seq, hidden = self._runner.encode(pixel_values, bool_masked_pos, True) if want else (self._runner.encode(pixel_values, bool_masked_pos), None)
         if return_dict is False:
-            return (seq,)
-        return BaseModelOutput(last_hidden_state=seq, hidden_states=None, attentions=None)
+            return (seq,) + ((hidden,) if want else ())
+        return BaseModelOutput(last_hidden_state=seq, hidden_states=hidden, attentions=None)
 
 
 class SmbVideoMAEForVideoClassification(_EncoderModelBase):
@@ -290,14 +315,17 @@ class SmbVideoMAEForVideoClassification(_EncoderModelBase):
             extra += [("classifier.weight", (config.num_labels, config.hidden_size + extra_in)), ("classifier.bias", (config.num_labels,))]
         self._make(config, final_ln=False, extra=extra)
 
-        def _encode(pixel_values, bool_masked_pos=None, _ref=weakref.ref(self)):
+        def _encode(pixel_values, bool_masked_pos=None, output_hidden_states=None, _ref=weakref.ref(self)):
+            if output_hidden_states:
+                seq, hidden = _ref()._runner.encode(pixel_values, bool_masked_pos, True)
+                return BaseModelOutput(last_hidden_state=seq, hidden_states=hidden)
             return BaseModelOutput(last_hidden_state=_ref()._runner.encode(pixel_values, bool_masked_pos))
         object.__setattr__(self._modules["videomae"], "_encode", _encode)
 
     def forward(self, pixel_values: Optional[torch.Tensor] = None, additional_features: Optional[torch.Tensor] = None, head_mask=None,
                 labels: Optional[torch.Tensor] = None, output_attentions=None, output_hidden_states=None, return_dict=None, **kwargs):
-        self._reject(head_mask, output_attentions, output_hidden_states)
-        seq = self._runner.encode(pixel_values)
+        want = self._reject(head_mask, output_attentions, output_hidden_states)
+        seq, hidden = self._runner.encode(pixel_values, None, True) if want else (self._runner.encode(pixel_values), None)
         sd = dict(self.named_parameters())
         # the head works on [B, d]: plain tensor ops (fc_norm uses torch's default eps, spec :925)
         pooled = torch.nn.functional.layer_norm(seq.mean(1), (self.config.hidden_size,), sd["fc_norm.weight"], sd["fc_norm.bias"], 1e-5)
@@ -324,15 +352,19 @@ class SmbVideoMAEForVideoClassification(_EncoderModelBase):
             else:
                 loss = nn.functional.binary_cross_entropy_with_logits(logits, labels)
         if return_dict is False:
-            return ((loss,) if loss is not None else ()) + (logits,)
-        return ImageClassifierOutput(loss=loss, logits=logits, hidden_states=None, attentions=None)
+            return ((loss,) if loss is not None else ()) + (logits,) + ((hidden,) if want else ())
+        return ImageClassifierOutput(loss=loss, logits=logits, hidden_states=hidden, attentions=None)
 
 
-def encode_with(pretraining_model, pixel_values: torch.Tensor, bool_masked_pos: Optional[torch.Tensor] = None) -> BaseModelOutput:
+def encode_with(pretraining_model, pixel_values: torch.Tensor, bool_masked_pos: Optional[torch.Tensor] = None,
+                output_hidden_states: Optional[bool] = None) -> BaseModelOutput:
     """``model.videomae(pixel_values)`` for a ``SmbVideoMAEForPreTraining`` (``src/run_inference.py:78-83``): its encoder over all
     tokens (or the visible ones), no decoder."""
     r = getattr(pretraining_model, "_encoder_runner", None)
     if r is None:
         r = _EncoderRunner(pretraining_model, pretraining_model.config, "videomae.", final_ln=False)
         object.__setattr__(pretraining_model, "_encoder_runner", r)
+    if output_hidden_states:
+        seq, hidden = r.encode(pixel_values, bool_masked_pos, True)
+        return BaseModelOutput(last_hidden_state=seq, hidden_states=hidden)
     return BaseModelOutput(last_hidden_state=r.encode(pixel_values, bool_masked_pos))

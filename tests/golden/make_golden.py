@@ -388,8 +388,55 @@ def make_decay_names(name="decay_names"):
     print(name, {k: (len(v["decay"]), len(v["no_decay"])) for k, v in out.items() if not k.startswith("_")})
 
 
+def make_hidden_states(name="hidden_states_tiny"):
+    """output_hidden_states=True of the installed transformers classes on the EXISTING fixtures' weights and inputs (encoder_tiny, mim_tiny_p16): the
+    classes are rebuilt from the stored parameters, must reproduce the stored outputs bit for bit, and only the hidden-state tuples are written."""
+    from safetensors.torch import load_file, save_file
+    from transformers import VideoMAEConfig, VideoMAEForPreTraining, VideoMAEForVideoClassification, VideoMAEModel
+
+    out = {}
+    enc = load_file(os.path.join(HERE, "encoder_tiny.safetensors"))
+    pix, mask = enc["in.pixel_values"], enc["in.bool_masked_pos"].bool()
+    cfg = VideoMAEConfig(num_channels=1, num_labels=3, use_mean_pooling=True, **ENC_TINY)
+    cfg._attn_implementation = "eager"
+    cls = VideoMAEForVideoClassification(cfg).float().eval()
+    cls.load_state_dict(hf_state_from_pinned({k[len("cls.param."):]: v for k, v in enc.items() if k.startswith("cls.param.")}), strict=True)
+    cfg2 = VideoMAEConfig(num_channels=1, use_mean_pooling=False, **ENC_TINY)
+    cfg2._attn_implementation = "eager"
+    mdl = VideoMAEModel(cfg2).float().eval()
+    mdl.load_state_dict(hf_state_from_pinned({k[len("enc.param."):]: v for k, v in enc.items() if k.startswith("enc.param.")}), strict=True)
+    with torch.no_grad():
+        a = cls.videomae(pix, output_hidden_states=True)
+        assert torch.equal(a.last_hidden_state, enc["cls.out.last_hidden_state"])
+        b = cls.videomae(pix, bool_masked_pos=mask, output_hidden_states=True)
+        assert torch.equal(b.last_hidden_state, enc["cls.out.visible_hidden_state"])
+        c = mdl(pix, output_hidden_states=True)
+        assert torch.equal(c.last_hidden_state, enc["enc.out.last_hidden_state"])
+        full = cls(pixel_values=pix, output_hidden_states=True)
+        assert torch.equal(full.logits, enc["cls.out.logits"]) and len(full.hidden_states) == len(a.hidden_states)
+    for tag, o in (("cls.all", a), ("cls.visible", b), ("enc.all", c)):
+        assert len(o.hidden_states) == ENC_TINY["num_hidden_layers"] + 1
+        for l, h in enumerate(o.hidden_states):
+            out[f"{tag}.{l}"] = h.contiguous()
+    mim = load_file(os.path.join(HERE, "mim_tiny_p16.safetensors"))
+    mcfg = VideoMAEConfig(num_channels=1, **GOLDEN_CONFIGS["mim_tiny_p16"]["cfg"])
+    mcfg._attn_implementation = "eager"
+    m = VideoMAEForPreTraining(mcfg).float().eval()
+    m.load_state_dict(hf_state_from_pinned({k[len("param."):]: v for k, v in mim.items() if k.startswith("param.")}), strict=True)
+    with torch.no_grad():
+        o = m(pixel_values=mim["in.pixel_values"], bool_masked_pos=mim["in.bool_masked_pos"].bool(), output_hidden_states=True)
+    assert torch.equal(o.logits, mim["out.logits"]) and float(o.loss) == float(mim["out.loss"])
+    assert len(o.hidden_states) == mcfg.num_hidden_layers + 1
+    for l, h in enumerate(o.hidden_states):
+        out[f"mim.{l}"] = h.contiguous()
+    meta = {"generator": "transformers VideoMAEModel / VideoMAEForVideoClassification / VideoMAEForPreTraining fp32 eager CPU, output_hidden_states=True, on the "
+                         "parameters and inputs of encoder_tiny.safetensors / mim_tiny_p16.safetensors", "transformers": __import__("transformers").__version__, "torch": torch.__version__}
+    save_file(out, os.path.join(HERE, name + ".safetensors"), metadata=meta)
+    print(name, {k: tuple(v.shape) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["mim", "vjepa", "encoder"]
+    which = sys.argv[1:] or ["mim", "vjepa", "encoder", "hidden"]
     if "mim" in which:
         make_masks()
         for n, s in GOLDEN_CONFIGS.items():
@@ -401,5 +448,7 @@ if __name__ == "__main__":
         make_vjepa_multimask()
     if "encoder" in which:
         make_encoder()
+    if "hidden" in which:
+        make_hidden_states()
     if "decay" in which:
         make_decay_names()

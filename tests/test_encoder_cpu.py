@@ -42,6 +42,29 @@ def test_oracle_matches_reference_encoder_outputs(blob):
         assert rel(mo.encoder_forward(pe, ocfg(), pix, None, prefix="", final_ln=True), blob["enc.out.last_hidden_state"]) < 1e-5
 
 
+def test_oracle_hidden_states_match_the_reference_classes(blob):
+    """output_hidden_states=True (spec :452-457, 478-483): the oracle's per-layer residual stream against tests/golden/hidden_states_tiny.safetensors
+    (make_golden.py make_hidden_states: the installed transformers classes on this fixture's weights; they reproduced its stored outputs bit for bit)."""
+    hs = load_file(os.path.join(G, "hidden_states_tiny.safetensors"))
+    p, pe = _params(blob, "cls.param."), _params(blob, "enc.param.")
+    pix, mask = blob["in.pixel_values"], blob["in.bool_masked_pos"].bool()
+    with torch.no_grad():
+        for tag, params, m, prefix, fl in (("cls.all", p, None, "videomae.", False), ("cls.visible", p, mask, "videomae.", False), ("enc.all", pe, None, "", True)):
+            got = []
+            mo.encoder_forward(params, ocfg(), pix, m, prefix=prefix, final_ln=fl, hidden_states=got)
+            assert len(got) == CFG["num_hidden_layers"] + 1
+            for l, h in enumerate(got):
+                assert h.shape == hs[f"{tag}.{l}"].shape and rel(h, hs[f"{tag}.{l}"]) < 1e-5, (tag, l)
+        # the pre-training model hands on its ENCODER's hidden states (visible tokens; spec :900-907)
+        mim = load_file(os.path.join(G, "mim_tiny_p16.safetensors"))
+        mc = mo.MIMConfig(image_size=64, num_frames=32, patch_size=16, tubelet_size=16, hidden_size=64, num_hidden_layers=2, num_attention_heads=1, intermediate_size=256,
+                          decoder_hidden_size=64, decoder_num_hidden_layers=1, decoder_num_attention_heads=1, decoder_intermediate_size=128)
+        got = []
+        mo.encoder_forward(_params(mim, "param."), mc, mim["in.pixel_values"], mim["in.bool_masked_pos"].bool(), hidden_states=got)
+        for l, h in enumerate(got):
+            assert rel(h, hs[f"mim.{l}"]) < 1e-5, l
+
+
 def test_oracle_fine_tune_gradients_match_reference(blob):
     p = {k: v.clone().requires_grad_(True) for k, v in _params(blob, "cls.param.").items()}
     logits = mo.classification_forward(p, ocfg(), blob["in.pixel_values"])

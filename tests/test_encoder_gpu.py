@@ -84,6 +84,86 @@ def test_model_with_final_layernorm(blob):
     close(out.last_hidden_state, blob["enc.out.last_hidden_state"])
 
 
+def test_output_hidden_states_of_every_class_match_the_reference(blob):
+    """output_hidden_states=True (spec :452-457, 478-483, 596-599, 900-907): the embedding output and every layer's output, NOT the final LayerNorm's - out of the
+    step workspace (smbv_encoder_hidden_states / smbv_mim_hidden_states, ABI 3006) against tests/golden/hidden_states_tiny.safetensors (the installed transformers
+    classes on this fixture's weights).  Inference, fine-tuning (autograd on), by config, as a tuple, through model.videomae(...), the pre-training model in its
+    three modes; the outputs beside them are unchanged."""
+    from transformers import VideoMAEConfig
+    from smb_vision_amd.modeling_videomae import SmbVideoMAEForPreTraining
+    from smb_vision_amd.modeling_videomae_encoder import SmbVideoMAEForVideoClassification, SmbVideoMAEModel
+    hs = load_file(os.path.join(G, "hidden_states_tiny.safetensors"))
+    pix, mask = blob["in.pixel_values"].cuda(), blob["in.bool_masked_pos"].bool().cuda()
+
+    def check(got, tag, n=3):
+        assert isinstance(got, tuple) and len(got) == n
+        for l, h in enumerate(got):
+            assert h.dtype == torch.float32 and not h.requires_grad and tuple(h.shape) == tuple(hs[f"{tag}.{l}"].shape)
+            close(h, hs[f"{tag}.{l}"])
+
+    m = SmbVideoMAEForVideoClassification(VideoMAEConfig(num_channels=1, num_labels=3, use_mean_pooling=True, **CFG))
+    m.load_state_dict(_params(blob, "cls.param."), strict=True)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        plain = m(pixel_values=pix)
+        assert plain.hidden_states is None
+        out = m(pixel_values=pix, output_hidden_states=True)
+        check(out.hidden_states, "cls.all")
+        assert torch.equal(out.logits, plain.logits)          # the per-layer workspace form computes what the shared-set form computes
+        check(m.videomae(pix, output_hidden_states=True).hidden_states, "cls.all")
+        vis = m.videomae(pix, bool_masked_pos=mask, output_hidden_states=True)
+        check(vis.hidden_states, "cls.visible")
+        close(vis.last_hidden_state, blob["cls.out.visible_hidden_state"])
+        tup = m(pixel_values=pix, output_hidden_states=True, return_dict=False)
+        assert len(tup) == 2 and torch.equal(tup[0], plain.logits)
+        check(tup[1], "cls.all")
+        assert m.videomae(pix).hidden_states is None          # and back to the inference workspace
+    # fine-tuning: autograd on, the hidden states are detached copies, the backward still runs
+    m.train()
+    out = m(pixel_values=pix, labels=blob["in.labels"].cuda(), output_hidden_states=True)
+    check(out.hidden_states, "cls.all")
+    out.loss.backward()
+    g = dict(m.named_parameters())["videomae.encoder.layer.0.attention.attention.query.weight"].grad
+    r = blob["cls.grad.videomae.encoder.layer.0.attention.attention.query.weight"]
+    assert float((g.cpu() - r).norm() / r.norm()) < 8e-2
+    # resolved from the config when the argument is None (spec :596-599); the final LayerNorm is not part of the tuple
+    cfg = VideoMAEConfig(num_channels=1, use_mean_pooling=False, output_hidden_states=True, **CFG)
+    e = SmbVideoMAEModel(cfg)
+    e.load_state_dict(_params(blob, "enc.param."), strict=True)
+    e = e.cuda().eval()
+    with torch.no_grad():
+        out = e(pix)
+        check(out.hidden_states, "enc.all")
+        close(out.last_hidden_state, blob["enc.out.last_hidden_state"])
+        assert e(pix, output_hidden_states=False).hidden_states is None
+        with pytest.raises(NotImplementedError):
+            e(pix, output_attentions=True)
+    # the pre-training model hands on its encoder's hidden states over the visible tokens
+    mim = load_file(os.path.join(G, "mim_tiny_p16.safetensors"))
+    mc = dict(image_size=64, num_frames=32, patch_size=16, tubelet_size=16, hidden_size=64, num_hidden_layers=2, num_attention_heads=1, intermediate_size=256,
+              decoder_hidden_size=64, decoder_num_hidden_layers=1, decoder_num_attention_heads=1, decoder_intermediate_size=128)
+    mpix, mmask = mim["in.pixel_values"].cuda(), mim["in.bool_masked_pos"].bool().cuda()
+    for extra in ({}, {"smbv_recompute": "always"}):
+        pm = SmbVideoMAEForPreTraining(VideoMAEConfig(num_channels=1, **mc, **extra))
+        pm.load_state_dict(_params(mim, "param."), strict=True)
+        pm = pm.cuda().train()
+        if extra:
+            pm.gradient_checkpointing_enable()
+        out = pm(pixel_values=mpix, bool_masked_pos=mmask, output_hidden_states=True)
+        check(out.hidden_states, "mim")
+        assert float(out.loss) == pytest.approx(float(mim["out.loss"]), rel=5e-3)
+        out.loss.backward()                                    # the backward reads the same workspace the copies were taken from
+        k0 = "videomae.encoder.layer.0.attention.attention.query.weight"
+        assert float((dict(pm.named_parameters())[k0].grad.cpu() - mim["grad." + k0]).norm() / mim["grad." + k0].norm()) < 2.5e-2
+        with torch.no_grad():
+            tup = pm(pixel_values=mpix, bool_masked_pos=mmask, output_hidden_states=True, return_dict=False)
+        assert len(tup) == 3
+        check(tup[2], "mim")
+        assert pm(pixel_values=mpix, bool_masked_pos=mmask).hidden_states is None
+        with pytest.raises(NotImplementedError):
+            pm(pixel_values=mpix, bool_masked_pos=mmask, output_attentions=True)
+
+
 def test_pretraining_model_videomae_call_matches_its_own_encoder(blob):
     """model.videomae(image) on SmbVideoMAEForPreTraining: same encoder weights as the classification golden -> same embeddings."""
     from transformers import VideoMAEConfig
