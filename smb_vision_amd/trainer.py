@@ -142,7 +142,7 @@ def _is_native(model) -> bool:
 
 
 class SmbTrainer(Trainer):
-    def __init__(self, *args, dp_bucket_bytes: int = 32 << 20, dp_grad_dtype: str = None, **kwargs):
+    def __init__(self, *args, dp_bucket_bytes: int = 25 << 20, dp_grad_dtype: str = None, **kwargs):
         self._dp_bucket_bytes = dp_bucket_bytes
         # what the gradient all-reduce ships: "fp32" (default, DDP's plain buckets) or "bf16" (DDP's bf16_compress_hook: half the xGMI bytes); SMBV_DP_GRAD_DTYPE
         self._dp_grad_dtype = dp_grad_dtype or os.environ.get("SMBV_DP_GRAD_DTYPE", "fp32")
