@@ -12,7 +12,7 @@ absent and the reference holds no fixture; ``tests/test_nifti_cpu.py`` pins this
   ``scl_slope`` / ``scl_inter`` value scaling, the voxel-to-world affine from the sform rows, else from the qform quaternion, else from ``pixdim``;
 * ``Orientation("RAS")``: the closest axis permutation / flips of the affine's rotation part (polar factor by SVD, one output axis per input axis by largest
   absolute component), applied as flips and a transpose of the array;
-* ``Spacing(pixdim, mode="bilinear")``: output shape ``round((n - 1) * in_spacing / out_spacing) + 1`` per axis (first voxel centres coincide), trilinear
+* ``Spacing(pixdim, mode="bilinear")``: output shape ``round((n - 1) * in_spacing / out_spacing + 1)`` per axis (numpy's round-half-to-even applied AFTER the + 1, as MONAI's ``compute_shape_offset`` does; first voxel centres coincide), trilinear
   interpolation at ``i * out_spacing / in_spacing`` clamped to the volume ("border" padding), evaluated axis by axis in float32.
 
     python -m smb_vision_amd.nifti --json_path dataset.json --out_dir /data/cache      # {"train": [{"image": path}, ...], "validation": [...]}
@@ -154,7 +154,10 @@ def resample_spacing(vol: np.ndarray, spacing: Sequence[float], pixdim: Sequence
     out = vol.astype(np.float32)
     for ax in range(3):
         n_in = out.shape[ax]
-        n_out = int(np.round((n_in - 1) * spacing[ax] / pixdim[ax])) + 1
+        # MONAI sizes the output as np.round(extent + 1.0) (monai/data/utils.py compute_shape_offset, scale_extent=False), the extent being the distance between the
+        # first and last voxel centres in output voxels - NOT round(extent) + 1: numpy rounds halves to even, so the two differ whenever the extent ends in .5
+        # (512 voxels at 0.75 mm onto 1.5 mm: extent 255.5 -> 256 voxels, not 257)
+        n_out = int(np.round((n_in - 1) * (spacing[ax] / pixdim[ax]) + 1.0))
         out = _lerp_axis(out, ax, max(n_out, 1), pixdim[ax] / spacing[ax])
     return np.ascontiguousarray(out)
 

@@ -111,18 +111,22 @@ def test_reorientation_to_ras_from_sform_qform_and_pixdim(tmp_path):
 
 def test_spacing_resample_is_trilinear_with_coinciding_first_voxels():
     """Spacing(pixdim=(1.5, 1.5, 3.0), "bilinear"): a linear field is reproduced exactly at the new voxel centres (trilinear interpolation is exact on it), the shape is
-    round((n - 1) * in / out) + 1, the last samples are clamped to the border, and a volume already at the target spacing comes back untouched in its own dtype."""
+    round((n - 1) * in / out + 1) - numpy's round-half-to-even applied AFTER the + 1, as MONAI's compute_shape_offset sizes it -, the last samples are clamped to the border,
+    and a volume already at the target spacing comes back untouched in its own dtype."""
     shape, sp = (21, 17, 9), (0.75, 1.0, 4.0)
     x, y, z = ramp(shape)
     f = (2.0 * x * sp[0] - 3.0 * y * sp[1] + 0.5 * z * sp[2]).astype(np.float32)   # linear in millimetres
     out = nifti.resample_spacing(f, sp, (1.5, 1.5, 3.0))
-    exp_shape = tuple(int(np.round((n - 1) * s / p)) + 1 for n, s, p in zip(shape, sp, (1.5, 1.5, 3.0)))
+    exp_shape = tuple(int(np.round((n - 1) * (s / p) + 1.0)) for n, s, p in zip(shape, sp, (1.5, 1.5, 3.0)))
     assert out.shape == exp_shape == (11, 12, 12) and out.dtype == np.float32
     xo, yo, zo = ramp(exp_shape)
     mm = [np.minimum(o * p, (n - 1) * s) for o, p, n, s in zip((xo, yo, zo), (1.5, 1.5, 3.0), shape, sp)]   # positions past the last voxel clamp to it
     assert np.allclose(out, 2.0 * mm[0] - 3.0 * mm[1] + 0.5 * mm[2], atol=1e-4)
     same = np.arange(24, dtype=np.int16).reshape(2, 3, 4)
     assert nifti.resample_spacing(same, (1.5, 1.5, 3.0)) is same
+    # extents that end in .5 (every even voxel count at 0.75 mm onto 1.5 mm): np.round(extent + 1.0) rounds the half to even AFTER the + 1 - 512 voxels become 256, not 257
+    for n, want in ((20, 10), (22, 12), (512, 256), (511, 256), (513, 257)):
+        assert nifti.resample_spacing(np.zeros((n, 2, 2), np.float32), (0.75, 1.5, 3.0)).shape == (want, 2, 2), n
 
 
 def test_convert_feeds_the_cached_volume_dataset(tmp_path):
@@ -142,7 +146,7 @@ def test_convert_feeds_the_cached_volume_dataset(tmp_path):
     ra, rb = ds[0]["volume"], ds[1]["volume"]
     assert ra.shape == (12, 10, 6) and ra.code == 0 and np.array_equal(np.asarray(ra.array()), a)                  # flipped back to RAS, still int16
     assert ra.spacing == (1.5, 1.5, 3.0) and ra.window == (-1000.0, 1000.0, 0.0, 1.0, True)
-    assert rb.shape == (11, 11, 8) and rb.code == 3                                                               # round(19 * 0.75 / 1.5) + 1 = 11 (numpy rounds 9.5 to 10), float32
+    assert rb.shape == (10, 10, 8) and rb.code == 3                                                               # round(19 * 0.75 / 1.5 + 1) = round(10.5) = 10 (half to even, after the + 1), float32
     ref = nifti.resample_spacing(b, (0.75, 0.75, 3.0))
     assert np.allclose(np.asarray(rb.array()), ref)
     assert np.allclose(np.asarray(rb.array())[:, :, 0][::1, ::1][0, 0], b[0, 0, 0])
