@@ -111,13 +111,13 @@ def _axis_map(aff: np.ndarray):
     zooms[zooms == 0] = 1.0
     u, _, vt = np.linalg.svd(rzs / zooms)
     rot = u @ vt                                     # polar factor: the orthogonal matrix closest to the (possibly sheared) direction cosines
-    out, taken = [None] * 3, set()
-    for in_ax in np.argsort(-np.abs(rot).max(axis=0)):  # most axis-aligned column first, so that ties cannot strand an axis
-        col = np.abs(rot[:, in_ax]).copy()
-        col[list(taken)] = -1.0
-        w = int(np.argmax(col))
-        taken.add(w)
-        out[in_ax] = (w, 1.0 if rot[w, in_ax] >= 0 else -1.0)
+    out = [None] * 3
+    rot = rot.copy()
+    for in_ax in range(3):   # nibabel's io_orientation walks the array axes in order and removes a world axis once it is taken (its row is zeroed): mirrored for oblique volumes
+        col = rot[:, in_ax]
+        w = int(np.argmax(np.abs(col)))
+        out[in_ax] = (w, 1.0 if col[w] >= 0 else -1.0)
+        rot[w, :] = 0.0
     return out, zooms
 
 
