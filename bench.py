@@ -166,20 +166,29 @@ def reference_class_baseline(threads):
     mask = MaskGenerator(512, 320, 32, 16, 0.65)().unsqueeze(0)
     pix = torch.rand(1, 320, 1, 512, 512, generator=torch.Generator().manual_seed(1234))
 
-    def one(cfg_kw):
+    def one(cfg_kw, bf16=False):
         cfg = VideoMAEConfig(**cfg_kw)
         cfg._attn_implementation = "sdpa"
         torch.manual_seed(42)
         m = VideoMAEForPreTraining(cfg).float().train()
         t0 = time.perf_counter()
-        out = m(pixel_values=pix, bool_masked_pos=mask)
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=bf16):
+            out = m(pixel_values=pix, bool_masked_pos=mask)
         out.loss.backward()
-        return time.perf_counter() - t0, float(out.loss)
+        return time.perf_counter() - t0, float(out.loss.detach())
 
     one(dict(VIT_BASE, num_hidden_layers=2, decoder_num_hidden_layers=1))
     dt, loss = one(VIT_BASE)
-    return dict(value=1.0 / dt, unit="volumes/s", seconds_per_step=round(dt, 2), loss=loss, cores=threads,
-                what="transformers.VideoMAEForPreTraining (the reference's model class, src/run_mim.py:13-21), fp32, sdpa, forward + loss + backward, 1 timed step")
+    res = dict(value=1.0 / dt, unit="volumes/s", seconds_per_step=round(dt, 2), loss=loss, cores=threads,
+               what="transformers.VideoMAEForPreTraining (the reference's model class, src/run_mim.py:13-21), fp32, sdpa, forward + loss + backward, 1 timed step")
+    try:  # "fp32 and bf16-autocast" - the precision policy the reference trains under (--bf16 true), on the same cores
+        one(dict(VIT_BASE, num_hidden_layers=2, decoder_num_hidden_layers=1), bf16=True)
+        dtb, lossb = one(VIT_BASE, bf16=True)
+        res["bf16_autocast"] = dict(value=1.0 / dtb, unit="volumes/s", seconds_per_step=round(dtb, 2), loss=lossb,
+                                    what="the same class and step under torch.autocast('cpu', bfloat16), 1 timed step")
+    except Exception as e:
+        res["bf16_autocast"] = {"error": repr(e)}
+    return res
 
 
 class _FedSource:
