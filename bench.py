@@ -625,6 +625,9 @@ def main():
                        "tokens": model.num_patches, "masked": n_masked, "parallelism": f"dp{world}", "final_loss": final_loss,
                        "resident_ms_per_step": ms, "replicas_in_sync": in_sync},
         }
+        if dp is not None and dp._buckets:   # what travelled: the all-reduce plan of the last step (dp.py) and whether the host had every bucket's collective queued before its gradients existed
+            line["config"]["dp"] = {"backend": args.backend, "grad_dtype": dp.grad_dtype, "bucket_MB": [round((b - a) * 4 / 1e6, 1) for a, b, _ in dp._buckets],
+                                    "overlap": dp.comm_stream is not None, "enqueued_before_ready": [bool(x) for x in dp.enqueue_lead]}
         if fed is not None:
             line["fed"] = fed
         step_flop = 64.41 if args.vit_large else STEP_TFLOP

@@ -336,6 +336,9 @@ def test_bench_launches_its_own_ranks_without_a_launcher():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["replicas_in_sync"] is True and line["config"]["parallelism"] == "dp2"
     assert line["steps"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and line["roofline"]["frac"] > 0
+    # the all-reduce plan travels in the line: 25-MB buckets - every ViT-base encoder block on its own, 388.7 MB in all (dp.py)
+    plan = line["config"]["dp"]
+    assert plan["grad_dtype"] == "fp32" and len(plan["bucket_MB"]) == 14 and abs(sum(plan["bucket_MB"]) - 388.7) < 1.5 and plan["bucket_MB"][-1] < 13
     # a rank that fails must fail the launch: an unknown backend makes every rank raise in init_process_group
     bad = subprocess.run([a if a != "gloo" else "no-such-backend" for a in cmd], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and not bad.stdout.strip()
