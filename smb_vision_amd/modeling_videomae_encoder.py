@@ -292,6 +292,10 @@ class SmbVideoMAEModel(_EncoderModelBase):
         super().__init__(config)
         self._make(config, final_ln=not getattr(config, "use_mean_pooling", True))
 
+    def get_input_embeddings(self):
+        """``VideoMAEModel.get_input_embeddings`` (spec :525-526): the patch-embedding node (here the container of ``projection.{weight,bias}``)."""
+        return self._modules["embeddings"]._modules["patch_embeddings"]
+
     def forward(self, pixel_values: torch.Tensor = None, bool_masked_pos: Optional[torch.Tensor] = None, head_mask=None, output_attentions=None,
                 output_hidden_states=None, return_dict=None, **kwargs):
         want = self._reject(head_mask, output_attentions, output_hidden_states)

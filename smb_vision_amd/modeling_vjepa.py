@@ -401,6 +401,15 @@ class SmbVJEPA2Model(PreTrainedModel):
             self.dp.allreduce_after_backward(self)
         return self.grad_views()
 
+    def get_vision_features(self, pixel_values_videos) -> torch.Tensor:
+        """``VJEPA2Model.get_vision_features`` (modeling_vjepa.py:1165-1167): the encoder's ``last_hidden_state`` over every token.  The reference runs its
+        predictor as well and throws the result away; the encoder output does not depend on it, so it is skipped here."""
+        return self.forward(pixel_values_videos, skip_predictor=True).last_hidden_state
+
+    def get_input_embeddings(self):
+        """``VJEPA2Model.get_input_embeddings`` (:1076-1077): the patch-embedding node (here the container of ``proj_3d.{weight,bias}``)."""
+        return self._modules["encoder"]._modules["embeddings"]._modules["patch_embeddings"]
+
     # -- data parallel hooks (smb_vision_amd.dp.DataParallelEngine) --------------------------------------------------------------
     def flat_grads(self) -> torch.Tensor:
         return self._gflat

@@ -81,6 +81,8 @@ def test_drop_in_class_surface(blob):
     from smb_vision_amd.modeling_videomae_encoder import SmbVideoMAEForVideoClassification, SmbVideoMAEModel
     m = SmbVideoMAEForVideoClassification(VideoMAEConfig(num_channels=1, num_labels=3, use_mean_pooling=True, **CFG))
     assert set(dict(m.named_parameters())) == set(_params(blob, "cls.param."))
+    e0 = SmbVideoMAEModel(VideoMAEConfig(num_channels=1, use_mean_pooling=False, **CFG))
+    assert set(dict(e0.get_input_embeddings().named_parameters())) == {"projection.weight", "projection.bias"}   # spec :525-526
     assert not m.load_state_dict(_params(blob, "cls.param."), strict=True).missing_keys
     e = SmbVideoMAEModel(VideoMAEConfig(num_channels=1, use_mean_pooling=False, **CFG))
     assert set(dict(e.named_parameters())) == set(_params(blob, "enc.param."))

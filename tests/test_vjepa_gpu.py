@@ -143,6 +143,10 @@ def test_vjepa_step_matches_reference_golden():
     with torch.no_grad():
         full = model(pixel_values_videos=pix, context_mask=[cm], target_mask=[tm])   # the reference's forward: every output
     assert rel(full.last_hidden_state.cpu(), blob["out.last_hidden_state"]) < 3e-2
+    with torch.no_grad():   # get_vision_features (modeling_vjepa.py:1165-1167): no masks, the encoder over every token - the same last_hidden_state
+        feats = model.get_vision_features(pix)
+    assert feats.shape == full.last_hidden_state.shape and rel(feats.cpu(), blob["out.last_hidden_state"]) < 3e-2
+    assert dict(model.get_input_embeddings().named_parameters()).keys() == {"proj_3d.weight", "proj_3d.bias"}
     assert rel(full.predictor_output.last_hidden_state.cpu(), blob["out.predictor"]) < 3e-2
     assert rel(out.masked_hidden_state.cpu(), full.masked_hidden_state.cpu()) < 2e-3
     assert rel(out.predictor_output.last_hidden_state.detach().cpu(), blob["out.predictor"]) < 3e-2
